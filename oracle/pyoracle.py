@@ -1,0 +1,105 @@
+"""ctypes binding to oracle/liboracle.so (the plain-C CPU restatement, oracle/smash_oracle.c).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from .refbind import GLB_P, GLB_S, GNP, GNS, GUB_P, GUB_S, JOBS, JREG, STRUCTURES, pack, unpack
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [("structure", C.c_int), ("nrow", C.c_int), ("ncol", C.c_int), ("nt", C.c_int), ("ng", C.c_int),
+                ("denormalize_forward", C.c_int), ("optimize_start_step", C.c_int), ("njf", C.c_int),
+                ("jobs_fun", C.c_int * 8), ("wjobs_fun", C.c_float * 8), ("njr", C.c_int),
+                ("jreg_fun", C.c_int * 4), ("wjreg_fun", C.c_float * 4), ("wjreg", C.c_float),
+                ("dt", C.c_float), ("dx", C.c_float), ("optim_parameters", C.c_int * GNP),
+                ("optim_states", C.c_int * GNS), ("lb_parameters", C.c_float * GNP),
+                ("ub_parameters", C.c_float * GNP), ("lb_states", C.c_float * GNS), ("ub_states", C.c_float * GNS)]
+
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        _lib.orc_forward.restype = C.c_int
+        _lib.orc_forward_b.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, params_bgd=None,
+        states_bgd=None, denormalize_forward=False, optimize_start_step=1, jobs_fun=("nse",),
+        wjobs_fun=(1.0,), jreg_fun=(), wjreg_fun=(), wjreg=0.0, wgauge=None, optim_parameters=None,
+        optim_states=None, lb_parameters=None, ub_parameters=None, lb_states=None, ub_states=None,
+        cost_b=1.0):
+    """Same calling convention and result dict as oracle.refbind.run (dense forcing only)."""
+    from smash_amd.synth import PARAM_NAMES, STATE_NAMES
+    L = lib()
+    nrow, ncol, ng = mesh.nrow, mesh.ncol, mesh.ng
+    nt = prcp.shape[2]
+    cfg = OrcConfig()
+    cfg.structure, cfg.nrow, cfg.ncol, cfg.nt, cfg.ng = STRUCTURES[structure], nrow, ncol, nt, ng
+    cfg.denormalize_forward, cfg.optimize_start_step = int(denormalize_forward), optimize_start_step
+    cfg.njf = len(jobs_fun)
+    for i, j in enumerate(jobs_fun):
+        cfg.jobs_fun[i], cfg.wjobs_fun[i] = JOBS[j], wjobs_fun[i]
+    cfg.njr = len(jreg_fun)
+    for i, j in enumerate(jreg_fun):
+        cfg.jreg_fun[i], cfg.wjreg_fun[i] = JREG[j], wjreg_fun[i]
+    cfg.wjreg, cfg.dt, cfg.dx = wjreg, dt, mesh.dx
+    for i in range(GNP):
+        cfg.optim_parameters[i] = 0 if optim_parameters is None else int(optim_parameters[i])
+        cfg.lb_parameters[i] = (GLB_P if lb_parameters is None else lb_parameters)[i]
+        cfg.ub_parameters[i] = (GUB_P if ub_parameters is None else ub_parameters)[i]
+    for i in range(GNS):
+        cfg.optim_states[i] = 0 if optim_states is None else int(optim_states[i])
+        cfg.lb_states[i] = (GLB_S if lb_states is None else lb_states)[i]
+        cfg.ub_states[i] = (GUB_S if ub_states is None else ub_states)[i]
+    P = pack(params, PARAM_NAMES, nrow, ncol)
+    S = pack(states, STATE_NAMES, nrow, ncol)
+    Pb = pack(params_bgd, PARAM_NAMES, nrow, ncol) if params_bgd is not None else P.copy(order="F")
+    Sb = pack(states_bgd, STATE_NAMES, nrow, ncol) if states_bgd is not None else S.copy(order="F")
+    wg = np.full(max(ng, 1), 1.0 / max(ng, 1), np.float32) if wgauge is None else np.ascontiguousarray(wgauge, np.float32)
+    f32 = lambda a: np.asfortranarray(a, dtype=np.float32)
+    i32 = lambda a: np.asfortranarray(a, dtype=np.int32)
+    flwdir, flwacc, path, active, gpos = i32(mesh.flwdir), i32(mesh.flwacc), i32(mesh.path), i32(mesh.active_cell), i32(mesh.gauge_pos)
+    area = np.ascontiguousarray(mesh.area, np.float32)
+    prcp, pet, qobs = f32(prcp), f32(pet), f32(qobs)
+    qsim = np.zeros((max(ng, 1), nt), np.float32, order="F")
+    costs = np.zeros(3, np.float32)
+    fstates = np.zeros((nrow, ncol, GNS), np.float32, order="F")
+    p_b = np.zeros((nrow, ncol, GNP), np.float32, order="F")
+    s_b = np.zeros((nrow, ncol, GNS), np.float32, order="F")
+    common = [C.byref(cfg), _p(flwdir), _p(flwacc), _p(path), _p(active), _p(gpos), _p(area), _p(prcp), _p(pet),
+              _p(qobs), _p(wg), _p(P), _p(Pb), _p(S), _p(Sb)]
+    if adjoint:
+        rc = L.orc_forward_b(*common, C.c_float(cost_b), _p(qsim), _p(costs), _p(p_b), _p(s_b))
+    else:
+        rc = L.orc_forward(*common, _p(qsim), _p(costs), _p(fstates))
+    if rc != 0:
+        raise RuntimeError(f"oracle returned {rc}")
+    return dict(qsim=qsim[:ng], cost=float(costs[0]), cost_jobs=float(costs[1]), cost_jreg=float(costs[2]),
+                fstates=unpack(fstates, STATE_NAMES), parameters=unpack(P, PARAM_NAMES),
+                states=unpack(S, STATE_NAMES), parameters_b=unpack(p_b, PARAM_NAMES),
+                states_b=unpack(s_b, STATE_NAMES))

@@ -1,0 +1,46 @@
+#!/usr/bin/env bash
+# Build the UNMODIFIED reference solver (Fortran 90 + adStack.c + lbfgsb.f) from the sources where
+# they lie under /root/reference into oracle/_ref/ (git-ignored), plus our own bind(C) driver
+# (oracle/ref/ref_capi.f90) -> oracle/_ref/libsmash_ref.so.
+#
+# Test infrastructure only.  No reference source is copied: the compiler reads the files in place.
+# Compile order = the reference's makefile.dep:11-41.  Flags per SURVEY Appendix D:
+#   -O2 -ffp-contract=off  (bit-identical to -O0; no FMA contraction) = the parity oracle build.
+# A second build with the reference's own optimisation level (-O3 -march=native, makefile:6) is
+# produced as libsmash_ref_fast.so and is only used as the timed CPU baseline ("reference" kind).
+set -euo pipefail
+REF=${SMASH_REFERENCE:-/root/reference}
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="$HERE/../_ref"
+FC=${FC:-/opt/rocm/lib/llvm/bin/flang}
+CC=${CC:-gcc}
+S="$REF/smash/solver"
+if [ ! -d "$S" ]; then echo "build_ref: $S not present, skipping (prebuilt oracle/_ref is used)"; exit 0; fi
+
+ORDER="global/md_constant derived_type/mwd_setup derived_type/mwd_mesh derived_type/mwd_input_data
+derived_type/mwd_states derived_type/mwd_output derived_type/mwd_parameters forward/mw_forward
+operator/md_gr_operator operator/md_routing_operator operator/md_vic_operator forward/md_forward_structure
+routine/m_array_creation routine/m_array_manipulation routine/m_sort routine/m_statistic
+routine/mw_derived_type_copy routine/mw_derived_type_update routine/mw_mask routine/mw_sparse_storage
+routine/mw_interception_store routine/mw_forcing_statistic routine/mwd_parameters_manipulation
+routine/mwd_states_manipulation optimize/mwd_cost routine/mw_multiple_run optimize/mw_optimize
+optimize/mw_adjoint_test forward/forward_db forward/forward"
+
+build_variant () {  # $1 = subdir, $2 = lib name, rest = flags
+  local sub=$1 lib=$2; shift 2
+  local obj="$OUT/$sub"; mkdir -p "$obj"
+  $CC -O2 -fPIC -c "$S/tapenade/adStack.c" -o "$obj/adStack.o"
+  $FC "$@" -fPIC -c "$S/optimize/lbfgsb.f" -o "$obj/lbfgsb.o"
+  for f in $ORDER; do
+    b=$(basename "$f")
+    $FC -cpp "$@" -fPIC -module-dir "$obj" -I"$obj" -c "$S/$f.f90" -o "$obj/$b.o"
+  done
+  $FC -cpp "$@" -fPIC -module-dir "$obj" -I"$obj" -c "$HERE/ref_capi.f90" -o "$obj/ref_capi.o"
+  $FC -shared -o "$OUT/$lib" "$obj"/*.o
+  echo "built $OUT/$lib"
+}
+
+build_variant obj_parity libsmash_ref.so      -O2 -ffp-contract=off
+if [ "${REF_FAST:-1}" = "1" ]; then
+  build_variant obj_fast   libsmash_ref_fast.so -O3 -march=x86-64-v3 -funroll-loops
+fi

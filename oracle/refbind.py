@@ -1,0 +1,129 @@
+"""ctypes binding to oracle/_ref/libsmash_ref.so -- the UNMODIFIED reference Fortran solver built by
+oracle/ref/build_ref.sh, driven through oracle/ref/ref_capi.f90.
+
+TEST INFRASTRUCTURE: imported only by tests/, tests/golden/make_golden.py, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg.  Never imported by the product package smash_amd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GNP, GNS = 16, 8
+STRUCTURES = {"gr-a": 1, "gr-b": 2, "gr-c": 3, "gr-d": 4}
+JOBS = {"nse": 1, "kge": 2, "kge2": 3, "se": 4, "rmse": 5, "logarithmic": 6}
+JREG = {"prior": 1, "smoothing": 2, "hard_smoothing": 3}
+GLB_P = np.array([1e-6] * 6 + [-50.0] + [1e-6] * 9, dtype=np.float32)
+GUB_P = np.array([1e2, 1e3, 1e3, 1e3, 1e4, 0.999999, 50.0, 1e1, 2e3, 2e3, 2e3, 1e4, 0.999999, 30.0,
+                  0.999999, 1e3], dtype=np.float32)
+GLB_S = np.array([1e-6] * 8, dtype=np.float32)
+GUB_S = np.array([0.999999] * 7 + [10000.0], dtype=np.float32)
+
+
+def lib_path(fast: bool = False) -> str:
+    return os.path.join(_HERE, "_ref", "libsmash_ref_fast.so" if fast else "libsmash_ref.so")
+
+
+def available(fast: bool = False) -> bool:
+    return os.path.exists(lib_path(fast))
+
+
+_libs = {}
+
+
+def _lib(fast):
+    if fast not in _libs:
+        _libs[fast] = C.CDLL(lib_path(fast))
+    return _libs[fast]
+
+
+def _f(a, dtype):
+    return np.asfortranarray(a, dtype=dtype)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pack(fields: dict, names, nrow, ncol):
+    out = np.zeros((nrow, ncol, len(names)), dtype=np.float32, order="F")
+    for i, n in enumerate(names):
+        out[:, :, i] = fields[n]
+    return out
+
+
+def unpack(a, names):
+    return {n: np.asfortranarray(a[:, :, i]) for i, n in enumerate(names)}
+
+
+def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, params_bgd=None,
+        states_bgd=None, sparse_storage=False, denormalize_forward=False, optimize_start_step=1,
+        jobs_fun=("nse",), wjobs_fun=(1.0,), jreg_fun=(), wjreg_fun=(), wjreg=0.0, wgauge=None,
+        optim_parameters=None, optim_states=None, lb_parameters=None, ub_parameters=None,
+        lb_states=None, ub_states=None, cost_b=1.0, nrep=1, fast=False):
+    """Call the reference forward / forward_b (mw_forward.f90:18-68) on flat arrays.
+
+    mesh: object with nrow, ncol, dx, flwdir, flwacc, path (0-based), active_cell, gauge_pos (0-based),
+    area.  params/states: dict name -> (nrow, ncol) float32.  Returns a dict of outputs."""
+    from smash_amd.synth import PARAM_NAMES, STATE_NAMES
+    lib = _lib(fast)
+    nrow, ncol, ng = mesh.nrow, mesh.ncol, mesh.ng
+    nt = prcp.shape[2]
+    jobs_fun, jreg_fun = list(jobs_fun), list(jreg_fun)
+    icfg = np.array([STRUCTURES[structure], nrow, ncol, nt, ng, int(sparse_storage),
+                     int(denormalize_forward), optimize_start_step, len(jobs_fun), len(jreg_fun),
+                     int(adjoint), nrep], dtype=np.int32)
+    rcfg = np.array([dt, mesh.dx, wjreg, cost_b], dtype=np.float32)
+    P = pack(params, PARAM_NAMES, nrow, ncol)
+    S = pack(states, STATE_NAMES, nrow, ncol)
+    Pb = pack(params_bgd, PARAM_NAMES, nrow, ncol) if params_bgd is not None else P.copy(order="F")
+    Sb = pack(states_bgd, STATE_NAMES, nrow, ncol) if states_bgd is not None else S.copy(order="F")
+    wg = np.full(max(ng, 1), 1.0 / max(ng, 1), np.float32) if wgauge is None else np.asarray(wgauge, np.float32)
+    jc = np.array([JOBS[j] for j in jobs_fun] + [0], dtype=np.int32)
+    wj = np.array(list(wjobs_fun) + [0], dtype=np.float32)
+    rc = np.array([JREG[j] for j in jreg_fun] + [0], dtype=np.int32)
+    wr = np.array(list(wjreg_fun) + [0], dtype=np.float32)
+    op = np.zeros(GNP, np.int32) if optim_parameters is None else np.asarray(optim_parameters, np.int32)
+    os_ = np.zeros(GNS, np.int32) if optim_states is None else np.asarray(optim_states, np.int32)
+    lbp = GLB_P if lb_parameters is None else np.asarray(lb_parameters, np.float32)
+    ubp = GUB_P if ub_parameters is None else np.asarray(ub_parameters, np.float32)
+    lbs = GLB_S if lb_states is None else np.asarray(lb_states, np.float32)
+    ubs = GUB_S if ub_states is None else np.asarray(ub_states, np.float32)
+    qsim = np.zeros((max(ng, 1), nt), np.float32, order="F")
+    costs = np.zeros(3, np.float32)
+    fstates = np.zeros((nrow, ncol, GNS), np.float32, order="F")
+    pout = np.zeros((nrow, ncol, GNP), np.float32, order="F")
+    sout = np.zeros((nrow, ncol, GNS), np.float32, order="F")
+    p_b = np.zeros((nrow, ncol, GNP), np.float32, order="F")
+    s_b = np.zeros((nrow, ncol, GNS), np.float32, order="F")
+    elapsed = C.c_double(0.0)
+    args = [icfg, rcfg, _f(mesh.flwdir, np.int32), _f(mesh.flwacc, np.int32),
+            _f(np.asarray(mesh.path) + 1, np.int32), _f(mesh.active_cell, np.int32),
+            _f(np.asarray(mesh.gauge_pos) + 1, np.int32), np.ascontiguousarray(mesh.area, np.float32),
+            _f(prcp, np.float32), _f(pet, np.float32), _f(qobs, np.float32), P, Pb, S, Sb, wg, jc, wj,
+            rc, wr, op, os_, lbp, ubp, lbs, ubs, qsim, costs, fstates, pout, sout, p_b, s_b]
+    cargs = [_ptr(a) for a in args] + [C.byref(elapsed)]
+    err = []
+
+    def call():
+        try:
+            lib.ref_run(*cargs)
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    # the reference keeps (nrow,ncol,16) automatic arrays on the stack (mwd_cost.f90:185-186)
+    old = threading.stack_size(min(2 << 30, max(64 << 20, 64 * nrow * ncol * 4 * 12)))
+    th = threading.Thread(target=call)
+    th.start()
+    th.join()
+    threading.stack_size(old)
+    if err:
+        raise err[0]
+    return dict(qsim=qsim[:ng], cost=float(costs[0]), cost_jobs=float(costs[1]), cost_jreg=float(costs[2]),
+                fstates=unpack(fstates, STATE_NAMES), parameters=unpack(pout, PARAM_NAMES),
+                states=unpack(sout, STATE_NAMES), parameters_b=unpack(p_b, PARAM_NAMES),
+                states_b=unpack(s_b, STATE_NAMES), elapsed=elapsed.value)

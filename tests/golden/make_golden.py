@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the UNMODIFIED reference solver (oracle/_ref/libsmash_ref.so,
+built by oracle/ref/build_ref.sh with flang -O2 -ffp-contract=off from /root/reference).
+
+Run in the build container (needs /root/reference):   python tests/golden/make_golden.py
+Each fixture is data only: the inputs handed to the reference's mw_forward::forward / forward_b
+(smash/solver/forward/mw_forward.f90:18-68) and the outputs it returned.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+
+from oracle import refbind  # noqa: E402
+from oracle.refbind import GLB_P, GLB_S, GUB_P, GUB_S  # noqa: E402
+from smash_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+DT = 3600.0
+
+
+def norm(d, names, lb, ub):
+    return {k: np.asfortranarray(((d[k] - lb[i]) / (ub[i] - lb[i])).astype(np.float32)) for i, k in enumerate(names)}
+
+
+CASES = [
+    # name, structure, n, nt, ng, mask, gaps ppm, options
+    dict(name="gr_a_12x12x48_nse", structure="gr-a", n=12, nt=48, ng=2, mask=False, gaps=0, opts={}),
+    dict(name="gr_b_16x16x96_nse_gaps", structure="gr-b", n=16, nt=96, ng=3, mask=False, gaps=20000, opts={}),
+    dict(name="gr_c_16x16x96_kge_se_log_mask", structure="gr-c", n=16, nt=96, ng=3, mask=True, gaps=5000,
+         opts=dict(jobs_fun=("kge", "se", "logarithmic"), wjobs_fun=(1.0, 0.5, 0.25))),
+    dict(name="gr_d_12x12x48_rmse_kge2_start", structure="gr-d", n=12, nt=48, ng=2, mask=False, gaps=5000,
+         opts=dict(jobs_fun=("rmse", "kge2"), wjobs_fun=(1.0, 0.5), optimize_start_step=7)),
+    dict(name="gr_b_24x24x120_norm_jreg", structure="gr-b", n=24, nt=120, ng=3, mask=True, gaps=5000, normalized=True,
+         opts=dict(jobs_fun=("nse", "kge"), wjobs_fun=(0.7, 0.3), jreg_fun=("prior", "smoothing", "hard_smoothing"),
+                   wjreg_fun=(1.0, 0.5, 0.1), wjreg=1e-3, denormalize_forward=True, optimize_start_step=13,
+                   wgauge=[0.5, 0.0, 0.5])),
+    dict(name="gr_a_24x24x120_norm_prior", structure="gr-a", n=24, nt=120, ng=3, mask=False, gaps=1000, normalized=True,
+         opts=dict(jreg_fun=("prior",), wjreg_fun=(1.0,), wjreg=1e-2, denormalize_forward=True)),
+    # larger cases: forcing is regenerated from smash_amd.synth (sha256 pinned in the fixture)
+    dict(name="gr_b_64x64x720_nse", structure="gr-b", n=64, nt=720, ng=4, mask=False, gaps=1000, big=True, opts={}),
+    dict(name="gr_a_64x64x720_nse", structure="gr-a", n=64, nt=720, ng=4, mask=False, gaps=1000, big=True, opts={}),
+    dict(name="gr_c_48x48x480_nse", structure="gr-c", n=48, nt=480, ng=4, mask=True, gaps=1000, big=True, opts={}),
+    dict(name="gr_d_48x48x480_nse", structure="gr-d", n=48, nt=480, ng=4, mask=False, gaps=1000, big=True, opts={}),
+]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def build_case(c):
+    n, nt = c["n"], c["nt"]
+    mesh = synth.make_mesh(n, n, ng=c["ng"], mask_corner=c["mask"])
+    prcp, pet = synth.dense_forcing(mesh, nt, gap_per_million=c["gaps"])
+    P = synth.make_parameters(n, n)
+    S = synth.make_states(n, n)
+    Pq = synth.make_parameters(n, n, perturb=0.1)
+    qobs = refbind.run(c["structure"], mesh, DT, prcp, pet, np.zeros((c["ng"], nt), np.float32), Pq, S)["qsim"].copy()
+    if c["gaps"]:
+        qobs[-1, nt // 5: nt // 3] = -99.0          # missing observations (mwd_cost.f90:378)
+    opts = dict(c["opts"])
+    if c.get("normalized"):
+        op = np.zeros(16, np.int32)
+        op[[1, 3, 6, 15]] = 1
+        os_ = np.zeros(8, np.int32)
+        os_[[1, 2]] = 1
+        opts.update(optim_parameters=op, optim_states=os_,
+                    params_bgd=norm(Pq, synth.PARAM_NAMES, GLB_P, GUB_P),
+                    states_bgd=norm(S, synth.STATE_NAMES, GLB_S, GUB_S))
+        P = norm(P, synth.PARAM_NAMES, GLB_P, GUB_P)
+        S = norm(S, synth.STATE_NAMES, GLB_S, GUB_S)
+    return mesh, prcp, pet, qobs, P, S, opts
+
+
+def main():
+    if not refbind.available():
+        raise SystemExit("oracle/_ref/libsmash_ref.so missing: run oracle/ref/build_ref.sh first")
+    for c in CASES:
+        mesh, prcp, pet, qobs, P, S, opts = build_case(c)
+        f = refbind.run(c["structure"], mesh, DT, prcp, pet, qobs, P, S, **opts)
+        b = refbind.run(c["structure"], mesh, DT, prcp, pet, qobs, P, S, adjoint=True, **opts)
+        d = dict(structure=c["structure"], dt=DT, dx=mesh.dx, nrow=mesh.nrow, ncol=mesh.ncol, nt=c["nt"],
+                 gaps=c["gaps"], mask=int(c["mask"]), big=int(bool(c.get("big"))),
+                 flwdir=mesh.flwdir, flwacc=mesh.flwacc, path=mesh.path, active_cell=mesh.active_cell,
+                 gauge_pos=mesh.gauge_pos, area=mesh.area, qobs=qobs,
+                 prcp_sha=sha(prcp), pet_sha=sha(pet))
+        if not c.get("big"):
+            d.update(prcp=prcp, pet=pet)
+        for k in synth.PARAM_NAMES:
+            d["p_" + k] = P[k]
+        for k in synth.STATE_NAMES:
+            d["s_" + k] = S[k]
+        for k, v in opts.items():
+            if k in ("params_bgd", "states_bgd"):
+                for kk, vv in v.items():
+                    d[("pbgd_" if k == "params_bgd" else "sbgd_") + kk] = vv
+            elif k in ("jobs_fun", "jreg_fun"):
+                d["opt_" + k] = np.array(list(v))
+            else:
+                d["opt_" + k] = np.asarray(v)
+        # expected outputs
+        d.update(fwd_qsim=f["qsim"], fwd_cost=np.float32(f["cost"]), fwd_cost_jobs=np.float32(f["cost_jobs"]),
+                 fwd_cost_jreg=np.float32(f["cost_jreg"]), adj_qsim=b["qsim"], adj_cost=np.float32(b["cost"]))
+        for k in synth.STATE_NAMES:
+            d["fwd_fstates_" + k] = f["fstates"][k]
+            d["adj_states_b_" + k] = b["states_b"][k]
+            d["fwd_states_out_" + k] = f["states"][k]
+        for k in synth.PARAM_NAMES:
+            d["adj_parameters_b_" + k] = b["parameters_b"][k]
+            d["fwd_parameters_out_" + k] = f["parameters"][k]
+        path = os.path.join(OUT, c["name"] + ".npz")
+        np.savez_compressed(path, **d)
+        print(f"{c['name']}: cost={f['cost']:.8g} |cp_b|={np.abs(b['parameters_b']['cp']).max():.4g} "
+              f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()
