@@ -1,0 +1,154 @@
+/* smashx.h -- C ABI of libsmashx: the MI355X-native forward + adjoint solver that stands in for the
+ * reference's differentiated core.
+ *
+ * What it replaces.  The reference's wrapped boundary is
+ *     mw_forward::forward    smash/solver/forward/mw_forward.f90:18-39
+ *     mw_forward::forward_b  smash/solver/forward/mw_forward.f90:41-68
+ * which forward, through an implicit interface, to the external procedures
+ *     base_forward    smash/solver/forward/forward.f90:1-80
+ *     base_forward_b  smash/solver/forward/forward_db.f90:10648-10936
+ * A drop-in links objects defining base_forward_/base_forward_b_ that marshal the derived types'
+ * allocatable components into the calls below (fortran/smashx_dropin.f90).
+ *
+ * Conventions.  Plain pointers and sizes only.  Host arrays are column-major exactly as the
+ * reference holds them (row index fastest); gauge_pos and path are 0-based here (the Fortran shim
+ * subtracts 1), optimize_start_step stays 1-based like setup%optimize%optimize_start_step.  The
+ * caller owns every array; the plan owns all device memory.  Every function returns 0 on success
+ * or a negative SMASHX_E_* code (the reference has no error channel: the Fortran shim prints and
+ * continues).  There is no CPU fallback: without a usable HIP device plan creation fails.
+ */
+#ifndef SMASHX_H
+#define SMASHX_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMASHX_GNP 16 /* md_constant.f90:32  ci cp beta cft cst alpha exc b cusl1 cusl2 clsl ks ds dsm ws lr */
+#define SMASHX_GNS 8  /* md_constant.f90:33  hi hp hft hst husl1 husl2 hlsl hlr */
+
+enum { SMASHX_GR_A = 1, SMASHX_GR_B = 2, SMASHX_GR_C = 3, SMASHX_GR_D = 4 };   /* setup%structure, forward.f90:43-65 */
+enum { SMASHX_NSE = 1, SMASHX_KGE = 2, SMASHX_KGE2 = 3, SMASHX_SE = 4, SMASHX_RMSE = 5, SMASHX_LOGARITHMIC = 6 }; /* mwd_cost.f90:98-126 */
+enum { SMASHX_PRIOR = 1, SMASHX_SMOOTHING = 2, SMASHX_HARD_SMOOTHING = 3 };   /* mwd_cost.f90:199-224 */
+enum { SMASHX_P_CI = 0, SMASHX_P_CP = 1, SMASHX_P_BETA = 2, SMASHX_P_CFT = 3, SMASHX_P_CST = 4, SMASHX_P_ALPHA = 5,
+       SMASHX_P_EXC = 6, SMASHX_P_LR = 15 };
+enum { SMASHX_S_HI = 0, SMASHX_S_HP = 1, SMASHX_S_HFT = 2, SMASHX_S_HST = 3, SMASHX_S_HLR = 7 };
+
+enum {
+    SMASHX_OK = 0,
+    SMASHX_E_ARG = -1,          /* bad argument / inconsistent sizes */
+    SMASHX_E_UNSUPPORTED = -2,  /* option outside the hot path built so far */
+    SMASHX_E_HIP = -3,          /* a HIP runtime call failed (smashx_last_error() has the text) */
+    SMASHX_E_NODEVICE = -4,     /* no usable gfx950 device: there is no CPU fallback */
+    SMASHX_E_MESH = -5,         /* flow directions do not form a forest over the active cells */
+    SMASHX_E_STATE = -6         /* call order (forcing / options not set) */
+};
+
+/* SetupDT + MeshDT scalars the path reads (mwd_setup.f90:108-157, mwd_mesh.f90:45-72) */
+typedef struct {
+    int structure;     /* SMASHX_GR_* */
+    int nrow, ncol;
+    int nt;            /* setup%ntime_step */
+    int ng;
+    float dt;          /* s */
+    float dx;          /* m */
+    int chunk_steps;   /* time-chunk length of the checkpointed adjoint; 0 = choose from free HBM */
+    int group_size;    /* routing workgroup size (cells + inlets per group); 0 = default */
+    int device;        /* HIP device ordinal; -1 = current device */
+} smashx_config;
+
+typedef struct {
+    const int* flwdir;       /* (nrow,ncol) D8 codes 1..8, <=0 nodata            mwd_mesh.f90:57 */
+    const int* flwacc;       /* (nrow,ncol) cells draining through, self included mwd_mesh.f90:58 */
+    const int* active_cell;  /* (nrow,ncol) 1 = active                            mwd_mesh.f90:60 */
+    const int* path;         /* (2,nrow*ncol) 0-based visiting order; only needed for the sparse forcing layout; may be NULL */
+    const int* gauge_pos;    /* (ng,2) 0-based (row, col)                         mwd_mesh.f90:63 */
+    const float* area;       /* (ng) m^2                                          mwd_mesh.f90:65 */
+} smashx_mesh;
+
+/* Optimize_SetupDT fields the path reads (mwd_setup.f90:57-105) */
+typedef struct {
+    int denormalize_forward;
+    int optimize_start_step;        /* 1-based */
+    int njf;
+    int jobs_fun[8];                /* SMASHX_NSE ... */
+    float wjobs_fun[8];
+    int njr;
+    int jreg_fun[4];                /* SMASHX_PRIOR ... */
+    float wjreg_fun[4];
+    float wjreg;
+    int optim_parameters[SMASHX_GNP];
+    int optim_states[SMASHX_GNS];
+    float lb_parameters[SMASHX_GNP], ub_parameters[SMASHX_GNP];
+    float lb_states[SMASHX_GNS], ub_states[SMASHX_GNS];
+    const float* wgauge;            /* (ng) */
+} smashx_options;
+
+/* ParametersDT / StatesDT as 16 / 8 pointers to (nrow,ncol) host arrays in md_constant order;
+ * fields the structure does not use may be NULL (smash/core/_constant.py:15-29). */
+typedef struct { float* f[SMASHX_GNP]; } smashx_parameters;
+typedef struct { float* f[SMASHX_GNS]; } smashx_states;
+
+typedef struct { float cost, cost_jobs, cost_jreg; } smashx_costs;   /* output%cost*, mwd_cost.f90:300-304 */
+
+/* device-side time of the last sweep, measured with HIP events on the plan's stream */
+typedef struct {
+    float sweep_ms;          /* whole device sweep (forward, or forward + cost + adjoint) */
+    float vert_fwd_ms;       /* vertical (production/transfer) forward kernels            */
+    float route_fwd_ms;      /* routing forward kernels                                   */
+    float cost_ms;
+    float route_adj_ms;
+    float vert_adj_ms;
+    int   vert_fwd_launches, route_fwd_launches, route_adj_launches, vert_adj_launches;
+    int   n_chunks, chunk_steps, n_rounds, n_groups;
+    double device_bytes;     /* HBM held by the plan */
+} smashx_timing;
+
+typedef struct smashx_plan smashx_plan;
+
+const char* smashx_last_error(void);
+int smashx_device_count(void);
+
+/* builds the routing schedule from the mesh and allocates device storage */
+int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx_plan** out);
+int smashx_plan_destroy(smashx_plan* plan);
+
+/* number of active cells and the device cell order: k -> (row, col), 0-based */
+int smashx_plan_ncells(const smashx_plan* plan);
+int smashx_plan_cell_order(const smashx_plan* plan, int* rows, int* cols);
+
+/* forcing: Input_DataDT%prcp/pet (nrow,ncol,nt) [sparse = 0] or %sparse_prcp/pet (nac,nt) numbered along
+ * path over active cells [sparse = 1] (mwd_input_data.f90:32-50, mw_sparse_storage.f90:12-49).
+ * Stays resident in HBM across sweeps. */
+int smashx_set_forcing(smashx_plan* plan, const float* prcp, const float* pet, int sparse);
+/* device-resident block: d_prcp/d_pet are DEVICE pointers to (t1-t0, ncells) arrays, cell index in
+ * plan order (smashx_plan_cell_order) fastest.  Used by bench.py to build the forcing in HBM. */
+int smashx_set_forcing_device_block(smashx_plan* plan, int t0, int t1, const float* d_prcp, const float* d_pet);
+int smashx_set_qobs(smashx_plan* plan, const float* qobs /* (ng,nt) */);
+int smashx_set_options(smashx_plan* plan, const smashx_options* opt);
+
+/* base_forward (forward.f90:1-80): qsim (ng,nt); fstates = output%fstates; params/states are inout
+ * like the reference (denormalised on return when denormalize_forward; states restored). */
+int smashx_forward(smashx_plan* plan, smashx_parameters* params, const smashx_parameters* params_bgd,
+                   smashx_states* states, const smashx_states* states_bgd, float* qsim, smashx_costs* costs,
+                   smashx_states* fstates /* nullable */);
+
+/* base_forward_b (forward_db.f90:10648-10936): params_b/states_b are fully overwritten with
+ * d cost / d (normalised when denormalize_forward) parameters and initial states, times cost_b. */
+int smashx_forward_b(smashx_plan* plan, smashx_parameters* params, const smashx_parameters* params_bgd,
+                     smashx_states* states, const smashx_states* states_bgd, float cost_b, float* qsim,
+                     smashx_costs* costs, smashx_parameters* params_b, smashx_states* states_b);
+
+/* split-phase form of the two calls above, for measurement with inputs resident in HBM:
+ * upload -> (sweep)* -> download.  adjoint = 0: forward sweep; 1: forward + cost + adjoint sweep. */
+int smashx_upload(smashx_plan* plan, const smashx_parameters* params, const smashx_parameters* params_bgd,
+                  const smashx_states* states, const smashx_states* states_bgd);
+int smashx_sweep(smashx_plan* plan, int adjoint, float cost_b);
+int smashx_download(smashx_plan* plan, int adjoint, smashx_parameters* params, smashx_states* states, float* qsim,
+                    smashx_costs* costs, smashx_states* fstates, smashx_parameters* params_b, smashx_states* states_b);
+int smashx_get_timing(const smashx_plan* plan, smashx_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMASHX_H */

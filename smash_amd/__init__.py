@@ -1,0 +1,10 @@
+"""smash_amd -- MI355X-native forward + adjoint solver for smash's distributed rainfall-runoff path.
+
+The package is a thin host-side mirror of the reference's ``mw_forward`` boundary over libsmashx
+(HIP kernels behind the C ABI of include/smashx.h).  Importing it does not need a GPU; calling the
+solver does, and fails loudly without one.
+"""
+from .solver import Solver, forward, forward_b  # noqa: F401
+from .types import (Input_DataDT, MeshDT, Optimize_SetupDT, OutputDT, ParametersDT, SetupDT,  # noqa: F401
+                    StatesDT)
+from ._lib import SmashxError  # noqa: F401

@@ -1,0 +1,89 @@
+"""ctypes view of include/smashx.h.  Loading fails loudly when libsmashx.so is missing: there is no
+Python / CPU implementation of the solver behind this module."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmashx.so")
+
+GNP, GNS = 16, 8
+
+E_OK, E_ARG, E_UNSUPPORTED, E_HIP, E_NODEVICE, E_MESH, E_STATE = 0, -1, -2, -3, -4, -5, -6
+
+SYMBOLS = [
+    "smashx_last_error", "smashx_device_count", "smashx_plan_create", "smashx_plan_destroy", "smashx_plan_ncells",
+    "smashx_plan_cell_order", "smashx_set_forcing", "smashx_set_forcing_device_block", "smashx_set_qobs",
+    "smashx_set_options", "smashx_forward", "smashx_forward_b", "smashx_upload", "smashx_sweep", "smashx_download",
+    "smashx_get_timing",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("structure", C.c_int), ("nrow", C.c_int), ("ncol", C.c_int), ("nt", C.c_int), ("ng", C.c_int),
+                ("dt", C.c_float), ("dx", C.c_float), ("chunk_steps", C.c_int), ("group_size", C.c_int),
+                ("device", C.c_int)]
+
+
+class Mesh(C.Structure):
+    _fields_ = [("flwdir", C.c_void_p), ("flwacc", C.c_void_p), ("active_cell", C.c_void_p), ("path", C.c_void_p),
+                ("gauge_pos", C.c_void_p), ("area", C.c_void_p)]
+
+
+class Options(C.Structure):
+    _fields_ = [("denormalize_forward", C.c_int), ("optimize_start_step", C.c_int), ("njf", C.c_int),
+                ("jobs_fun", C.c_int * 8), ("wjobs_fun", C.c_float * 8), ("njr", C.c_int), ("jreg_fun", C.c_int * 4),
+                ("wjreg_fun", C.c_float * 4), ("wjreg", C.c_float), ("optim_parameters", C.c_int * GNP),
+                ("optim_states", C.c_int * GNS), ("lb_parameters", C.c_float * GNP), ("ub_parameters", C.c_float * GNP),
+                ("lb_states", C.c_float * GNS), ("ub_states", C.c_float * GNS), ("wgauge", C.c_void_p)]
+
+
+class Parameters(C.Structure):
+    _fields_ = [("f", C.c_void_p * GNP)]
+
+
+class States(C.Structure):
+    _fields_ = [("f", C.c_void_p * GNS)]
+
+
+class Costs(C.Structure):
+    _fields_ = [("cost", C.c_float), ("cost_jobs", C.c_float), ("cost_jreg", C.c_float)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("sweep_ms", C.c_float), ("vert_fwd_ms", C.c_float), ("route_fwd_ms", C.c_float), ("cost_ms", C.c_float),
+                ("route_adj_ms", C.c_float), ("vert_adj_ms", C.c_float), ("vert_fwd_launches", C.c_int),
+                ("route_fwd_launches", C.c_int), ("route_adj_launches", C.c_int), ("vert_adj_launches", C.c_int),
+                ("n_chunks", C.c_int), ("chunk_steps", C.c_int), ("n_rounds", C.c_int), ("n_groups", C.c_int),
+                ("device_bytes", C.c_double)]
+
+
+class SmashxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsmashx error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """The C-ABI library.  Raises if the HIP extension has not been built (python -c 'import
+    __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build the HIP library first (__graft_entry__.build()); "
+                              "smash_amd has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.smashx_last_error.restype = C.c_char_p
+        for s in SYMBOLS[1:]:
+            getattr(L, s).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SmashxError(rc, lib().smashx_last_error().decode())

@@ -1,0 +1,697 @@
+// smashx.hip -- C ABI implementation (include/smashx.h): plan, HBM residency, sweep orchestration.
+// gfx950 only.  No CPU compute path: every entry point that needs the device fails without one.
+#include "../../include/smashx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sx_cost.h"
+#include "sx_kernels.h"
+#include "sx_plan.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(SMASHX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+// which of the 16 / 8 fields each structure reads (smash/core/_constant.py:15-29; ci via gr_interception)
+const int kParamFields[6] = {SMASHX_P_CI, SMASHX_P_CP, SMASHX_P_CFT, SMASHX_P_CST, SMASHX_P_EXC, SMASHX_P_LR};
+const int kStateFields[5] = {SMASHX_S_HI, SMASHX_S_HP, SMASHX_S_HFT, SMASHX_S_HST, SMASHX_S_HLR};
+bool uses_param(int st, int f) {
+    switch (f) {
+        case SMASHX_P_CI: return st == 2 || st == 3;
+        case SMASHX_P_CP: case SMASHX_P_CFT: case SMASHX_P_LR: return true;
+        case SMASHX_P_CST: return st == 3;
+        case SMASHX_P_EXC: return st != 4;
+        default: return false;
+    }
+}
+bool uses_state(int st, int f) {
+    switch (f) {
+        case SMASHX_S_HI: return st == 2 || st == 3;
+        case SMASHX_S_HP: case SMASHX_S_HFT: case SMASHX_S_HLR: return true;
+        case SMASHX_S_HST: return st == 3;
+        default: return false;
+    }
+}
+
+// ---- small elementwise kernels on full (nrow*ncol) fields and on the cell vectors -------------------
+__global__ void k_denormalize(float* a, long n, float lb, float ub) {   // mwd_parameters_manipulation.f90:199
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = a[i] * (ub - lb) + lb;
+}
+__global__ void k_normalize(float* a, long n, float lb, float ub) {     // mwd_parameters_manipulation.f90:172
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = (a[i] - lb) / (ub - lb);
+}
+__global__ void k_gather(float* dst, const float* src, const int* idx, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[k] = src[idx[k]];
+}
+__global__ void k_gather_rows(float* dst, const float* src, const int* idx, int n, int npad, long plane, int rows) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (k < n && r < rows) dst[(size_t)r * npad + k] = src[(size_t)r * plane + idx[k]];
+}
+__global__ void k_scatter(float* dst, const float* src, const int* idx, int n, float scale, int scaled) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) dst[idx[k]] = scaled ? scale * src[k] : src[k];
+}
+
+struct Launch { hipEvent_t a, b; int kind; };
+
+}  // namespace
+
+struct smashx_plan {
+    smashx_config cfg{};
+    SxSchedule sch;
+    int n = 0, npad = 0, nt = 0, ng = 0, st = 0;
+    long n2 = 0;
+    int M = 0;
+    int Tc = 0, nchunks = 0;
+    bool have_forcing = false, have_options = false, have_qobs = false, uploaded = false;
+    bool chunk_ready = false, adj_ready = false;
+    smashx_options opt{};
+    std::vector<float> wgauge;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    double bytes = 0;
+    SxDeviceArrays A{};
+    // extra device storage
+    int* d_cell_flat = nullptr;      // k -> flat (row + col*nrow)
+    int* d_sparse_idx = nullptr;     // k -> index in the sparse (nac) vectors
+    float* d_stage = nullptr;        // staging for full planes
+    long stage_planes = 0;
+    float* d_fullP[SMASHX_GNP] = {nullptr};
+    float* d_fullS[SMASHX_GNS] = {nullptr};
+    float* st0[5] = {nullptr};       // initial (denormalised) states in cell order
+    float* ckpt = nullptr;           // [nchunks][5][npad]
+    float* d_prcp = nullptr; float* d_pet = nullptr;
+    // cost
+    int ngc = 0;
+    std::vector<int> gauge_gid;
+    int *d_gauge_gid = nullptr, *d_gauge_flwacc = nullptr;
+    float *d_area = nullptr, *d_wgauge = nullptr, *d_qobs = nullptr, *d_qsim_b = nullptr, *d_cost_out = nullptr;
+    SxGaugeSums* d_sums = nullptr; SxCostCoef* d_coef = nullptr;
+    float jobs = 0.f;
+    // timing
+    std::vector<Launch> launches;
+    std::vector<hipEvent_t> pool; size_t pool_used = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    smashx_timing timing{};
+    int last_adjoint = 0;
+
+    template <class T> int dmalloc(T** p, size_t count) {
+        void* q = nullptr;
+        const size_t b = std::max<size_t>(count, 1) * sizeof(T);
+        hipError_t e = hipMalloc(&q, b);
+        if (e != hipSuccess) return fail(SMASHX_E_HIP, std::string("hipMalloc(") + std::to_string(b) + " B): " + hipGetErrorString(e));
+        allocs.push_back(q); bytes += (double)b; *p = (T*)q;
+        return 0;
+    }
+    template <class T> int upload_vec(T** p, const std::vector<T>& v) {
+        int rc = dmalloc(p, v.size()); if (rc) return rc;
+        if (!v.empty()) HIPCHK(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    }
+    hipEvent_t event() {
+        if (pool_used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
+        return pool[pool_used++];
+    }
+    void mark_begin(int kind) { Launch l; l.a = event(); l.b = nullptr; l.kind = kind; if (l.a) (void)hipEventRecord(l.a, stream); launches.push_back(l); }
+    void mark_end() { Launch& l = launches.back(); l.b = event(); if (l.b) (void)hipEventRecord(l.b, stream); }
+};
+
+namespace {
+
+int set_device(const smashx_plan* p) {
+    if (p->cfg.device >= 0) HIPCHK(hipSetDevice(p->cfg.device));
+    return 0;
+}
+
+int chunk_len(const smashx_plan* p, int c) { return std::min(p->Tc, p->nt - c * p->Tc); }
+
+// allocate the time-chunk buffers; Tc from cfg or from free HBM
+int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
+    const int st = p->st;
+    const int ntape = (st == 2 ? 3 : st == 3 ? 4 : 2);
+    if (!p->chunk_ready) {
+        const int nt16 = (p->nt + 15) / 16 * 16;
+        int Tc = p->cfg.chunk_steps > 0 ? (p->cfg.chunk_steps + 15) / 16 * 16 : 0;
+        if (Tc == 0) {
+            size_t fr = 0, tot = 0;
+            HIPCHK(hipMemGetInfo(&fr, &tot));
+            const double per_step = 4.0 * ((double)p->npad * (2 + ntape) + (double)std::max(p->sch.nxslots, 1));
+            const double avail = (double)fr * 0.85 - 1.0e9;
+            long t = (long)(avail / per_step) / 16 * 16;
+            Tc = (int)std::max<long>(16, std::min<long>(nt16, t));
+        }
+        Tc = std::min(Tc, nt16);
+        p->Tc = Tc;
+        p->A.Tc = Tc;
+        p->nchunks = (p->nt + Tc - 1) / Tc;
+        int rc;
+        if ((rc = p->dmalloc(&p->A.qtT, (size_t)p->npad * Tc))) return rc;
+        if ((rc = p->dmalloc(&p->A.xT, (size_t)std::max(p->sch.nxslots, 1) * Tc))) return rc;
+        HIPCHK(hipMemsetAsync(p->A.qtT, 0, (size_t)p->npad * Tc * 4, p->stream));
+        HIPCHK(hipMemsetAsync(p->A.xT, 0, (size_t)std::max(p->sch.nxslots, 1) * Tc * 4, p->stream));
+        p->chunk_ready = true;
+    }
+    if (adjoint && !p->adj_ready) {
+        int rc;
+        const size_t cs = (size_t)p->npad * p->Tc;
+        if ((rc = p->dmalloc(&p->A.hrT, cs))) return rc;
+        if ((rc = p->dmalloc(&p->A.tape_hp, cs))) return rc;
+        if ((rc = p->dmalloc(&p->A.tape_hft, cs))) return rc;
+        if (st == 2 || st == 3) { if ((rc = p->dmalloc(&p->A.tape_hi, cs))) return rc; }
+        if (st == 3) { if ((rc = p->dmalloc(&p->A.tape_hst, cs))) return rc; }
+        if (p->nchunks > 1) { if ((rc = p->dmalloc(&p->ckpt, (size_t)p->nchunks * 5 * p->npad))) return rc; }
+        float** g[11] = {&p->A.ci_b, &p->A.cp_b, &p->A.cft_b, &p->A.cst_b, &p->A.exc_b, &p->A.lr_b,
+                         &p->A.hi_b, &p->A.hp_b, &p->A.hft_b, &p->A.hst_b, &p->A.hlr_b};
+        for (auto q : g) if ((rc = p->dmalloc(q, (size_t)p->npad))) return rc;
+        if ((rc = p->dmalloc(&p->A.qgb, (size_t)std::max(p->ngc, 1) * p->nt))) return rc;
+        if ((rc = p->dmalloc(&p->d_qsim_b, (size_t)std::max(p->ng, 1) * p->nt))) return rc;
+        p->adj_ready = true;
+    }
+    return 0;
+}
+
+template <int ST>
+void launch_vert_fwd(smashx_plan* p, bool tape, int t0, int T) {
+    const dim3 grid(p->npad / SX_VBLOCK), block(SX_VBLOCK);
+    p->mark_begin(0);
+    if (tape) hipLaunchKernelGGL((sx_k_vert_fwd<ST, true>), grid, block, 0, p->stream, p->A, t0, T);
+    else      hipLaunchKernelGGL((sx_k_vert_fwd<ST, false>), grid, block, 0, p->stream, p->A, t0, T);
+    p->mark_end();
+}
+void vert_fwd(smashx_plan* p, bool tape, int t0, int T) {
+    switch (p->st) {
+        case 1: launch_vert_fwd<1>(p, tape, t0, T); break;
+        case 2: launch_vert_fwd<2>(p, tape, t0, T); break;
+        case 3: launch_vert_fwd<3>(p, tape, t0, T); break;
+        default: launch_vert_fwd<4>(p, tape, t0, T); break;
+    }
+}
+void vert_adj(smashx_plan* p, int t0, int T) {
+    const dim3 grid(p->npad / SX_VBLOCK), block(SX_VBLOCK);
+    p->mark_begin(3);
+    switch (p->st) {
+        case 1: hipLaunchKernelGGL((sx_k_vert_adj<1>), grid, block, 0, p->stream, p->A, t0, T); break;
+        case 2: hipLaunchKernelGGL((sx_k_vert_adj<2>), grid, block, 0, p->stream, p->A, t0, T); break;
+        case 3: hipLaunchKernelGGL((sx_k_vert_adj<3>), grid, block, 0, p->stream, p->A, t0, T); break;
+        default: hipLaunchKernelGGL((sx_k_vert_adj<4>), grid, block, 0, p->stream, p->A, t0, T); break;
+    }
+    p->mark_end();
+}
+void route_fwd(smashx_plan* p, bool tape, int t0, int T) {
+    const size_t lds = (size_t)2 * p->M * sizeof(float4);
+    for (int r = 0; r < p->sch.nrounds; ++r) {
+        const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
+        p->mark_begin(1);
+        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true>), dim3(ngr), dim3(p->M), lds, p->stream, p->A, g0, t0, T);
+        else      hipLaunchKernelGGL((sx_k_route_fwd<false>), dim3(ngr), dim3(p->M), lds, p->stream, p->A, g0, t0, T);
+        p->mark_end();
+    }
+}
+void route_adj(smashx_plan* p, int t0, int T) {
+    const size_t lds = (size_t)2 * p->M * sizeof(float4);
+    for (int r = p->sch.nrounds - 1; r >= 0; --r) {
+        const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
+        p->mark_begin(2);
+        hipLaunchKernelGGL(sx_k_route_adj, dim3(ngr), dim3(p->M), lds, p->stream, p->A, g0, t0, T);
+        p->mark_end();
+    }
+}
+
+SxCostArgs cost_args(smashx_plan* p, float jobs_b) {
+    SxCostArgs C{};
+    C.ng = p->ng; C.nt = p->nt; C.s0 = p->opt.optimize_start_step - 1; C.njf = p->opt.njf;
+    for (int j = 0; j < SX_MAXJF; ++j) { C.jobs_fun[j] = p->opt.jobs_fun[j]; C.wjobs_fun[j] = p->opt.wjobs_fun[j]; }
+    C.dt = p->cfg.dt; C.dx = p->cfg.dx;
+    C.qg = p->A.qg; C.qgb = p->A.qgb; C.ngc = p->ngc;
+    C.gauge_gid = p->d_gauge_gid; C.gauge_flwacc = p->d_gauge_flwacc; C.area = p->d_area; C.wgauge = p->d_wgauge;
+    C.qobs = p->d_qobs; C.qsim_b = p->d_qsim_b; C.sums = p->d_sums; C.coef = p->d_coef; C.out = p->d_cost_out;
+    C.jobs_b = jobs_b;
+    return C;
+}
+
+int run_cost(smashx_plan* p, int adjoint, float cost_b) {
+    if (p->ng == 0) return 0;
+    SxCostArgs C = cost_args(p, cost_b);
+    p->mark_begin(4);
+    hipLaunchKernelGGL(sx_k_cost_sums, dim3(p->ng), dim3(64), 0, p->stream, C);
+    hipLaunchKernelGGL(sx_k_cost_final, dim3(1), dim3(1), 0, p->stream, C, adjoint);
+    if (adjoint) {
+        const dim3 b(256), g1((p->nt + 255) / 256, p->ng), g2((p->nt + 255) / 256, p->ngc);
+        hipLaunchKernelGGL(sx_k_cost_seeds, g1, b, 0, p->stream, C);
+        hipLaunchKernelGGL(sx_k_cost_cellseeds, g2, b, 0, p->stream, C);
+    }
+    p->mark_end();
+    return 0;
+}
+
+int restore_states(smashx_plan* p, float* const src[5]) {
+    float* dst[5] = {p->A.hi, p->A.hp, p->A.hft, p->A.hst, p->A.hlr};
+    for (int i = 0; i < 5; ++i)
+        if (uses_state(p->st, kStateFields[i]))
+            HIPCHK(hipMemcpyAsync(dst[i], src[i], (size_t)p->npad * 4, hipMemcpyDeviceToDevice, p->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* smashx_last_error(void) { return g_err.c_str(); }
+
+int smashx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx_plan** out) {
+    if (!cfg || !mesh || !out) return fail(SMASHX_E_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->structure < 1 || cfg->structure > 4) return fail(SMASHX_E_UNSUPPORTED, "structure must be gr-a/b/c/d (vic-a is a later row)");
+    if (cfg->nrow <= 0 || cfg->ncol <= 0 || cfg->nt <= 0 || cfg->ng < 0 || !(cfg->dt > 0.f) || !(cfg->dx > 0.f))
+        return fail(SMASHX_E_ARG, "bad sizes in smashx_config");
+    if (!mesh->flwdir || !mesh->flwacc || !mesh->active_cell || (cfg->ng > 0 && (!mesh->gauge_pos || !mesh->area)))
+        return fail(SMASHX_E_ARG, "null mesh array");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SMASHX_E_NODEVICE, "no HIP device: libsmashx has no CPU fallback");
+    smashx_plan* p = new smashx_plan();
+    p->cfg = *cfg;
+    if (set_device(p)) { delete p; return SMASHX_E_HIP; }
+    p->M = cfg->group_size > 0 ? cfg->group_size : 512;
+    if (p->M % 64 != 0 || p->M > 1024 || p->M < 64) { delete p; return fail(SMASHX_E_ARG, "group_size must be a multiple of 64 in [64, 1024]"); }
+    const int rc0 = sx_build_schedule(cfg->nrow, cfg->ncol, mesh->flwdir, mesh->active_cell, cfg->ng, mesh->gauge_pos, p->M, p->sch);
+    if (rc0 != 0) { std::string e = p->sch.error; delete p; return fail(rc0 == -5 ? SMASHX_E_MESH : SMASHX_E_ARG, e); }
+    p->n = p->sch.n; p->npad = (p->n + SX_VBLOCK - 1) / SX_VBLOCK * SX_VBLOCK;
+    p->nt = cfg->nt; p->ng = cfg->ng; p->st = cfg->structure; p->n2 = (long)cfg->nrow * cfg->ncol;
+    int rc = 0;
+#define TRY(x) do { rc = (x); if (rc) { smashx_plan_destroy(p); return rc; } } while (0)
+    if (hipStreamCreate(&p->stream) != hipSuccess) { delete p; return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
+    (void)hipEventCreate(&p->ev0); (void)hipEventCreate(&p->ev1);
+    SxDeviceArrays& A = p->A;
+    A.n = p->n; A.npad = p->npad; A.nt = p->nt; A.dt = cfg->dt; A.dx = cfg->dx; A.Tc = 0;
+    // schedule tables
+    int *d1, *d2, *d3, *d4, *d5, *d6, *d7, *d8;
+    TRY(p->upload_vec(&d1, p->sch.g_slot_begin)); A.g_slot_begin = d1;
+    TRY(p->upload_vec(&d2, p->sch.g_dmax)); A.g_dmax = d2;
+    TRY(p->upload_vec(&d3, p->sch.s_cell)); A.s_cell = d3;
+    TRY(p->upload_vec(&d4, p->sch.s_stage)); A.s_stage = d4;
+    TRY(p->upload_vec(&d5, p->sch.s_cstart)); A.s_cstart = d5;
+    TRY(p->upload_vec(&d6, p->sch.s_ccount)); A.s_ccount = d6;
+    TRY(p->upload_vec(&d7, p->sch.s_parent)); A.s_parent = d7;
+    TRY(p->upload_vec(&d8, p->sch.s_xout)); A.s_xout = d8;
+    TRY(p->upload_vec(&p->d_cell_flat, p->sch.cell_flat));
+    // per-cell mesh data
+    std::vector<int> facc(p->npad, 1), cg(p->npad, -1);
+    for (int k = 0; k < p->n; ++k) facc[k] = mesh->flwacc[p->sch.cell_flat[k]];
+    p->gauge_gid.assign(p->ng, -1);
+    std::vector<int> gfl(std::max(p->ng, 1), 1);
+    for (int g = 0; g < p->ng; ++g) {
+        const int k = p->sch.gauge_k[g];
+        if (cg[k] < 0) cg[k] = p->ngc++;
+        p->gauge_gid[g] = cg[k];
+        gfl[g] = mesh->flwacc[p->sch.cell_flat[k]];
+    }
+    TRY(p->upload_vec(&A.flwacc, facc));
+    TRY(p->upload_vec(&A.cell_gauge, cg));
+    // sparse forcing index: k -> position along path over active cells (mw_sparse_storage.f90:12-49)
+    if (mesh->path) {
+        std::vector<int> sp(p->n, -1);
+        int ind = 0;
+        for (long i = 0; i < p->n2; ++i) {
+            const int row = mesh->path[2 * i], col = mesh->path[2 * i + 1];
+            if (row < 0 || col < 0 || row >= cfg->nrow || col >= cfg->ncol) continue;
+            const long c = row + (long)col * cfg->nrow;
+            if (mesh->active_cell[c] == 1) { const int k = p->sch.k_of_flat[c]; if (k >= 0 && sp[k] < 0) sp[k] = ind; ++ind; }
+        }
+        bool ok = true;
+        for (int k = 0; k < p->n; ++k) ok &= sp[k] >= 0;
+        if (ok) TRY(p->upload_vec(&p->d_sparse_idx, sp));
+    }
+    // parameters, states, routing invariants
+    float** pf[6] = {&A.ci, &A.cp, &A.cft, &A.cst, &A.exc, &A.lr};
+    for (auto q : pf) TRY(p->dmalloc(q, (size_t)p->npad));
+    float** sf[5] = {&A.hi, &A.hp, &A.hft, &A.hst, &A.hlr};
+    for (auto q : sf) TRY(p->dmalloc(q, (size_t)p->npad));
+    for (int i = 0; i < 5; ++i) TRY(p->dmalloc(&p->st0[i], (size_t)p->npad));
+    float** rf[4] = {&A.rt_a, &A.rt_f, &A.rt_denf, &A.rt_denb};
+    for (auto q : rf) TRY(p->dmalloc(q, (size_t)p->npad));
+    for (int i = 0; i < 6; ++i) TRY(p->dmalloc(&p->d_fullP[kParamFields[i]], (size_t)p->n2));
+    for (int i = 0; i < 5; ++i) TRY(p->dmalloc(&p->d_fullS[kStateFields[i]], (size_t)p->n2));
+    p->stage_planes = std::max<long>(1, std::min<long>(64, (256L << 20) / (p->n2 * 4)));
+    TRY(p->dmalloc(&p->d_stage, (size_t)p->n2 * p->stage_planes));
+    // gauges / cost
+    TRY(p->dmalloc(&A.qg, (size_t)std::max(p->ngc, 1) * p->nt));
+    TRY(p->upload_vec(&p->d_gauge_gid, p->gauge_gid.empty() ? std::vector<int>(1, 0) : p->gauge_gid));
+    TRY(p->upload_vec(&p->d_gauge_flwacc, gfl));
+    std::vector<float> area(std::max(p->ng, 1), 1.f);
+    for (int g = 0; g < p->ng; ++g) area[g] = mesh->area[g];
+    TRY(p->upload_vec(&p->d_area, area));
+    TRY(p->dmalloc(&p->d_wgauge, (size_t)std::max(p->ng, 1)));
+    TRY(p->dmalloc(&p->d_qobs, (size_t)std::max(p->ng, 1) * p->nt));
+    TRY(p->dmalloc(&p->d_sums, (size_t)std::max(p->ng, 1)));
+    TRY(p->dmalloc(&p->d_coef, (size_t)std::max(p->ng, 1) * SX_MAXJF));
+    TRY(p->dmalloc(&p->d_cost_out, 4));
+    if (hipMemset(p->d_qobs, 0, (size_t)std::max(p->ng, 1) * p->nt * 4) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipMemset"); }
+    // default options: plain Model.run(): njf = 0 (mwd_setup.f90:236)
+    std::memset(&p->opt, 0, sizeof(p->opt));
+    p->opt.optimize_start_step = 1;
+    p->wgauge.assign(std::max(p->ng, 1), p->ng > 0 ? 1.f / p->ng : 0.f);
+    if (hipMemcpy(p->d_wgauge, p->wgauge.data(), p->wgauge.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipMemcpy"); }
+    p->have_options = true;
+#undef TRY
+    *out = p;
+    return 0;
+}
+
+int smashx_plan_destroy(smashx_plan* p) {
+    if (!p) return 0;
+    (void)set_device(p);
+    if (p->stream) (void)hipStreamSynchronize(p->stream);
+    for (void* q : p->allocs) (void)hipFree(q);
+    for (hipEvent_t e : p->pool) (void)hipEventDestroy(e);
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->stream) (void)hipStreamDestroy(p->stream);
+    delete p;
+    return 0;
+}
+
+int smashx_plan_ncells(const smashx_plan* p) { return p ? p->n : SMASHX_E_ARG; }
+
+int smashx_plan_cell_order(const smashx_plan* p, int* rows, int* cols) {
+    if (!p || !rows || !cols) return fail(SMASHX_E_ARG, "null argument");
+    for (int k = 0; k < p->n; ++k) { rows[k] = p->sch.cell_flat[k] % p->cfg.nrow; cols[k] = p->sch.cell_flat[k] / p->cfg.nrow; }
+    return 0;
+}
+
+static int alloc_forcing(smashx_plan* p) {
+    if (p->d_prcp) return 0;
+    int rc;
+    if ((rc = p->dmalloc(&p->d_prcp, (size_t)p->nt * p->npad))) return rc;
+    if ((rc = p->dmalloc(&p->d_pet, (size_t)p->nt * p->npad))) return rc;
+    p->A.prcp = p->d_prcp; p->A.pet = p->d_pet;
+    return 0;
+}
+
+int smashx_set_forcing(smashx_plan* p, const float* prcp, const float* pet, int sparse) {
+    if (!p || !prcp || !pet) return fail(SMASHX_E_ARG, "null argument");
+    int rc = set_device(p); if (rc) return rc;
+    if (sparse && !p->d_sparse_idx) return fail(SMASHX_E_ARG, "sparse forcing needs mesh.path at plan creation");
+    if ((rc = alloc_forcing(p))) return rc;
+    const long plane = sparse ? p->n : p->n2;
+    const int* idx = sparse ? p->d_sparse_idx : p->d_cell_flat;
+    const float* src[2] = {prcp, pet};
+    float* dst[2] = {p->d_prcp, p->d_pet};
+    for (int v = 0; v < 2; ++v)
+        for (int t = 0; t < p->nt; t += (int)p->stage_planes) {
+            const int rows = (int)std::min<long>(p->stage_planes, p->nt - t);
+            HIPCHK(hipMemcpyAsync(p->d_stage, src[v] + (size_t)t * plane, (size_t)rows * plane * 4, hipMemcpyHostToDevice, p->stream));
+            hipLaunchKernelGGL(k_gather_rows, dim3((p->n + 255) / 256, rows), dim3(256), 0, p->stream,
+                               dst[v] + (size_t)t * p->npad, p->d_stage, idx, p->n, p->npad, plane, rows);
+            HIPCHK(hipStreamSynchronize(p->stream));
+        }
+    p->have_forcing = true;
+    return 0;
+}
+
+int smashx_set_forcing_device_block(smashx_plan* p, int t0, int t1, const float* d_prcp, const float* d_pet) {
+    if (!p || !d_prcp || !d_pet || t0 < 0 || t1 > p->nt || t0 >= t1) return fail(SMASHX_E_ARG, "bad block");
+    int rc = set_device(p); if (rc) return rc;
+    if ((rc = alloc_forcing(p))) return rc;
+    HIPCHK(hipMemcpy2DAsync(p->d_prcp + (size_t)t0 * p->npad, (size_t)p->npad * 4, d_prcp, (size_t)p->n * 4, (size_t)p->n * 4, t1 - t0, hipMemcpyDeviceToDevice, p->stream));
+    HIPCHK(hipMemcpy2DAsync(p->d_pet + (size_t)t0 * p->npad, (size_t)p->npad * 4, d_pet, (size_t)p->n * 4, (size_t)p->n * 4, t1 - t0, hipMemcpyDeviceToDevice, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    p->have_forcing = true;
+    return 0;
+}
+
+int smashx_set_qobs(smashx_plan* p, const float* qobs) {
+    if (!p || (!qobs && p->ng > 0)) return fail(SMASHX_E_ARG, "null argument");
+    int rc = set_device(p); if (rc) return rc;
+    std::vector<float> tr((size_t)std::max(p->ng, 1) * p->nt);
+    for (int g = 0; g < p->ng; ++g)
+        for (int t = 0; t < p->nt; ++t) tr[(size_t)g * p->nt + t] = qobs[g + (size_t)p->ng * t];   // (ng,nt) column-major -> [g][t]
+    HIPCHK(hipMemcpy(p->d_qobs, tr.data(), tr.size() * 4, hipMemcpyHostToDevice));
+    p->have_qobs = true;
+    return 0;
+}
+
+int smashx_set_options(smashx_plan* p, const smashx_options* o) {
+    if (!p || !o) return fail(SMASHX_E_ARG, "null argument");
+    int rc = set_device(p); if (rc) return rc;
+    if (o->njf < 0 || o->njf > SX_MAXJF || o->njr < 0 || o->njr > 4) return fail(SMASHX_E_ARG, "njf/njr out of range");
+    if (o->optimize_start_step < 1 || o->optimize_start_step > p->nt) return fail(SMASHX_E_ARG, "optimize_start_step out of range");
+    for (int j = 0; j < o->njf; ++j)
+        if (o->jobs_fun[j] < SMASHX_NSE || o->jobs_fun[j] > SMASHX_LOGARITHMIC)
+            return fail(SMASHX_E_UNSUPPORTED, "signature-based jobs_fun are outside the hot path (SURVEY.md 8a a9)");
+    if (o->njr > 0) return fail(SMASHX_E_UNSUPPORTED, "jreg (prior/smoothing) is row f2 of SURVEY.md 8f: not built yet");
+    p->opt = *o;
+    p->opt.wgauge = nullptr;
+    for (int g = 0; g < p->ng; ++g) {
+        const float w = o->wgauge ? o->wgauge[g] : 1.f / p->ng;
+        if (w < 0.f) return fail(SMASHX_E_UNSUPPORTED, "negative wgauge (median over gauges, mwd_cost.f90:145-154) not built yet");
+        p->wgauge[g] = w;
+    }
+    HIPCHK(hipMemcpy(p->d_wgauge, p->wgauge.data(), p->wgauge.size() * 4, hipMemcpyHostToDevice));
+    p->have_options = true;
+    return 0;
+}
+
+int smashx_upload(smashx_plan* p, const smashx_parameters* params, const smashx_parameters* params_bgd,
+                  const smashx_states* states, const smashx_states* states_bgd) {
+    (void)params_bgd; (void)states_bgd;   // only read by jreg (not built yet)
+    if (!p || !params || !states) return fail(SMASHX_E_ARG, "null argument");
+    int rc = set_device(p); if (rc) return rc;
+    const int st = p->st;
+    const dim3 b(256), gfull((unsigned)((p->n2 + 255) / 256)), gk((p->n + 255) / 256);
+    float* pdst[6] = {p->A.ci, p->A.cp, p->A.cft, p->A.cst, p->A.exc, p->A.lr};
+    for (int i = 0; i < 6; ++i) {
+        const int f = kParamFields[i];
+        if (!uses_param(st, f)) continue;
+        if (!params->f[f]) return fail(SMASHX_E_ARG, "a parameter field the structure uses is NULL");
+        HIPCHK(hipMemcpyAsync(p->d_fullP[f], params->f[f], (size_t)p->n2 * 4, hipMemcpyHostToDevice, p->stream));
+        if (p->opt.denormalize_forward)
+            hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullP[f], p->n2, p->opt.lb_parameters[f], p->opt.ub_parameters[f]);
+        hipLaunchKernelGGL(k_gather, gk, b, 0, p->stream, pdst[i], p->d_fullP[f], p->d_cell_flat, p->n);
+    }
+    for (int i = 0; i < 5; ++i) {
+        const int f = kStateFields[i];
+        if (!uses_state(st, f)) continue;
+        if (!states->f[f]) return fail(SMASHX_E_ARG, "a state field the structure uses is NULL");
+        HIPCHK(hipMemcpyAsync(p->d_fullS[f], states->f[f], (size_t)p->n2 * 4, hipMemcpyHostToDevice, p->stream));
+        if (p->opt.denormalize_forward)
+            hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullS[f], p->n2, p->opt.lb_states[f], p->opt.ub_states[f]);
+        hipLaunchKernelGGL(k_gather, gk, b, 0, p->stream, p->st0[i], p->d_fullS[f], p->d_cell_flat, p->n);
+    }
+    hipLaunchKernelGGL(sx_k_prep_routing, gk, b, 0, p->stream, p->A);
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipGetLastError());
+    p->uploaded = true;
+    return 0;
+}
+
+int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
+    if (!p) return fail(SMASHX_E_ARG, "null plan");
+    if (!p->have_forcing) return fail(SMASHX_E_STATE, "forcing not set");
+    if (!p->uploaded) return fail(SMASHX_E_STATE, "parameters/states not uploaded");
+    int rc = set_device(p); if (rc) return rc;
+    if ((rc = ensure_chunk_buffers(p, adjoint != 0))) return rc;
+    p->launches.clear(); p->pool_used = 0;
+    HIPCHK(hipEventRecord(p->ev0, p->stream));
+    if ((rc = restore_states(p, p->st0))) return rc;
+    const int C = p->nchunks;
+    if (!adjoint) {
+        for (int c = 0; c < C; ++c) {
+            const int t0 = c * p->Tc, T = chunk_len(p, c);
+            vert_fwd(p, false, t0, T);
+            route_fwd(p, false, t0, T);
+        }
+        if ((rc = run_cost(p, 0, 0.f))) return rc;
+    } else {
+        for (int c = 0; c < C; ++c) {
+            const int t0 = c * p->Tc, T = chunk_len(p, c);
+            if (C > 1) {
+                float* src[5] = {p->A.hi, p->A.hp, p->A.hft, p->A.hst, p->A.hlr};
+                for (int i = 0; i < 5; ++i)
+                    if (uses_state(p->st, kStateFields[i]))
+                        HIPCHK(hipMemcpyAsync(p->ckpt + ((size_t)c * 5 + i) * p->npad, src[i], (size_t)p->npad * 4, hipMemcpyDeviceToDevice, p->stream));
+            }
+            vert_fwd(p, C == 1, t0, T);
+            route_fwd(p, C == 1, t0, T);
+        }
+        if ((rc = run_cost(p, 1, cost_b))) return rc;
+        float* g[11] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.lr_b, p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b, p->A.hlr_b};
+        for (auto q : g) HIPCHK(hipMemsetAsync(q, 0, (size_t)p->npad * 4, p->stream));
+        if (p->ng == 0) HIPCHK(hipMemsetAsync(p->A.qgb, 0, (size_t)std::max(p->ngc, 1) * p->nt * 4, p->stream));
+        for (int c = C - 1; c >= 0; --c) {
+            const int t0 = c * p->Tc, T = chunk_len(p, c);
+            if (C > 1) {
+                float* src[5];
+                for (int i = 0; i < 5; ++i) src[i] = p->ckpt + ((size_t)c * 5 + i) * p->npad;
+                if ((rc = restore_states(p, src))) return rc;
+                vert_fwd(p, true, t0, T);
+                route_fwd(p, true, t0, T);
+            }
+            route_adj(p, t0, T);
+            vert_adj(p, t0, T);
+        }
+    }
+    HIPCHK(hipEventRecord(p->ev1, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipGetLastError());
+    // timing
+    smashx_timing& tm = p->timing;
+    std::memset(&tm, 0, sizeof(tm));
+    (void)hipEventElapsedTime(&tm.sweep_ms, p->ev0, p->ev1);
+    for (const Launch& l : p->launches) {
+        float ms = 0.f;
+        if (l.a && l.b) (void)hipEventElapsedTime(&ms, l.a, l.b);
+        switch (l.kind) {
+            case 0: tm.vert_fwd_ms += ms; tm.vert_fwd_launches++; break;
+            case 1: tm.route_fwd_ms += ms; tm.route_fwd_launches++; break;
+            case 2: tm.route_adj_ms += ms; tm.route_adj_launches++; break;
+            case 3: tm.vert_adj_ms += ms; tm.vert_adj_launches++; break;
+            default: tm.cost_ms += ms; break;
+        }
+    }
+    tm.n_chunks = p->nchunks; tm.chunk_steps = p->Tc; tm.n_rounds = p->sch.nrounds; tm.n_groups = p->sch.ngroups;
+    tm.device_bytes = p->bytes;
+    p->last_adjoint = adjoint;
+    return 0;
+}
+
+int smashx_get_timing(const smashx_plan* p, smashx_timing* out) {
+    if (!p || !out) return fail(SMASHX_E_ARG, "null argument");
+    *out = p->timing;
+    return 0;
+}
+
+int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smashx_states* states, float* qsim,
+                    smashx_costs* costs, smashx_states* fstates, smashx_parameters* params_b, smashx_states* states_b) {
+    if (!p) return fail(SMASHX_E_ARG, "null plan");
+    int rc = set_device(p); if (rc) return rc;
+    const int st = p->st;
+    const dim3 b(256), gfull((unsigned)((p->n2 + 255) / 256)), gk((p->n + 255) / 256);
+    // discharge at gauges: output%qsim(ng,nt)
+    if (qsim && p->ng > 0) {
+        std::vector<float> qg((size_t)p->ngc * p->nt);
+        HIPCHK(hipMemcpy(qg.data(), p->A.qg, qg.size() * 4, hipMemcpyDeviceToHost));
+        for (int g = 0; g < p->ng; ++g)
+            for (int t = 0; t < p->nt; ++t) qsim[g + (size_t)p->ng * t] = qg[(size_t)p->gauge_gid[g] * p->nt + t];
+    }
+    if (costs) {
+        float jobs = 0.f;
+        if (p->ng > 0) HIPCHK(hipMemcpy(&jobs, p->d_cost_out, 4, hipMemcpyDeviceToHost));
+        const float jreg = 0.f;                      // njr = 0 (set_options rejects anything else for now)
+        costs->cost = jobs + p->opt.wjreg * jreg;    // mwd_cost.f90:300
+        costs->cost_jobs = jobs; costs->cost_jreg = jreg;
+    }
+    // final states: output%fstates = states (forward.f90:71); inactive cells keep their entry values
+    if (fstates && !adjoint) {
+        float* cur[5] = {p->A.hi, p->A.hp, p->A.hft, p->A.hst, p->A.hlr};
+        for (int i = 0; i < 5; ++i) {
+            const int f = kStateFields[i];
+            if (!uses_state(st, f) || !fstates->f[f]) continue;
+            HIPCHK(hipMemcpyAsync(p->d_stage, p->d_fullS[f], (size_t)p->n2 * 4, hipMemcpyDeviceToDevice, p->stream));
+            hipLaunchKernelGGL(k_scatter, gk, b, 0, p->stream, p->d_stage, cur[i], p->d_cell_flat, p->n, 1.f, 0);
+            HIPCHK(hipMemcpyAsync(fstates->f[f], p->d_stage, (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
+            HIPCHK(hipStreamSynchronize(p->stream));
+        }
+    }
+    // parameters / states as the reference leaves them (forward.f90:33-38,72; mwd_cost.f90:284-298):
+    // denormalised; base_forward additionally sends them through normalise -> denormalise inside compute_cost.
+    if (p->opt.denormalize_forward) {
+        for (int i = 0; i < 6; ++i) {
+            const int f = kParamFields[i];
+            if (!uses_param(st, f) || !params || !params->f[f]) continue;
+            if (!adjoint) {
+                hipLaunchKernelGGL(k_normalize, gfull, b, 0, p->stream, p->d_fullP[f], p->n2, p->opt.lb_parameters[f], p->opt.ub_parameters[f]);
+                hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullP[f], p->n2, p->opt.lb_parameters[f], p->opt.ub_parameters[f]);
+            }
+            HIPCHK(hipMemcpyAsync(params->f[f], p->d_fullP[f], (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
+        }
+        for (int i = 0; i < 5; ++i) {
+            const int f = kStateFields[i];
+            if (!uses_state(st, f) || !states || !states->f[f]) continue;
+            if (!adjoint) {
+                hipLaunchKernelGGL(k_normalize, gfull, b, 0, p->stream, p->d_fullS[f], p->n2, p->opt.lb_states[f], p->opt.ub_states[f]);
+                hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullS[f], p->n2, p->opt.lb_states[f], p->opt.ub_states[f]);
+            }
+            HIPCHK(hipMemcpyAsync(states->f[f], p->d_fullS[f], (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
+        }
+        HIPCHK(hipStreamSynchronize(p->stream));
+        p->uploaded = false;   // the full-field copies were transformed: a new upload is required
+    }
+    if (adjoint) {
+        if (!p->adj_ready) return fail(SMASHX_E_STATE, "no adjoint sweep has run");
+        float* gp[6] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.lr_b};
+        float* gs[5] = {p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b, p->A.hlr_b};
+        // parameters_b / states_b are fully overwritten (forward_db.f90:10869-10870); DENORMALIZE_*_B multiplies by (ub-lb)
+        if (params_b)
+            for (int f = 0; f < SMASHX_GNP; ++f) {
+                if (!params_b->f[f]) continue;
+                int i = -1;
+                for (int q = 0; q < 6; ++q) if (kParamFields[q] == f) i = q;
+                if (i < 0 || !uses_param(st, f)) { std::memset(params_b->f[f], 0, (size_t)p->n2 * 4); continue; }
+                HIPCHK(hipMemsetAsync(p->d_stage, 0, (size_t)p->n2 * 4, p->stream));
+                hipLaunchKernelGGL(k_scatter, gk, b, 0, p->stream, p->d_stage, gp[i], p->d_cell_flat, p->n,
+                                   p->opt.ub_parameters[f] - p->opt.lb_parameters[f], p->opt.denormalize_forward);
+                HIPCHK(hipMemcpyAsync(params_b->f[f], p->d_stage, (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
+                HIPCHK(hipStreamSynchronize(p->stream));
+            }
+        if (states_b)
+            for (int f = 0; f < SMASHX_GNS; ++f) {
+                if (!states_b->f[f]) continue;
+                int i = -1;
+                for (int q = 0; q < 5; ++q) if (kStateFields[q] == f) i = q;
+                if (i < 0 || !uses_state(st, f)) { std::memset(states_b->f[f], 0, (size_t)p->n2 * 4); continue; }
+                HIPCHK(hipMemsetAsync(p->d_stage, 0, (size_t)p->n2 * 4, p->stream));
+                hipLaunchKernelGGL(k_scatter, gk, b, 0, p->stream, p->d_stage, gs[i], p->d_cell_flat, p->n,
+                                   p->opt.ub_states[f] - p->opt.lb_states[f], p->opt.denormalize_forward);
+                HIPCHK(hipMemcpyAsync(states_b->f[f], p->d_stage, (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
+                HIPCHK(hipStreamSynchronize(p->stream));
+            }
+    }
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int smashx_forward(smashx_plan* p, smashx_parameters* params, const smashx_parameters* params_bgd, smashx_states* states,
+                   const smashx_states* states_bgd, float* qsim, smashx_costs* costs, smashx_states* fstates) {
+    int rc;
+    if ((rc = smashx_upload(p, params, params_bgd, states, states_bgd))) return rc;
+    if ((rc = smashx_sweep(p, 0, 0.f))) return rc;
+    return smashx_download(p, 0, params, states, qsim, costs, fstates, nullptr, nullptr);
+}
+
+int smashx_forward_b(smashx_plan* p, smashx_parameters* params, const smashx_parameters* params_bgd, smashx_states* states,
+                     const smashx_states* states_bgd, float cost_b, float* qsim, smashx_costs* costs,
+                     smashx_parameters* params_b, smashx_states* states_b) {
+    int rc;
+    if ((rc = smashx_upload(p, params, params_bgd, states, states_bgd))) return rc;
+    if ((rc = smashx_sweep(p, 1, cost_b))) return rc;
+    return smashx_download(p, 1, params, states, qsim, costs, nullptr, params_b, states_b);
+}
+
+}  // extern "C"

@@ -1,0 +1,225 @@
+// sx_cost.h -- gauge-discharge cost and its adjoint seeds on the device.
+//
+//   compute_jobs     smash/solver/optimize/mwd_cost.f90:37-156   (nse :350, kge :403-490, se :492, rmse :521, logarithmic :558)
+//   COMPUTE_JOBS_B   smash/solver/forward/forward_db.f90:2553-2715 (NSE_B :3505, KGE_B :3657-3829, SE_B :3868, RMSE_B :3936, LOGARITHMIC_B :4025)
+//
+// The reference accumulates every sum sequentially in fp32 over time.  A tree reduction would move
+// the cost by ~1e-6 relative, i.e. by the whole parity budget, so each gauge is reduced by ONE
+// wavefront that loads 64 consecutive steps coalesced and folds them in time order through
+// cross-lane broadcasts (v_readlane): wave-wide loads, reference summation order.  The seeds
+// qsim_b(g,t) are then independent per (g,t) and computed fully in parallel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "sx_math.h"
+
+#define SX_MAXJF 8
+
+struct SxGaugeSums {   // per gauge, reference order sums
+    int n;
+    float sum_x, sum_y, sum_xx, sum_yy, sum_xy, se, lg;
+};
+
+struct SxCostCoef {    // per (gauge, cost function): what the per-element adjoint needs
+    int kind;          // 0 none, 1 nse "x*c_xy + 2*y*c_yy", 4 kge "... + c_y", 2 se-like "-2*(x-y)*c", 3 logarithmic
+    float c_xy, c_yy, c_y, c;
+};
+
+struct SxCostArgs {
+    int ng, nt, s0;                 // s0 = optimize_start_step - 1
+    int njf;
+    int jobs_fun[SX_MAXJF];
+    float wjobs_fun[SX_MAXJF];
+    float dt, dx;
+    const float* qg;                // [ngc][nt]
+    float* qgb;                     // [ngc][nt]
+    int ngc;
+    const int* gauge_gid;           // [ng] gauge -> gauge-cell id
+    const int* gauge_flwacc;        // [ng]
+    const float* area;              // [ng]
+    const float* wgauge;            // [ng]
+    const float* qobs;              // [ng][nt]  (time fastest)
+    float* qsim_b;                  // [ng][nt]
+    SxGaugeSums* sums;              // [ng]
+    SxCostCoef* coef;               // [ng][SX_MAXJF]
+    float* out;                     // [0] = jobs
+    float jobs_b;
+};
+
+__device__ __forceinline__ float sx_qs(const SxCostArgs& C, int g, int t) {
+    return C.qg[(size_t)C.gauge_gid[g] * C.nt + t] * C.dt / C.area[g] * 1e3f;          // mwd_cost.f90:84-85
+}
+__device__ __forceinline__ float sx_qo(const SxCostArgs& C, int g, int t) {
+    return C.qobs[(size_t)g * C.nt + t] * C.dt / ((float)C.gauge_flwacc[g] * C.dx * C.dx) * 1e3f;   // :90-92
+}
+
+// one wavefront per gauge
+__global__ __launch_bounds__(64) void sx_k_cost_sums(SxCostArgs C) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    SxGaugeSums S; S.n = 0; S.sum_x = S.sum_y = S.sum_xx = S.sum_yy = S.sum_xy = S.se = S.lg = 0.f;
+    const float w = C.wgauge[g];
+    if (w > 0.f || w < 0.f) {
+        bool want_lg = false;
+        for (int j = 0; j < C.njf; ++j) want_lg |= (C.jobs_fun[j] == 6);
+        for (int tb = C.s0; tb < C.nt; tb += 64) {
+            const int t = tb + lane;
+            float x = -1.f, y = 0.f;
+            if (t < C.nt) { x = sx_qo(C, g, t); y = sx_qs(C, g, t); }
+            const int cnt = min(64, C.nt - tb);
+            for (int i = 0; i < cnt; ++i) {
+                const float xi = __shfl(x, i), yi = __shfl(y, i);
+                if (xi >= 0.f) {
+                    S.n++;
+                    S.sum_x = S.sum_x + xi;
+                    S.sum_y = S.sum_y + yi;
+                    S.sum_xx = S.sum_xx + (xi * xi);
+                    S.sum_yy = S.sum_yy + (yi * yi);
+                    S.sum_xy = S.sum_xy + (xi * yi);
+                    S.se = S.se + (xi - yi) * (xi - yi);
+                }
+                if (want_lg && xi > 0.f && yi > 0.f) {
+                    const float lgv = sx_logf(yi / xi);
+                    S.lg = S.lg + xi * lgv * lgv;
+                }
+            }
+        }
+    }
+    if (lane == 0) C.sums[g] = S;
+}
+
+struct SxKge { float mean_x, mean_y, var_x, var_y, cov, r, a, b; };
+__device__ __forceinline__ SxKge sx_kge_components(const SxGaugeSums& S) {
+    SxKge k;
+    const float n = (float)S.n;
+    k.mean_x = S.sum_x / n;
+    k.mean_y = S.sum_y / n;
+    k.var_x = (S.sum_xx / n) - (k.mean_x * k.mean_x);
+    k.var_y = (S.sum_yy / n) - (k.mean_y * k.mean_y);
+    k.cov = (S.sum_xy / n) - (k.mean_x * k.mean_y);
+    k.r = (k.cov / sqrtf(k.var_x)) / sqrtf(k.var_y);
+    k.a = sqrtf(k.var_y) / sqrtf(k.var_x);
+    k.b = k.mean_y / k.mean_x;
+    return k;
+}
+__device__ __forceinline__ float sx_kge_value(const SxKge& k) {
+    return sqrtf((k.r - 1.f) * (k.r - 1.f) + (k.b - 1.f) * (k.b - 1.f) + (k.a - 1.f) * (k.a - 1.f));
+}
+__device__ __forceinline__ void sx_kge_coef(const SxGaugeSums& S, const SxKge& k, float res_b, SxCostCoef& c) {
+    const float arg1 = (k.r - 1.f) * (k.r - 1.f) + (k.b - 1.f) * (k.b - 1.f) + (k.a - 1.f) * (k.a - 1.f);
+    const float arg1_b = (arg1 == 0.f) ? 0.f : res_b / (2.0f * sqrtf(arg1));
+    const float r_b = 2.f * (k.r - 1.f) * arg1_b, b_b = 2.f * (k.b - 1.f) * arg1_b, a_b = 2.f * (k.a - 1.f) * arg1_b;
+    const float n = (float)S.n;
+    const float result1 = sqrtf(k.var_x), result2 = sqrtf(k.var_y);
+    const float result1_b = a_b / sqrtf(k.var_x);
+    float var_y_b = (k.var_y == 0.f) ? 0.f : result1_b / (2.0f * sqrtf(k.var_y));
+    const float temp_b = r_b / (result1 * result2);
+    const float cov_b = temp_b;
+    const float result2_b = -(k.cov * temp_b / result2);
+    if (!(k.var_y == 0.f)) var_y_b = var_y_b + result2_b / (2.0f * sqrtf(k.var_y));
+    const float mean_y_b = b_b / k.mean_x - k.mean_x * cov_b - 2.f * k.mean_y * var_y_b;
+    c.kind = 4; c.c_xy = cov_b / n; c.c_yy = var_y_b / n; c.c_y = mean_y_b / n; c.c = 0.f;
+}
+
+// single thread: per-gauge criteria, weighted sum over gauges in gauge order, adjoint coefficients
+__global__ void sx_k_cost_final(SxCostArgs C, int adjoint) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float jobs = 0.f;
+    for (int g = 0; g < C.ng; ++g) {
+        const float w = C.wgauge[g];
+        if (!(w > 0.f || w < 0.f)) continue;
+        const SxGaugeSums S = C.sums[g];
+        const bool any = S.n > 0;
+        float gauge_jobs = 0.f, j_imd = 0.f;
+        for (int j = 0; j < C.njf; ++j) {
+            if (any) {
+                const float n = (float)S.n;
+                switch (C.jobs_fun[j]) {
+                    case 1: { const float mean_x = S.sum_x / n;
+                              const float num = S.sum_xx - 2.f * S.sum_xy + S.sum_yy;
+                              const float den = S.sum_xx - n * mean_x * mean_x;
+                              j_imd = num / den; } break;
+                    case 2: j_imd = sx_kge_value(sx_kge_components(S)); break;
+                    case 3: { const float imd = sx_kge_value(sx_kge_components(S)); j_imd = imd * imd; } break;
+                    case 4: j_imd = S.se; break;
+                    case 5: j_imd = sqrtf(S.se / n); break;
+                    case 6: j_imd = S.lg; break;
+                    default: break;
+                }
+            }
+            gauge_jobs = gauge_jobs + C.wjobs_fun[j] * j_imd;
+        }
+        jobs = jobs + w * gauge_jobs;   // wgauge < 0 (median over gauges) is rejected on the host
+    }
+    C.out[0] = jobs;
+    if (!adjoint) return;
+    float j_imd_b = 0.f;   // carried across gauges exactly like the reference's scalar (forward_db.f90:2656-2704)
+    for (int g = C.ng - 1; g >= 0; --g) {
+        for (int j = 0; j < SX_MAXJF; ++j) { SxCostCoef z; z.kind = 0; z.c_xy = z.c_yy = z.c_y = z.c = 0.f; C.coef[g * SX_MAXJF + j] = z; }
+        const float w = C.wgauge[g];
+        if (!(w > 0.f)) continue;
+        const SxGaugeSums S = C.sums[g];
+        const bool any = S.n > 0;
+        const float gauge_jobs_b = w * C.jobs_b;
+        const float n = (float)S.n;
+        for (int j = C.njf - 1; j >= 0; --j) {
+            j_imd_b = j_imd_b + C.wjobs_fun[j] * gauge_jobs_b;
+            if (!any) continue;
+            SxCostCoef c; c.kind = 0; c.c_xy = c.c_yy = c.c_y = c.c = 0.f;
+            switch (C.jobs_fun[j]) {
+                case 1: { const float mean_x = S.sum_x / n;
+                          const float den = S.sum_xx - n * mean_x * mean_x;
+                          const float num_b = j_imd_b / den;
+                          c.kind = 1; c.c_yy = num_b; c.c_xy = -(2.f * num_b); c.c_y = 0.f; j_imd_b = 0.f; } break;
+                case 2: { const SxKge k = sx_kge_components(S); sx_kge_coef(S, k, j_imd_b, c); j_imd_b = 0.f; } break;
+                case 3: { const SxKge k = sx_kge_components(S); const float imd = sx_kge_value(k);
+                          sx_kge_coef(S, k, 2.f * imd * j_imd_b, c); j_imd_b = 0.f; } break;
+                case 4: c.kind = 2; c.c = j_imd_b; j_imd_b = 0.f; break;
+                case 5: { const float result1 = S.se;
+                          c.kind = 2; c.c = (result1 / n == 0.f) ? 0.f : j_imd_b / (n * 2.0f * sqrtf(result1 / n)); j_imd_b = 0.f; } break;
+                case 6: c.kind = 3; c.c = j_imd_b; j_imd_b = 0.f; break;
+                default: break;
+            }
+            C.coef[g * SX_MAXJF + j] = c;
+        }
+    }
+}
+
+// parallel over (gauge, t): qsim_b(g,t)  (forward_db.f90:2709-2712)
+__global__ void sx_k_cost_seeds(SxCostArgs C) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (t >= C.nt) return;
+    float out = 0.f;
+    if (t >= C.s0 && C.wgauge[g] > 0.f) {
+        const float x = sx_qo(C, g, t), y = sx_qs(C, g, t);
+        float y_b = 0.f;
+        for (int j = C.njf - 1; j >= 0; --j) {
+            const SxCostCoef c = C.coef[g * SX_MAXJF + j];
+            if (c.kind == 1) { if (x >= 0.f) y_b = y_b + x * c.c_xy + 2.f * y * c.c_yy; }
+            else if (c.kind == 4) { if (x >= 0.f) y_b = y_b + x * c.c_xy + 2.f * y * c.c_yy + c.c_y; }
+            else if (c.kind == 2) { if (x >= 0.f) y_b = y_b - 2.f * (x - y) * c.c; }
+            else if (c.kind == 3) {
+                if (x > 0.f && y > 0.f) {
+                    const float arg1 = y / x, arg2 = y / x;
+                    const float arg1_b = sx_logf(arg2) * x * c.c / arg1;
+                    const float arg2_b = sx_logf(arg1) * x * c.c / arg2;
+                    y_b = y_b + arg2_b / x + arg1_b / x;
+                }
+            }
+        }
+        out = 0.f + C.dt * 1e3f * y_b / C.area[g];
+    }
+    C.qsim_b[(size_t)g * C.nt + t] = out;
+}
+
+// seeds per gauge CELL: q_b(cell) accumulates output_b%qsim(g,t) for g = ng..1 (forward_db.f90:8650-8654)
+__global__ void sx_k_cost_cellseeds(SxCostArgs C) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gc = blockIdx.y;
+    if (t >= C.nt) return;
+    float acc = 0.f;
+    for (int g = C.ng - 1; g >= 0; --g)
+        if (C.gauge_gid[g] == gc) acc = acc + C.qsim_b[(size_t)g * C.nt + t];
+    C.qgb[(size_t)gc * C.nt + t] = acc;
+}

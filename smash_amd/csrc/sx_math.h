@@ -1,0 +1,196 @@
+// sx_math.h -- device math for the smashx kernels (gfx950).
+//
+// Parity design (DESIGN.md "Numerics"): the reference is fp32 Fortran calling glibc's libm.  To stay
+// within 1e-6 of it over thousands of recurrent steps the kernels must reproduce libm's *rounded
+// results*, not just its accuracy class:
+//   * glibc 2.35 powf/expf/logf are correctly rounded in 99.94 % of calls (measured), so the
+//     kernels compute the few fixed powers the model needs (x^-4, x^-5, y^-1/4, y^-5/4, h^3.5,
+//     h^2.5) and exp/log as "fp32 hardware seed + one fp64 Newton step, round once" -- correctly
+//     rounded except in ~1e-7 of cases, no table, a handful of fp64 FMAs.
+//   * glibc 2.35 tanhf is the fdlibm float algorithm (expm1f based) and is NOT correctly rounded
+//     (36 % of results differ from the correctly rounded value), so sx_tanhf restates that published
+//     fdlibm algorithm operation by operation; it is bit-identical to glibc on every float in
+//     [2^-63, 24] (checked exhaustively on the host build of this header, tests/test_sx_math.py).
+// Everything is compiled with -ffp-contract=off; the only fused operations are the explicit fma().
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>
+#define SX_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#include <string.h>
+#define SX_HD static inline
+#endif
+
+SX_HD uint32_t sx_f2u(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u; memcpy(&u, &f, 4); return u;
+#endif
+}
+SX_HD float sx_u2f(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; memcpy(&f, &u, 4); return f;
+#endif
+}
+
+// fast fp32 seeds (~1 ulp); only their fp64-refined results are ever used
+SX_HD float sx_seed_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+SX_HD float sx_seed_rsq(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(x);
+#else
+    return 1.0f / sqrtf(x);
+#endif
+}
+SX_HD float sx_seed_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+
+// 1/x in fp64 to ~2^-45 from an fp32 seed: one Newton step  u <- u + u(1 - x u)
+SX_HD double sx_rcp_d(float x) {
+    const double d = (double)x;
+    double u = (double)sx_seed_rcp(x);
+    const double e = fma(-d, u, 1.0);
+    return fma(u, e, u);
+}
+// y^(-1/4) in fp64 to ~2^-43: Newton on r^-4 = y:  r <- r + r(1 - y r^4)/4
+SX_HD double sx_rquart_d(float y) {
+    const double d = (double)y;
+    double r = (double)sx_seed_rsq(sx_seed_sqrt(y));
+    const double r2 = r * r;
+    const double e = fma(-d, r2 * r2, 1.0);
+    return fma(r, 0.25 * e, r);
+}
+// sqrt(h) in fp64 to ~2^-44:  s = h*rs;  s <- s + (h - s^2) * rs/2
+SX_HD double sx_sqrt_d(float h) {
+    const double d = (double)h;
+    const double r = (double)sx_seed_rsq(h);
+    double s = d * r;
+    const double e = fma(-s, s, d);
+    return fma(e, 0.5 * r, s);
+}
+
+// powf(x, -4), powf(x, -5)   [x > 0]   (gr_transfer, md_gr_operator.f90:94-106; GR_TRANSFER_B forward_db.f90:6349-6368)
+SX_HD float sx_pow_m4(float x) { const double u = sx_rcp_d(x); const double u2 = u * u; return (float)(u2 * u2); }
+SX_HD void sx_pow_m4_m5(float x, float* m4, float* m5) {
+    const double u = sx_rcp_d(x); const double u2 = u * u; const double u4 = u2 * u2;
+    *m4 = (float)u4; *m5 = (float)(u4 * u);
+}
+// powf(y, -0.25), powf(y, -1.25)   [y > 0]
+SX_HD float sx_pow_m025(float y) { return (float)sx_rquart_d(y); }
+SX_HD void sx_pow_m025_m125(float y, float* m025, float* m125) {
+    const double r = sx_rquart_d(y); const double r2 = r * r;
+    *m025 = (float)r; *m125 = (float)((r2 * r2) * r);
+}
+// powf(h, 3.5), powf(h, 2.5)   [h >= 0]   (gr_exchange md_gr_operator.f90:77; GR_EXCHANGE_B forward_db.f90:6155-6156)
+SX_HD float sx_pow_3p5(float h) {
+    if (!(h > 0.f)) return 0.f;
+    const double d = (double)h; return (float)(((d * d) * d) * sx_sqrt_d(h));
+}
+SX_HD void sx_pow_3p5_2p5(float h, float* p35, float* p25) {
+    if (!(h > 0.f)) { *p35 = 0.f; *p25 = 0.f; return; }
+    const double d = (double)h, s = sx_sqrt_d(h), d2 = d * d;
+    *p35 = (float)((d2 * d) * s); *p25 = (float)(d2 * s);
+}
+
+// expf / logf: fp64 evaluation, one rounding (glibc's float versions are correctly rounded in 99.94 %)
+SX_HD float sx_expf(float x) { return (float)exp((double)x); }
+SX_HD float sx_logf(float x) { return (float)log((double)x); }
+// powf for the rare general call sites (gap branch) -- fp64 pow, one rounding
+SX_HD float sx_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+
+// ---- fdlibm float expm1 / tanh (Sun Microsystems 1993, public algorithm; the float port is what
+// ---- glibc 2.35 ships as expm1f/tanhf).  Restated for arguments the model can produce:
+// ---- expm1 for x <= 44 (tanh passes -2|x| in [-2,0) or 2|x| in [2,44)).
+SX_HD float sx_expm1f(float x) {
+    const float one = 1.0f, ln2_hi = 6.9313812256e-01f, ln2_lo = 9.0580006145e-06f, invln2 = 1.4426950216e+00f;
+    const float Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f, Q3 = -7.9365076090e-05f,
+                Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+    float y, hi, lo, c = 0.f, t, e, hxs, hfx, r1;
+    int32_t k;
+    uint32_t hx = sx_f2u(x);
+    const uint32_t xsb = hx & 0x80000000u;
+    hx &= 0x7fffffffu;
+    if (hx >= 0x4195b844u) {            // |x| >= 27 ln2
+        if (xsb) return -1.0f;          // fdlibm: tiny - one
+        return sx_expf(x) - one;        // never reached by tanh for |x| < 22 (2|x| < 44 < 88.7): fdlibm falls through
+    }
+    if (hx > 0x3eb17218u) {             // |x| > 0.5 ln2
+        if (hx < 0x3F851592u) {         // |x| < 1.5 ln2
+            if (!xsb) { hi = x - ln2_hi; lo = ln2_lo; k = 1; }
+            else      { hi = x + ln2_hi; lo = -ln2_lo; k = -1; }
+        } else {
+            k = (int32_t)(invln2 * x + (xsb ? -0.5f : 0.5f));
+            t = (float)k;
+            hi = x - t * ln2_hi;
+            lo = t * ln2_lo;
+        }
+        x = hi - lo;
+        c = (hi - x) - lo;
+    } else if (hx < 0x33000000u) {      // |x| < 2^-25
+        return x;
+    } else {
+        k = 0;
+    }
+    hfx = 0.5f * x;
+    hxs = x * hfx;
+    r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+    t = 3.0f - r1 * hfx;
+    e = hxs * ((r1 - t) / (6.0f - x * t));
+    if (k == 0) return x - (x * e - hxs);
+    e = (x * (e - c) - c);
+    e -= hxs;
+    if (k == -1) return 0.5f * (x - e) - 0.5f;
+    if (k == 1) {
+        if (x < -0.25f) return -2.0f * (e - (x + 0.5f));
+        return one + 2.0f * (x - e);
+    }
+    if (k <= -2 || k > 56) {
+        y = one - (e - x);
+        y = sx_u2f(sx_f2u(y) + ((uint32_t)k << 23));
+        return y - one;
+    }
+    if (k < 23) {
+        t = sx_u2f(0x3f800000u - (0x1000000u >> k));
+        y = t - (e - x);
+        y = sx_u2f(sx_f2u(y) + ((uint32_t)k << 23));
+    } else {
+        t = sx_u2f((uint32_t)(0x7f - k) << 23);
+        y = x - (e + t);
+        y += one;
+        y = sx_u2f(sx_f2u(y) + ((uint32_t)k << 23));
+    }
+    return y;
+}
+
+SX_HD float sx_tanhf(float x) {
+    const uint32_t jx = sx_f2u(x), ix = jx & 0x7fffffffu;
+    float t, z;
+    if (ix < 0x41b00000u) {             // |x| < 22
+        if (ix == 0) return x;
+        if (ix < 0x24000000u) return x * (1.0f + x);
+        const float ax = sx_u2f(ix);
+        if (ix >= 0x3f800000u) { t = sx_expm1f(2.0f * ax); z = 1.0f - 2.0f / (t + 2.0f); }
+        else                   { t = sx_expm1f(-2.0f * ax); z = -t / (t + 2.0f); }
+    } else {
+        z = 1.0f - 1e-30f;
+    }
+    return (jx >> 31) ? -z : z;
+}

@@ -1,0 +1,294 @@
+// sx_ops.h -- per-cell operators of the hot path as device functions (gfx950), forward and adjoint.
+//
+// Forward operators restate, operation by operation (fp32, no contraction):
+//   gr_interception  smash/solver/operator/md_gr_operator.f90:20-34
+//   gr_production    md_gr_operator.f90:36-67      (beta = 1000 at every call site, md_forward_structure.f90:122,306,492,677)
+//   gr_exchange      md_gr_operator.f90:69-79
+//   gr_transfer      md_gr_operator.f90:81-110     (n = 5)
+// Adjoint operators evaluate the local adjoint expressions of the Tapenade output in its order:
+//   GR_INTERCEPTION_B forward_db.f90:5878-5925, GR_PRODUCTION_B :6012-6103, GR_EXCHANGE_B :6147-6157,
+//   GR_TRANSFER_B :6275-6412.
+// libm calls are replaced by the sx_math.h routines (see its header for the parity argument).
+#pragma once
+
+#include "sx_math.h"
+
+#define SX_DEV __device__ __forceinline__
+
+struct SxCellParams {   // time-invariant per cell, hoisted out of the time loop
+    float ci, cp, inv_cp, cft, cst, exc;
+    float cft_m4, cst_m4;   // powf(ct, -4)
+};
+
+// ---------------------------------------------------------------- forward
+SX_DEV void sx_interception(float prcp, float pet, float ci, float& hi, float& pn, float& ei) {
+    ei = fminf(pet, prcp + hi * ci);
+    pn = fmaxf(0.f, prcp - ci * (1.f - hi) - ei);
+    hi = hi + (prcp - ei - pn) / ci;
+}
+
+SX_DEV void sx_production(float pn, float en, float cp, float inv_cp, float& hp, float& pr, float& perc) {
+    const float beta = 1000.f;
+    pr = 0.f;
+    // tanh(0) = 0 exactly, and at most one of pn, en is non-zero in practice: skip the dead evaluation
+    float thp = 0.f, the = 0.f;
+    if (pn > 0.f) thp = sx_tanhf(pn * inv_cp);
+    if (en > 0.f) the = sx_tanhf(en * inv_cp);
+    const float ps = cp * (1.f - hp * hp) * thp / (1.f + hp * thp);
+    const float es = (hp * cp) * (2.f - hp) * the / (1.f + (1.f - hp) * the);
+    const float hp_imd = hp + (ps - es) * inv_cp;
+    if (pn > 0.f) pr = pn - (hp_imd - hp) * cp;
+    const float r = hp_imd / beta;
+    const float r2 = r * r;
+    const float pwx1 = 1.f + r2 * r2;
+    const float pwr1 = (pwx1 == 1.f) ? 1.f : sx_pow_m025(pwx1);
+    perc = (hp_imd * cp) * (1.f - pwr1);
+    hp = hp_imd - perc * inv_cp;
+}
+
+SX_DEV void sx_transfer(float prcp, float pr, float ct, float ct_m4, float& ht, float& q) {
+    float pr_imd;
+    if (prcp < 0.f) {   // data gap: closed-form inverse (md_gr_operator.f90:94-96)
+        pr_imd = sx_pow_m025(sx_pow_m4(ht * ct) - ct_m4) - (ht * ct);
+    } else {
+        pr_imd = pr;
+    }
+    const float ht_imd = fmaxf(1.e-6f, ht + pr_imd / ct);
+    ht = sx_pow_m025(sx_pow_m4(ht_imd * ct) + ct_m4) / ct;
+    q = (ht_imd - ht) * ct;
+}
+
+// one vertical cell-step: everything of md_forward_structure.f90:94-151 (gr-a), 280-330 (gr-b),
+// 466-517 (gr-c), 655-690 (gr-d) that precedes the routing module.  Returns qt.
+template <int ST>
+SX_DEV float sx_vertical_step(const SxCellParams& P, float prcp, float pet, float& hi, float& hp, float& hft, float& hst) {
+    float ei = 0.f, pn = 0.f, en = 0.f, pr = 0.f, perc = 0.f, l = 0.f;
+    if (prcp >= 0.f && pet >= 0.f) {
+        if (ST == 1 || ST == 4) {
+            ei = fminf(pet, prcp);
+            pn = fmaxf(0.f, prcp - ei);
+        } else {
+            sx_interception(prcp, pet, P.ci, hi, pn, ei);
+        }
+        en = pet - ei;
+        sx_production(pn, en, P.cp, P.inv_cp, hp, pr, perc);
+        if (ST != 4) l = P.exc * sx_pow_3p5(hft);
+    }
+    float qr, ql, qd, qt;
+    if (ST == 1 || ST == 2) {
+        const float prr = 0.9f * (pr + perc) + l;
+        const float prd = 0.1f * (pr + perc);
+        sx_transfer(prcp, prr, P.cft, P.cft_m4, hft, qr);
+        qd = fmaxf(0.f, prd + l);
+        qt = (qr + qd);
+    } else if (ST == 3) {
+        const float prr = 0.9f * 0.6f * (pr + perc) + l;
+        const float prl = 0.9f * 0.4f * (pr + perc);
+        const float prd = 0.1f * (pr + perc);
+        sx_transfer(prcp, prr, P.cft, P.cft_m4, hft, qr);
+        sx_transfer(prcp, prl, P.cst, P.cst_m4, hst, ql);
+        qd = fmaxf(0.f, prd + l);
+        qt = (qr + ql + qd);
+    } else {
+        const float prr = pr + perc;
+        sx_transfer(prcp, prr, P.cft, P.cft_m4, hft, qr);
+        qt = qr;
+    }
+    return qt;
+}
+
+// ---------------------------------------------------------------- adjoint
+SX_DEV void sx_interception_b(float prcp, float pet, float ci, float& ci_b, float hi, float& hi_b, float& pn_b, float& ei_b) {
+    float ei, pn;
+    bool br_ei, br_pn;
+    if (pet > prcp + hi * ci) { ei = prcp + hi * ci; br_ei = true; } else { ei = pet; br_ei = false; }
+    if (0.f < prcp - ci * (1.f - hi) - ei) { pn = prcp - ci * (1.f - hi) - ei; br_pn = true; } else { pn = 0.f; br_pn = false; }
+    const float temp_b = hi_b / ci;
+    ei_b = ei_b - temp_b;
+    pn_b = pn_b - temp_b;
+    ci_b = ci_b - (prcp - ei - pn) * temp_b / ci;
+    if (br_pn) {
+        ci_b = ci_b - (1.f - hi) * pn_b;
+        hi_b = hi_b + ci * pn_b;
+        ei_b = ei_b - pn_b;
+    }
+    if (br_ei) {
+        hi_b = hi_b + ci * ei_b;
+        ci_b = ci_b + hi * ei_b;
+    }
+}
+
+// hp = pre-step level; pr_b, perc_b in; pn_b, en_b out; hp_b, cp_b updated
+SX_DEV void sx_production_b(float pn, float& pn_b, float en, float& en_b, float cp, float inv_cp, float& cp_b, float hp,
+                            float& hp_b, float pr_b, float perc_b) {
+    const float beta = 1000.f;
+    float thp = 0.f, the = 0.f;
+    if (pn > 0.f) thp = sx_tanhf(pn * inv_cp);
+    if (en > 0.f) the = sx_tanhf(en * inv_cp);
+    const float ps = cp * (1.f - hp * hp) * thp / (1.f + hp * thp);
+    const float es = hp * cp * (2.f - hp) * the / (1.f + (1.f - hp) * the);
+    const float hp_imd = hp + (ps - es) * inv_cp;
+    const float r = hp_imd / beta, r2 = r * r;
+    const float pwx1 = 1.f + r2 * r2;
+    float pwr1 = 1.f, pw125 = 1.f;
+    if (pwx1 != 1.f) sx_pow_m025_m125(pwx1, &pwr1, &pw125);
+    const float perc = hp_imd * cp * (1.f - pwr1);
+    perc_b = perc_b - inv_cp * hp_b;
+    float inv_cp_b = -(perc * hp_b);
+    cp_b = cp_b + hp_imd * (1.f - pwr1) * perc_b;
+    const float pwr1_b = -(hp_imd * cp * perc_b);
+    const float pwx1_b = -(0.25f * pw125 * pwr1_b);
+    const float b2 = beta * beta;
+    float hp_imd_b = hp_b + cp * (1.f - pwr1) * perc_b + 4.f * (hp_imd * hp_imd * hp_imd) * pwx1_b / (b2 * b2);
+    if (pn > 0.f) {
+        pn_b = pr_b;
+        hp_imd_b = hp_imd_b - cp * pr_b;
+        hp_b = cp * pr_b;
+        cp_b = cp_b - (hp_imd - hp) * pr_b;
+    } else {
+        hp_b = 0.f;
+        pn_b = 0.f;
+    }
+    const float es_b = -(inv_cp * hp_imd_b);
+    const float temp4 = the;
+    const float temp3 = (-hp + 1.f) * temp4 + 1.f;
+    float temp1 = the;
+    float temp0 = hp * cp * (-hp + 2.f);
+    const float temp_b3 = es_b / temp3;
+    float temp_b = (2.f - hp) * temp1 * temp_b3;
+    float temp_b0 = -(temp0 * temp1 * temp_b3 / temp3);
+    hp_b = hp_b + hp_imd_b + cp * temp_b - hp * cp * temp1 * temp_b3 - temp4 * temp_b0;
+    const float ps_b = inv_cp * hp_imd_b;
+    const float temp_b4 = (1.0f - the * the) * temp0 * temp_b3;
+    const float temp_b5 = (1.0f - the * the) * (1.f - hp) * temp_b0;
+    en_b = inv_cp * temp_b5 + inv_cp * temp_b4;
+    cp_b = cp_b + hp * temp_b;
+    const float temp = thp;
+    temp0 = hp * temp + 1.f;
+    temp1 = thp;
+    const float temp2 = cp * (-(hp * hp) + 1.f);
+    temp_b = ps_b / temp0;
+    temp_b0 = (1.0f - thp * thp) * temp2 * temp_b;
+    const float temp_b1 = -(temp2 * temp1 * temp_b / temp0);
+    hp_b = hp_b + temp * temp_b1 - 2.f * hp * cp * temp1 * temp_b;
+    const float temp_b2 = (1.0f - thp * thp) * hp * temp_b1;
+    inv_cp_b = inv_cp_b + (ps - es) * hp_imd_b + en * temp_b5 + en * temp_b4 + pn * temp_b2 + pn * temp_b0;
+    cp_b = cp_b + (1.f - hp * hp) * temp1 * temp_b - inv_cp_b / (cp * cp);
+    pn_b = pn_b + inv_cp * temp_b2 + inv_cp * temp_b0;
+}
+
+// ht = pre-step level
+SX_DEV void sx_transfer_b(float prcp, float pr, float& pr_b, float ct, float ct_m4, float ct_m5, float& ct_b, float ht,
+                          float& ht_b, float q_b) {
+    float pr_imd, g_pwx1 = 0.f, g_pwx3 = 0.f;
+    const bool gap = prcp < 0.f;
+    if (gap) {
+        g_pwx1 = ht * ct;
+        g_pwx3 = sx_pow_m4(g_pwx1) - ct_m4;
+        pr_imd = sx_pow_m025(g_pwx3) - ht * ct;
+    } else {
+        pr_imd = pr;
+    }
+    float ht_imd;
+    bool br_max;
+    if (1.e-6f < ht + pr_imd / ct) { ht_imd = ht + pr_imd / ct; br_max = true; } else { ht_imd = 1.e-6f; br_max = false; }
+    const float pwx1 = ht_imd * ct;
+    float pwr1, pwx1_m5;
+    sx_pow_m4_m5(pwx1, &pwr1, &pwx1_m5);
+    const float pwx3 = pwr1 + ct_m4;
+    float pwr3, pwx3_m125;
+    sx_pow_m025_m125(pwx3, &pwr3, &pwx3_m125);
+    const float ht_new = pwr3 / ct;
+    float htb = ht_b - ct * q_b;
+    float pwr3_b = htb / ct;
+    float pwx3_b = -0.25f * pwx3_m125 * pwr3_b;      // pwy3*pwx3**(pwy3-1)*pwr3_b, pwy3 = -1/4 (pwx3 > 0 here)
+    float pwr1_b = pwx3_b, pwr2_b = pwx3_b;
+    float pwx1_b = -4.f * pwx1_m5 * pwr1_b;           // pwy1*pwx1**(pwy1-1)*pwr1_b, pwy1 = -4
+    const float ht_imd_b = ct * q_b + ct * pwx1_b;
+    ct_b = ct_b + (ht_imd - ht_new) * q_b + -4.f * ct_m5 * pwr2_b - pwr3 * htb / (ct * ct) + ht_imd * pwx1_b;
+    float pr_imd_b;
+    if (br_max) {
+        htb = ht_imd_b;
+        pr_imd_b = ht_imd_b / ct;
+        ct_b = ct_b - pr_imd * ht_imd_b / (ct * ct);
+    } else {
+        htb = 0.f;
+        pr_imd_b = 0.f;
+    }
+    if (!gap) {
+        pr_b = pr_imd_b;
+    } else {
+        pwr3_b = pr_imd_b;
+        // Tapenade guards pwx3 <= 0 with a non-integer exponent (forward_db.f90:6391-6395)
+        pwx3_b = (g_pwx3 <= 0.f) ? 0.f : -0.25f * sx_powf(g_pwx3, -1.25f) * pwr3_b;
+        pwr1_b = pwx3_b;
+        pwr2_b = -pwx3_b;
+        pwx1_b = -4.f * sx_powf(g_pwx1, -5.f) * pwr1_b;
+        htb = htb + ct * pwx1_b - ct * pr_imd_b;
+        ct_b = ct_b + -4.f * ct_m5 * pwr2_b - ht * pr_imd_b + ht * pwx1_b;
+        pr_b = 0.f;
+    }
+    ht_b = htb;
+}
+
+struct SxCellGrads {   // running sums, one per cell, accumulated in reverse time order like the reference
+    float ci_b, cp_b, cft_b, cst_b, exc_b;
+    float hi_b, hp_b, hft_b, hst_b;
+};
+
+// reverse of sx_vertical_step given the pre-step states and the incoming qt_b
+// (GR_{A,B,C,D}_FORWARD_B inner body: forward_db.f90:8128-8170 / 8674-8716 / 9233-9286 / 9762-9791)
+template <int ST>
+SX_DEV void sx_vertical_step_b(const SxCellParams& P, float ct_m5_ft, float ct_m5_st, float prcp, float pet, float hi, float hp,
+                               float hft, float hst, float qt_b, SxCellGrads& G) {
+    const bool wet = (prcp >= 0.f && pet >= 0.f);
+    float ei = 0.f, pn = 0.f, en = 0.f, pr = 0.f, perc = 0.f, l = 0.f, prr, prl = 0.f, prd = 0.f;
+    float h35 = 0.f, h25 = 0.f;
+    if (wet) {
+        float hi2 = hi, hp2 = hp;
+        if (ST == 1 || ST == 4) { ei = fminf(pet, prcp); pn = fmaxf(0.f, prcp - ei); }
+        else sx_interception(prcp, pet, P.ci, hi2, pn, ei);
+        en = pet - ei;
+        sx_production(pn, en, P.cp, P.inv_cp, hp2, pr, perc);
+        if (ST != 4) { sx_pow_3p5_2p5(hft, &h35, &h25); l = P.exc * h35; }
+    }
+    if (ST == 1 || ST == 2) { prr = 0.9f * (pr + perc) + l; prd = 0.1f * (pr + perc); }
+    else if (ST == 3) { prr = 0.9f * 0.6f * (pr + perc) + l; prl = 0.9f * 0.4f * (pr + perc); prd = 0.1f * (pr + perc); }
+    else prr = pr + perc;
+
+    const float qr_b = qt_b, ql_b = qt_b, qd_b = qt_b;
+    float prd_b = 0.f, l_b = 0.f, prr_b = 0.f, prl_b = 0.f, pr_b, perc_b;
+    if (ST != 4) {
+        if (0.f < prd + l) { prd_b = qd_b; l_b = qd_b; }
+    }
+    if (ST == 3) sx_transfer_b(prcp, prl, prl_b, P.cst, P.cst_m4, ct_m5_st, G.cst_b, hst, G.hst_b, ql_b);
+    sx_transfer_b(prcp, prr, prr_b, P.cft, P.cft_m4, ct_m5_ft, G.cft_b, hft, G.hft_b, qr_b);
+    if (ST == 1 || ST == 2) {
+        pr_b = 0.1f * prd_b + 0.9f * prr_b;
+        perc_b = 0.1f * prd_b + 0.9f * prr_b;
+        l_b = l_b + prr_b;
+    } else if (ST == 3) {
+        float tb = 0.4f * 0.9f * prl_b;
+        pr_b = 0.1f * prd_b + tb;
+        perc_b = 0.1f * prd_b + tb;
+        tb = 0.6f * 0.9f * prr_b;
+        l_b = l_b + prr_b;
+        pr_b = pr_b + tb;
+        perc_b = perc_b + tb;
+    } else {
+        pr_b = prr_b;
+        perc_b = prr_b;
+    }
+    if (wet) {
+        float pn_b = 0.f, en_b = 0.f;
+        if (ST != 4) {   // GR_EXCHANGE_B
+            G.exc_b = G.exc_b + h35 * l_b;
+            G.hft_b = G.hft_b + 3.5f * h25 * P.exc * l_b;
+        }
+        sx_production_b(pn, pn_b, en, en_b, P.cp, P.inv_cp, G.cp_b, hp, G.hp_b, pr_b, perc_b);
+        if (ST == 2 || ST == 3) {
+            float ei_b = -en_b;
+            sx_interception_b(prcp, pet, P.ci, G.ci_b, hi, G.hi_b, pn_b, ei_b);
+        }
+    }
+}

@@ -1,0 +1,164 @@
+// sx_plan.cpp -- builds the routing schedule (see sx_plan.h).  Host-only C++.
+#include "sx_plan.h"
+
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <numeric>
+
+namespace {
+// D8: code k = 1..8 = N, NE, E, SE, S, SW, W, NW flows to (row + DROW[k-1], col + DCOL[k-1])
+// (reference smash/mesh/mw_meshing.f90:163-164); the solver's upstream test
+// (md_routing_operator.f90:29-31,45) is the mirror image: neighbour i drains into me iff its code == i.
+const int DROW[8] = {-1, -1, 0, 1, 1, 1, 0, -1};
+const int DCOL[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+}  // namespace
+
+int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_cell, int ng, const int* gauge_pos,
+                      int group_size, SxSchedule& s) {
+    const int M = group_size;
+    if (nrow <= 0 || ncol <= 0 || M < 16) { s.error = "bad sizes"; return -1; }
+    const long n2 = (long)nrow * ncol;
+    s.nrow = nrow; s.ncol = ncol; s.group_size = M;
+
+    // ---- active cells in column-major order (temporary index a), parents, children in D8 order ----
+    std::vector<int> a_of_flat(n2, -1), flat_of_a;
+    flat_of_a.reserve(n2);
+    for (long c = 0; c < n2; ++c)
+        if (active_cell[c] == 1) { a_of_flat[c] = (int)flat_of_a.size(); flat_of_a.push_back((int)c); }
+    const int n = (int)flat_of_a.size();
+    s.n = n;
+    if (n == 0) { s.error = "no active cell"; return -1; }
+    std::vector<int> parent(n, -1), code(n, 0);
+    for (int a = 0; a < n; ++a) {
+        const int c = flat_of_a[a], row = c % nrow, col = c / nrow, fd = flwdir[c];
+        code[a] = fd;
+        if (fd < 1 || fd > 8) continue;
+        const int r2 = row + DROW[fd - 1], c2 = col + DCOL[fd - 1];
+        if (r2 < 0 || r2 >= nrow || c2 < 0 || c2 >= ncol) continue;
+        parent[a] = a_of_flat[r2 + (long)c2 * nrow];   // -1 when the receiver is inactive
+    }
+    std::vector<int> nchild(n, 0), cbeg(n + 1, 0);
+    for (int a = 0; a < n; ++a) if (parent[a] >= 0) nchild[parent[a]]++;
+    for (int a = 0; a < n; ++a) cbeg[a + 1] = cbeg[a] + nchild[a];
+    std::vector<int> child(cbeg[n]), fill(n, 0);
+    for (int a = 0; a < n; ++a) if (parent[a] >= 0) { const int p = parent[a]; child[cbeg[p] + fill[p]++] = a; }
+    for (int a = 0; a < n; ++a)   // order 1..8 as md_routing_operator.f90:37-53 sums them
+        std::sort(child.begin() + cbeg[a], child.begin() + cbeg[a + 1], [&](int x, int y) { return code[x] < code[y]; });
+
+    // ---- topological order (leaves first); a cycle (pit pair) cannot be scheduled ----
+    std::vector<int> topo; topo.reserve(n);
+    {
+        std::vector<int> indeg(nchild);
+        for (int a = 0; a < n; ++a) if (indeg[a] == 0) topo.push_back(a);
+        for (size_t i = 0; i < topo.size(); ++i) {
+            const int p = parent[topo[i]];
+            if (p >= 0 && --indeg[p] == 0) topo.push_back(p);
+        }
+        if ((int)topo.size() != n) { s.error = "flow directions contain a cycle over active cells"; return -5; }
+    }
+
+    // ---- rounds: repeatedly peel off every maximal subtree whose weight (cells + inlets) fits a group ----
+    std::vector<int> round_of(n, -1), w(n, 0);
+    struct Root { int a; int weight; };
+    std::vector<std::vector<std::vector<int>>> round_groups;   // round -> group -> list of roots
+    int remaining = n, round = 0;
+    std::vector<int> todo(topo);
+    while (remaining > 0) {
+        for (int a : todo) {
+            long ww = 1;
+            for (int j = cbeg[a]; j < cbeg[a + 1]; ++j) ww += (round_of[child[j]] >= 0) ? 1 : w[child[j]];
+            w[a] = (int)std::min<long>(ww, (long)M + 1);
+        }
+        std::vector<Root> roots;
+        for (int a : todo)
+            if (w[a] <= M && (parent[a] < 0 || w[parent[a]] > M)) roots.push_back({a, w[a]});
+        if (roots.empty()) { s.error = "schedule made no progress (group_size too small)"; return -1; }
+        std::vector<int> next; next.reserve(todo.size());
+        for (int a : todo) { if (w[a] <= M) { round_of[a] = round; --remaining; } else next.push_back(a); }
+        todo.swap(next);
+        // best-fit-decreasing packing of the subtrees into groups of capacity M
+        std::stable_sort(roots.begin(), roots.end(), [](const Root& x, const Root& y) { return x.weight > y.weight; });
+        std::vector<std::vector<int>> groups;
+        std::multimap<int, int> room;   // free capacity -> group
+        for (const Root& r : roots) {
+            auto it = room.lower_bound(r.weight);
+            int g;
+            if (it == room.end()) { g = (int)groups.size(); groups.emplace_back(); room.emplace(M - r.weight, g); }
+            else { g = it->second; const int left = it->first - r.weight; room.erase(it); room.emplace(left, g); }
+            groups[g].push_back(r.a);
+        }
+        round_groups.push_back(std::move(groups));
+        ++round;
+    }
+    s.nrounds = round;
+
+    // ---- exchange series: one per subtree root that has a receiver in a later round ----
+    // (roots without parent are catchment outlets: they publish nothing)
+    std::vector<int> xslot_of(n, -1);
+    int nx = 0;
+    for (int r = 0; r < s.nrounds; ++r)
+        for (auto& g : round_groups[r])
+            for (int a : g) if (parent[a] >= 0) xslot_of[a] = nx++;
+    s.nxslots = nx;
+
+    // ---- group-local breadth-first order, stages, device cell numbering ----
+    s.round_group_begin.assign(1, 0);
+    s.g_slot_begin.assign(1, 0);
+    std::vector<int> k_of_a(n, -1);
+    int knext = 0;
+    s.max_stage = 0;
+    std::vector<int> q_node, q_par, q_depth;   // BFS queue: node (>=0 cell a, <0 inlet of cell -1-a), local parent, depth
+    for (int r = 0; r < s.nrounds; ++r) {
+        for (auto& g : round_groups[r]) {
+            q_node.clear(); q_par.clear(); q_depth.clear();
+            for (int a : g) { q_node.push_back(a); q_par.push_back(-1); q_depth.push_back(0); }
+            std::vector<int> cstart, ccount;
+            for (size_t i = 0; i < q_node.size(); ++i) {
+                const int node = q_node[i];
+                cstart.push_back((int)q_node.size()); ccount.push_back(0);
+                if (node < 0) continue;   // inlet pseudo-cell: no children here
+                for (int j = cbeg[node]; j < cbeg[node + 1]; ++j) {
+                    const int c = child[j];
+                    q_node.push_back(round_of[c] == r ? c : -1 - c);
+                    q_par.push_back((int)i); q_depth.push_back(q_depth[i] + 1);
+                    ccount[i]++;
+                }
+            }
+            const int m = (int)q_node.size();
+            if (m > M) { s.error = "internal: group overflow"; return -1; }
+            int dmax = 0;
+            for (int i = 0; i < m; ++i) dmax = std::max(dmax, q_depth[i]);
+            s.g_dmax.push_back(dmax);
+            s.max_stage = std::max(s.max_stage, dmax);
+            for (int i = 0; i < m; ++i) {
+                const int node = q_node[i];
+                if (node >= 0) { k_of_a[node] = knext++; s.s_cell.push_back(k_of_a[node]); }
+                else s.s_cell.push_back(-1 - xslot_of[-1 - node]);
+                s.s_stage.push_back(dmax - q_depth[i]);
+                s.s_cstart.push_back(cstart[i]);
+                s.s_ccount.push_back(ccount[i]);
+                s.s_parent.push_back(q_par[i]);
+                s.s_xout.push_back((node >= 0 && q_par[i] < 0) ? xslot_of[node] : -1);
+            }
+            s.g_slot_begin.push_back((int)s.s_cell.size());
+        }
+        s.round_group_begin.push_back((int)s.g_slot_begin.size() - 1);
+    }
+    s.ngroups = (int)s.g_slot_begin.size() - 1;
+    s.nslots = (int)s.s_cell.size();
+    if (knext != n) { s.error = "internal: cell numbering"; return -1; }
+
+    s.cell_flat.resize(n);
+    s.k_of_flat.assign(n2, -1);
+    for (int a = 0; a < n; ++a) { s.cell_flat[k_of_a[a]] = flat_of_a[a]; s.k_of_flat[flat_of_a[a]] = k_of_a[a]; }
+    s.gauge_k.resize(ng);
+    for (int g = 0; g < ng; ++g) {
+        const int row = gauge_pos[g], col = gauge_pos[g + ng];
+        if (row < 0 || row >= nrow || col < 0 || col >= ncol || s.k_of_flat[row + (long)col * nrow] < 0) {
+            s.error = "gauge outside the active domain"; return -1;
+        }
+        s.gauge_k[g] = s.k_of_flat[row + (long)col * nrow];
+    }
+    return 0;
+}

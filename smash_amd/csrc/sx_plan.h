@@ -1,0 +1,40 @@
+// sx_plan.h -- host-side routing schedule: turns the D8 mesh (MeshDT flwdir / flwacc / active_cell,
+// reference mwd_mesh.f90:45-72) into the tree partition the routing kernels run on.
+//
+// The reference visits cells in increasing flow-accumulation order inside every time step
+// (md_forward_structure.f90:57-59, mesh%path from smash/mesh/meshing.py:216-224) because a cell reads
+// the *current-step* discharge of its D8-upstream neighbours (md_routing_operator.f90:35-56).  On the
+// GPU that dependency is honoured by cutting the river tree into subtrees of at most `group_size`
+// members, each routed by ONE workgroup as a time-skewed wavefront through LDS, and by ordering the
+// subtrees in "rounds": round r subtrees only receive inflow from subtrees of rounds < r, through
+// per-inlet discharge series in HBM.  See DESIGN.md "Routing schedule".
+#pragma once
+
+#include <string>
+#include <vector>
+
+struct SxSchedule {
+    int nrow = 0, ncol = 0;
+    int n = 0;                       // active cells
+    int group_size = 0;              // M: slots per workgroup
+    std::vector<int> cell_flat;      // k -> row + col*nrow   (device cell order)
+    std::vector<int> k_of_flat;      // flat -> k, -1 inactive
+    // routing groups; groups of one round are contiguous
+    int nrounds = 0, ngroups = 0, nslots = 0, nxslots = 0, max_stage = 0;
+    std::vector<int> round_group_begin;  // nrounds + 1
+    std::vector<int> g_slot_begin;       // ngroups + 1
+    std::vector<int> g_dmax;             // ngroups: largest stage in the group
+    // per slot (a slot = one thread of the routing workgroup: a real cell or an inlet pseudo-cell)
+    std::vector<int> s_cell;     // k (>= 0) for a cell, -1 - x for the inlet fed by exchange series x
+    std::vector<int> s_stage;    // children sit exactly one stage below their parent
+    std::vector<int> s_cstart;   // group-local index of the first child; children are contiguous, D8 order 1..8
+    std::vector<int> s_ccount;
+    std::vector<int> s_parent;   // group-local index of the parent, -1 for a subtree root
+    std::vector<int> s_xout;     // subtree roots: exchange series id they publish, else -1
+    std::vector<int> gauge_k;    // ng: device cell of every gauge
+    std::string error;
+};
+
+// Returns 0 on success, negative on failure (s.error set).  All arrays column-major (row fastest).
+int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_cell, int ng, const int* gauge_pos,
+                      int group_size, SxSchedule& s);

@@ -1,0 +1,203 @@
+"""Host-side mirror of the reference's wrapped boundary for the hot path:
+
+    forward    smash/solver/forward/mw_forward.f90:18-39   -> base_forward   (forward.f90:1-80)
+    forward_b  smash/solver/forward/mw_forward.f90:41-68   -> base_forward_b (forward_db.f90:10648-10936)
+
+Same names, argument order and in/out behaviour as the f90wrap functions the reference's Python calls
+(smash/core/model.py:490, smash/core/net.py:1044): parameters / states are modified in place
+(denormalised on return when setup.optimize.denormalize_forward), results land in ``output`` and in the
+``*_b`` objects, and -- like the reference -- nothing is raised for a cost that is NaN.  Differences a
+caller can see: unsupported options raise SmashxError instead of being silently ignored, and only the
+fields the structure uses are touched.
+
+All arithmetic happens in libsmashx (HIP, gfx950) behind the C ABI of include/smashx.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .types import JOBS_FUN, JREG_FUN, STRUCTURES
+from .synth import PARAM_NAMES, STATE_NAMES
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f32(a):
+    return np.asfortranarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.asfortranarray(a, dtype=np.int32)
+
+
+class Solver:
+    """A libsmashx plan: routing schedule + HBM-resident forcing for one (setup, mesh, input_data)."""
+
+    def __init__(self, setup, mesh, *, chunk_steps: int = 0, group_size: int = 0, device: int = -1):
+        L = _lib.lib()
+        self.nrow, self.ncol, self.nt, self.ng = mesh.nrow, mesh.ncol, setup.ntime_step, mesh.ng
+        self.structure = setup.structure
+        if setup.structure not in STRUCTURES:
+            raise _lib.SmashxError(_lib.E_UNSUPPORTED, f"structure {setup.structure!r} is not on the hot path yet")
+        cfg = _lib.Config(STRUCTURES[setup.structure], mesh.nrow, mesh.ncol, setup.ntime_step, mesh.ng, setup.dt,
+                          mesh.dx, chunk_steps, group_size, device)
+        self._keep = [_i32(mesh.flwdir), _i32(mesh.flwacc), _i32(mesh.active_cell), _i32(mesh.path),
+                      _i32(np.asarray(mesh.gauge_pos).reshape(-1, 2)), np.ascontiguousarray(mesh.area, np.float32)]
+        m = _lib.Mesh(*[_ptr(a) for a in self._keep])
+        self._h = C.c_void_p()
+        _lib.check(L.smashx_plan_create(C.byref(cfg), C.byref(m), C.byref(self._h)))
+        self.ncells = L.smashx_plan_ncells(self._h)
+        self._sig = self.signature(setup, mesh)
+
+    @staticmethod
+    def signature(setup, mesh):
+        return (setup.structure, setup.ntime_step, float(setup.dt), mesh.nrow, mesh.ncol, mesh.ng, float(mesh.dx))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().smashx_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- residency ---------------------------------------------------------------------------
+    def cell_order(self):
+        rows = np.zeros(self.ncells, np.int32)
+        cols = np.zeros(self.ncells, np.int32)
+        _lib.check(_lib.lib().smashx_plan_cell_order(self._h, _ptr(rows), _ptr(cols)))
+        return rows, cols
+
+    def set_forcing(self, prcp, pet, sparse=False):
+        p, e = _f32(prcp), _f32(pet)
+        _lib.check(_lib.lib().smashx_set_forcing(self._h, _ptr(p), _ptr(e), int(bool(sparse))))
+
+    def set_forcing_device_block(self, t0, t1, d_prcp_ptr, d_pet_ptr):
+        _lib.check(_lib.lib().smashx_set_forcing_device_block(self._h, int(t0), int(t1), C.c_void_p(d_prcp_ptr),
+                                                              C.c_void_p(d_pet_ptr)))
+
+    def set_qobs(self, qobs):
+        q = _f32(qobs)
+        _lib.check(_lib.lib().smashx_set_qobs(self._h, _ptr(q)))
+
+    def set_options(self, opt):
+        o = _lib.Options()
+        o.denormalize_forward = int(bool(opt.denormalize_forward))
+        o.optimize_start_step = int(opt.optimize_start_step)
+        o.njf = len(opt.jobs_fun)
+        for i, j in enumerate(opt.jobs_fun):
+            if j not in JOBS_FUN:
+                raise _lib.SmashxError(_lib.E_UNSUPPORTED, f"jobs_fun {j!r} is outside the hot path")
+            o.jobs_fun[i] = JOBS_FUN[j]
+            o.wjobs_fun[i] = float(opt.wjobs_fun[i])
+        o.njr = len(opt.jreg_fun)
+        for i, j in enumerate(opt.jreg_fun):
+            o.jreg_fun[i] = JREG_FUN.get(j, 0)
+            o.wjreg_fun[i] = float(opt.wjreg_fun[i])
+        o.wjreg = float(opt.wjreg)
+        for i in range(16):
+            o.optim_parameters[i] = int(opt.optim_parameters[i])
+            o.lb_parameters[i] = float(opt.lb_parameters[i])
+            o.ub_parameters[i] = float(opt.ub_parameters[i])
+        for i in range(8):
+            o.optim_states[i] = int(opt.optim_states[i])
+            o.lb_states[i] = float(opt.lb_states[i])
+            o.ub_states[i] = float(opt.ub_states[i])
+        wg = np.ascontiguousarray(opt.wgauge, np.float32) if self.ng else np.zeros(1, np.float32)
+        o.wgauge = _ptr(wg)
+        _lib.check(_lib.lib().smashx_set_options(self._h, C.byref(o)))
+
+    # -- calls ---------------------------------------------------------------------------------
+    @staticmethod
+    def _pack(obj, names, struct_cls):
+        s = struct_cls()
+        keep = []
+        for i, k in enumerate(names):
+            a = getattr(obj, k, None) if obj is not None else None
+            if a is None:
+                s.f[i] = None
+                continue
+            if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.f_contiguous):
+                a = np.asfortranarray(a, dtype=np.float32)
+                setattr(obj, k, a)
+            keep.append(a)
+            s.f[i] = a.ctypes.data
+        return s, keep
+
+    def upload(self, parameters, states, parameters_bgd=None, states_bgd=None):
+        P, k1 = self._pack(parameters, PARAM_NAMES, _lib.Parameters)
+        S, k2 = self._pack(states, STATE_NAMES, _lib.States)
+        _lib.check(_lib.lib().smashx_upload(self._h, C.byref(P), None, C.byref(S), None))
+
+    def sweep(self, adjoint=False, cost_b=1.0):
+        _lib.check(_lib.lib().smashx_sweep(self._h, int(bool(adjoint)), C.c_float(cost_b)))
+
+    def timing(self):
+        t = _lib.Timing()
+        _lib.check(_lib.lib().smashx_get_timing(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _lib.Timing._fields_}
+
+    def download(self, adjoint, parameters, states, output, parameters_b=None, states_b=None):
+        P, k1 = self._pack(parameters, PARAM_NAMES, _lib.Parameters)
+        S, k2 = self._pack(states, STATE_NAMES, _lib.States)
+        qsim = np.zeros((max(self.ng, 1), self.nt), np.float32, order="F")[: self.ng] if self.ng else None
+        qs = np.zeros((self.ng, self.nt), np.float32, order="F") if self.ng else None
+        costs = _lib.Costs()
+        F = PB = SB = None
+        kf = kp = ks = None
+        if not adjoint and output is not None:
+            F, kf = self._pack(output.fstates, STATE_NAMES, _lib.States)
+        if adjoint:
+            PB, kp = self._pack(parameters_b, PARAM_NAMES, _lib.Parameters)
+            SB, ks = self._pack(states_b, STATE_NAMES, _lib.States)
+        _lib.check(_lib.lib().smashx_download(self._h, int(bool(adjoint)), C.byref(P), C.byref(S), _ptr(qs), C.byref(costs),
+                                              C.byref(F) if F is not None else None,
+                                              C.byref(PB) if PB is not None else None,
+                                              C.byref(SB) if SB is not None else None))
+        if output is not None:
+            if qs is not None:
+                output.qsim = qs
+            output.cost, output.cost_jobs, output.cost_jreg = float(costs.cost), float(costs.cost_jobs), float(costs.cost_jreg)
+        return float(costs.cost)
+
+
+def _solver_for(setup, mesh, input_data, **kw):
+    s = getattr(input_data, "_smashx_solver", None)
+    if s is None or s._sig != Solver.signature(setup, mesh):
+        s = Solver(setup, mesh, **kw)
+        if setup.sparse_storage:
+            s.set_forcing(input_data.sparse_prcp, input_data.sparse_pet, sparse=True)
+        else:
+            s.set_forcing(input_data.prcp, input_data.pet, sparse=False)
+        input_data._smashx_solver = s
+    if mesh.ng:
+        s.set_qobs(input_data.qobs)
+    s.set_options(setup.optimize)
+    return s
+
+
+def forward(setup, mesh, input_data, parameters, parameters_bgd, states, states_bgd, output, cost=None):
+    """Drop-in for mw_forward::forward (mw_forward.f90:18-39).  Returns output.cost."""
+    s = _solver_for(setup, mesh, input_data)
+    s.upload(parameters, states, parameters_bgd, states_bgd)
+    s.sweep(False)
+    return s.download(False, parameters, states, output)
+
+
+def forward_b(setup, mesh, input_data, parameters, parameters_b, parameters_bgd, parameters_bgd_b, states, states_b,
+              states_bgd, states_bgd_b, output, output_b, cost=None, cost_b=1.0):
+    """Drop-in for mw_forward::forward_b (mw_forward.f90:41-68): parameters_b / states_b are overwritten
+    with the gradient of the cost (times cost_b); *_bgd_b and output_b are scratch in the reference and
+    are left untouched here."""
+    s = _solver_for(setup, mesh, input_data)
+    s.upload(parameters, states, parameters_bgd, states_bgd)
+    s.sweep(True, float(cost_b))
+    return s.download(True, parameters, states, output, parameters_b, states_b)

@@ -1,0 +1,158 @@
+"""GPU: the HIP path, called through the C ABI (smash_amd.forward / forward_b -> libsmashx.so), against
+(1) the golden vectors produced by the unmodified reference Fortran and (2) the plain-C oracle.
+
+Tolerance (BASELINE.json north_star: "within 1e-6 relative"): rel-L2 <= 1e-6
+per gauge discharge series, per gradient field and per final-state field; cost within 2e-6 relative.
+Bit-exactness is not demanded: the reference's own -O2 vs -O3 builds differ by 4e-7 rel-L2.
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-6
+
+
+def _types(g, **solver_kw):
+    import smash_amd
+    setup = smash_amd.SetupDT(0, g.mesh.ng, structure=g.structure, dt=g.dt, ntime_step=g.nt)
+    o = setup.optimize
+    o.jobs_fun = list(g.opts.get("jobs_fun", ("nse",)))
+    o.wjobs_fun = list(g.opts.get("wjobs_fun", (1.0,)))
+    o.optimize_start_step = int(g.opts.get("optimize_start_step", 1))
+    o.denormalize_forward = bool(g.opts.get("denormalize_forward", False))
+    if "wgauge" in g.opts:
+        o.wgauge = np.asarray(g.opts["wgauge"], np.float32)
+    mesh = smash_amd.MeshDT.from_synth(setup, g.mesh)
+    inp = smash_amd.Input_DataDT(setup, mesh)
+    inp.prcp, inp.pet, inp.qobs = g.prcp, g.pet, g.qobs
+    par = smash_amd.ParametersDT.from_dict(mesh, g.params)
+    sta = smash_amd.StatesDT.from_dict(mesh, g.states)
+    out = smash_amd.OutputDT(setup, mesh)
+    if solver_kw:
+        from smash_amd.solver import Solver
+        s = Solver(setup, mesh, **solver_kw)
+        s.set_forcing(inp.prcp, inp.pet)
+        inp._smashx_solver = s
+    return setup, mesh, inp, par, sta, out
+
+
+def _run_forward(g, **kw):
+    import smash_amd
+    setup, mesh, inp, par, sta, out = _types(g, **kw)
+    smash_amd.forward(setup, mesh, inp, par, par.copy(), sta, sta.copy(), out, np.float32(0))
+    return par, sta, out
+
+
+def _run_adjoint(g, **kw):
+    import smash_amd
+    setup, mesh, inp, par, sta, out = _types(g, **kw)
+    par_b, sta_b = par.copy(), sta.copy()
+    smash_amd.forward_b(setup, mesh, inp, par, par_b, par.copy(), par.copy(), sta, sta_b, sta.copy(), sta.copy(), out,
+                        out.copy(), np.float32(0), np.float32(1))
+    return par, sta, out, par_b, sta_b
+
+
+NOJREG = [n for n in gu.names() if "jreg" not in n and "prior" not in n]
+
+
+@pytest.mark.parametrize("name", NOJREG)
+def test_forward_vs_reference_golden(name):
+    g = gu.load(name)
+    par, sta, out = _run_forward(g)
+    for i in range(g.mesh.ng):
+        assert gu.rel_l2(out.qsim[i], g.fwd["qsim"][i]) <= TOL, (i, gu.rel_l2(out.qsim[i], g.fwd["qsim"][i]))
+    assert abs(out.cost - g.fwd["cost"]) <= 2e-6 * abs(g.fwd["cost"]), (out.cost, g.fwd["cost"])
+    for k in gu.STRUCT_STATES[g.structure]:
+        assert gu.rel_l2(getattr(out.fstates, k), g.fwd["fstates"][k]) <= TOL, k
+        assert np.array_equal(getattr(sta, k), g.fwd["states"][k]), k       # states are restored (forward.f90:72)
+
+
+@pytest.mark.parametrize("name", NOJREG)
+def test_adjoint_vs_reference_golden(name):
+    g = gu.load(name)
+    par, sta, out, par_b, sta_b = _run_adjoint(g)
+    for i in range(g.mesh.ng):
+        assert gu.rel_l2(out.qsim[i], g.adj["qsim"][i]) <= TOL
+    assert abs(out.cost - g.adj["cost"]) <= 2e-6 * abs(g.adj["cost"])
+    report = {}
+    for k in gu.STRUCT_PARAMS[g.structure]:
+        report[k] = gu.rel_l2(getattr(par_b, k), g.adj["parameters_b"][k])
+    for k in gu.STRUCT_STATES[g.structure]:
+        report[k] = gu.rel_l2(getattr(sta_b, k), g.adj["states_b"][k])
+    bad = {k: v for k, v in report.items() if not v <= TOL}
+    assert not bad, report
+    # fields the structure does not use come back zero, like parameters_b = 0 (forward_db.f90:10869)
+    assert not np.any(par_b.beta) and not np.any(sta_b.husl1)
+
+
+@pytest.mark.parametrize("name", ["gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask"])
+@pytest.mark.parametrize("chunk,group", [(16, 64), (32, 128), (48, 512)])
+def test_chunking_and_grouping_do_not_change_results(name, chunk, group):
+    """Time-chunk checkpointing and the routing partition only reorder independent work: results must be
+    bit-identical to the single-chunk default."""
+    g = gu.load(name)
+    ref = _run_adjoint(g)
+    alt = _run_adjoint(g, chunk_steps=chunk, group_size=group)
+    assert np.array_equal(ref[2].qsim, alt[2].qsim)
+    assert ref[2].cost == alt[2].cost
+    for k in gu.STRUCT_PARAMS[g.structure]:
+        assert np.array_equal(getattr(ref[3], k), getattr(alt[3], k)), k
+    for k in gu.STRUCT_STATES[g.structure]:
+        assert np.array_equal(getattr(ref[4], k), getattr(alt[4], k)), k
+
+
+def test_sparse_forcing_layout_matches_dense():
+    """Input_DataDT%sparse_prcp/pet (nac,nt) numbered along path (mw_sparse_storage.f90:12-49)."""
+    import smash_amd
+    g = gu.load("gr_c_16x16x96_kge_se_log_mask")
+    _, _, dense = _run_forward(g)
+    setup, mesh, inp, par, sta, out = _types(g)
+    setup.sparse_storage = True
+    act = g.mesh.active_cell
+    idx = [(r, c) for r, c in zip(g.mesh.path[0], g.mesh.path[1]) if r >= 0 and c >= 0 and act[r, c] == 1]
+    rr = np.array([i[0] for i in idx]); cc = np.array([i[1] for i in idx])
+    inp2 = smash_amd.Input_DataDT(setup, mesh)
+    inp2.sparse_prcp = np.asfortranarray(g.prcp[rr, cc, :]); inp2.sparse_pet = np.asfortranarray(g.pet[rr, cc, :])
+    inp2.qobs = g.qobs
+    smash_amd.forward(setup, mesh, inp2, par, par.copy(), sta, sta.copy(), out, np.float32(0))
+    assert np.array_equal(out.qsim, dense.qsim)
+
+
+def test_denormalize_forward_vs_oracle():
+    """denormalize_forward path (forward.f90:33-38, DENORMALIZE_*_B forward_db.f90:967-1057,1959-2014),
+    checked against the oracle on the normalised golden case with the regulariser switched off."""
+    from oracle import pyoracle
+    g = gu.load("gr_b_24x24x120_norm_jreg")
+    opts = {k: v for k, v in g.opts.items() if k not in ("jreg_fun", "wjreg_fun", "wjreg")}
+    g.opts = opts
+    ref_f = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, **opts)
+    ref_b = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, adjoint=True, **opts)
+    par, sta, out = _run_forward(g)
+    assert gu.rel_l2(out.qsim, ref_f["qsim"]) <= TOL and abs(out.cost - ref_f["cost"]) <= 2e-6 * abs(ref_f["cost"])
+    for k in gu.STRUCT_PARAMS[g.structure]:
+        assert np.array_equal(getattr(par, k), ref_f["parameters"][k]), k     # denormalised + round trip, exact affine ops
+    for k in gu.STRUCT_STATES[g.structure]:
+        assert np.array_equal(getattr(sta, k), ref_f["states"][k]), k
+    par, sta, out, par_b, sta_b = _run_adjoint(g)
+    for k in gu.STRUCT_PARAMS[g.structure]:
+        assert gu.rel_l2(getattr(par_b, k), ref_b["parameters_b"][k]) <= TOL, k
+        assert np.array_equal(getattr(par, k), ref_b["parameters"][k]), k
+    for k in gu.STRUCT_STATES[g.structure]:
+        assert gu.rel_l2(getattr(sta_b, k), ref_b["states_b"][k]) <= TOL, k
+
+
+def test_unsupported_options_fail_loudly():
+    import smash_amd
+    g = gu.load("gr_a_24x24x120_norm_prior")
+    setup, mesh, inp, par, sta, out = _types(g)
+    setup.optimize.jreg_fun, setup.optimize.wjreg_fun, setup.optimize.wjreg = ["prior"], [1.0], 1e-2
+    with pytest.raises(smash_amd.SmashxError):
+        smash_amd.forward(setup, mesh, inp, par, par.copy(), sta, sta.copy(), out, np.float32(0))
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()
