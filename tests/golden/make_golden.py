@@ -41,12 +41,19 @@ CASES = [
                    wgauge=[0.5, 0.0, 0.5])),
     dict(name="gr_a_24x24x120_norm_prior", structure="gr-a", n=24, nt=120, ng=3, mask=False, gaps=1000, normalized=True,
          opts=dict(jreg_fun=("prior",), wjreg_fun=(1.0,), wjreg=1e-2, denormalize_forward=True)),
+    dict(name="gr_a_12x12x48_nse_cold", structure="gr-a", n=12, nt=48, ng=2, mask=False, gaps=0, warm=False, opts={}),
     # larger cases: forcing is regenerated from smash_amd.synth (sha256 pinned in the fixture)
     dict(name="gr_b_64x64x720_nse", structure="gr-b", n=64, nt=720, ng=4, mask=False, gaps=1000, big=True, opts={}),
-    dict(name="gr_a_64x64x720_nse", structure="gr-a", n=64, nt=720, ng=4, mask=False, gaps=1000, big=True, opts={}),
+    dict(name="gr_a_64x64x720_nse_cold", structure="gr-a", n=64, nt=720, ng=4, mask=False, gaps=1000, big=True, warm=False, opts={}),
     dict(name="gr_c_48x48x480_nse", structure="gr-c", n=48, nt=480, ng=4, mask=True, gaps=1000, big=True, opts={}),
     dict(name="gr_d_48x48x480_nse", structure="gr-d", n=48, nt=480, ng=4, mask=False, gaps=1000, big=True, opts={}),
 ]
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    n = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / n) if n > 0 else float(np.linalg.norm(a - b))
 
 
 def sha(a):
@@ -58,7 +65,7 @@ def build_case(c):
     mesh = synth.make_mesh(n, n, ng=c["ng"], mask_corner=c["mask"])
     prcp, pet = synth.dense_forcing(mesh, nt, gap_per_million=c["gaps"])
     P = synth.make_parameters(n, n)
-    S = synth.make_states(n, n)
+    S = synth.make_states(n, n, warm=c.get("warm", True))
     Pq = synth.make_parameters(n, n, perturb=0.1)
     qobs = refbind.run(c["structure"], mesh, DT, prcp, pet, np.zeros((c["ng"], nt), np.float32), Pq, S)["qsim"].copy()
     if c["gaps"]:
@@ -84,6 +91,10 @@ def main():
         mesh, prcp, pet, qobs, P, S, opts = build_case(c)
         f = refbind.run(c["structure"], mesh, DT, prcp, pet, qobs, P, S, **opts)
         b = refbind.run(c["structure"], mesh, DT, prcp, pet, qobs, P, S, adjoint=True, **opts)
+        # the reference's own flag-to-flag noise: same sources built the way its makefile does
+        # (-O3 + FMA contraction, makefile:6) against the parity build (-O2 -ffp-contract=off)
+        f3 = refbind.run(c["structure"], mesh, DT, prcp, pet, qobs, P, S, fast=True, **opts)
+        b3 = refbind.run(c["structure"], mesh, DT, prcp, pet, qobs, P, S, adjoint=True, fast=True, **opts)
         d = dict(structure=c["structure"], dt=DT, dx=mesh.dx, nrow=mesh.nrow, ncol=mesh.ncol, nt=c["nt"],
                  gaps=c["gaps"], mask=int(c["mask"]), big=int(bool(c.get("big"))),
                  flwdir=mesh.flwdir, flwacc=mesh.flwacc, path=mesh.path, active_cell=mesh.active_cell,
@@ -106,6 +117,13 @@ def main():
         # expected outputs
         d.update(fwd_qsim=f["qsim"], fwd_cost=np.float32(f["cost"]), fwd_cost_jobs=np.float32(f["cost_jobs"]),
                  fwd_cost_jreg=np.float32(f["cost_jreg"]), adj_qsim=b["qsim"], adj_cost=np.float32(b["cost"]))
+        d["noise_qsim"] = np.array([rel_l2(f3["qsim"][i], f["qsim"][i]) for i in range(c["ng"])])
+        d["noise_cost"] = np.float64(abs(f3["cost"] - f["cost"]) / max(abs(f["cost"]), 1e-300))
+        for k in synth.STATE_NAMES:
+            d["noise_fstates_" + k] = np.float64(rel_l2(f3["fstates"][k], f["fstates"][k]))
+            d["noise_states_b_" + k] = np.float64(rel_l2(b3["states_b"][k], b["states_b"][k]))
+        for k in synth.PARAM_NAMES:
+            d["noise_parameters_b_" + k] = np.float64(rel_l2(b3["parameters_b"][k], b["parameters_b"][k]))
         for k in synth.STATE_NAMES:
             d["fwd_fstates_" + k] = f["fstates"][k]
             d["adj_states_b_" + k] = b["states_b"][k]
