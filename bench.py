@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- cell-timesteps/s of one forward + adjoint sweep (the work of one reference forward_b call:
+cost + gradient w.r.t. all distributed parameters and initial states) on a synthetic catchment with
+hourly x 1 yr forcing resident in HBM (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward+adjoint sweep of the hot path over the whole (grid x nt) batch.  At N = 1 the
+workload is BASELINE.json configs[2]: 1024 x 1024 grid, 8760 steps, gr-b (4096^2, the grid the metric is
+quoted on, needs 1.18 TB of forcing and only fits 8 GPUs).  Prints ONE JSON line on rank 0.
+
+PyTorch is plumbing here (device memory for building the forcing in HBM, streams, torch.distributed);
+all solver arithmetic is in libsmashx (HIP) behind the C ABI.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=1024, help="cells per side of the per-GPU tile")
+    ap.add_argument("--nt", type=int, default=8760)
+    ap.add_argument("--structure", default="gr-b")
+    ap.add_argument("--chunk", type=int, default=0, help="time-chunk length (0 = from free HBM)")
+    ap.add_argument("--group", type=int, default=0, help="routing group size (0 = default)")
+    ap.add_argument("--ng", type=int, default=8)
+    ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-grid", type=int, default=192)
+    ap.add_argument("--cpu-nt", type=int, default=120)
+    return ap.parse_args()
+
+
+def cpu_baseline(structure, n, nt):
+    """The reference path timed on the host cores of this box, on a bounded sample of the same synthetic
+    workload: one forward_b (cost + gradient) on an n x n catchment over nt steps, single thread -- the only
+    mode the reference has for this path (mw_forward.f90:41-68; no OpenMP in forward_b)."""
+    from oracle import pyoracle, refbind
+    from smash_amd import synth
+    m = synth.make_mesh(n, n, ng=4)
+    prcp, pet = synth.dense_forcing(m, nt)
+    P, S = synth.make_parameters(n, n), synth.make_states(n, n, warm=True)
+    Pq = synth.make_parameters(n, n, perturb=0.1)
+    kind = "reference" if refbind.available(fast=True) else "port"
+    if kind == "reference":
+        qobs = refbind.run(structure, m, 3600.0, prcp, pet, np.zeros((4, nt), np.float32), Pq, S, fast=True)["qsim"]
+        r = refbind.run(structure, m, 3600.0, prcp, pet, qobs, P, S, adjoint=True, fast=True)
+        secs = r["elapsed"]
+        what = "reference Fortran (flang -O3, libsmash_ref_fast.so) forward_b"
+    else:
+        qobs = pyoracle.run(structure, m, 3600.0, prcp, pet, np.zeros((4, nt), np.float32), Pq, S)["qsim"]
+        t0 = time.perf_counter()
+        pyoracle.run(structure, m, 3600.0, prcp, pet, qobs, P, S, adjoint=True)
+        secs = time.perf_counter() - t0
+        what = "plain-C oracle (gcc -O2) forward_b"
+    return {"value": m.nac * nt / secs, "unit": "cell-timesteps/s", "cores": 1, "kind": kind,
+            "sample": f"{what}, {structure}, {n}x{n} synthetic catchment x {nt} hourly steps, {secs:.1f} s"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import smash_amd
+    from smash_amd import synth
+    from smash_amd.solver import Solver
+
+    n, nt = a.grid, a.nt
+    t_setup = time.perf_counter()
+    m = synth.make_mesh(n, n, ng=a.ng, seed=synth.SEED + rank)
+    setup = smash_amd.SetupDT(0, a.ng, structure=a.structure, dt=3600.0, ntime_step=nt)
+    setup.optimize.jobs_fun, setup.optimize.wjobs_fun = ["nse"], [1.0]
+    mesh = smash_amd.MeshDT.from_synth(setup, m)
+    sol = Solver(setup, mesh, chunk_steps=a.chunk, group_size=a.group, device=local)
+    rows, cols = sol.cell_order()
+    d_rows = torch.from_numpy(rows.astype(np.int64)).to(dev)
+    d_cols = torch.from_numpy(cols.astype(np.int64)).to(dev)
+    tb = max(1, min(nt, (1 << 26) // max(sol.ncells, 1)))     # ~64 M cell-steps of int64 temporaries per block
+    for t0 in range(0, nt, tb):
+        t1 = min(nt, t0 + tb)
+        prcp, pet = synth.forcing_block(d_rows, d_cols, t0, t1, xp=torch, device=dev)
+        torch.cuda.synchronize()
+        sol.set_forcing_device_block(t0, t1, prcp.data_ptr(), pet.data_ptr())
+        del prcp, pet
+    del d_rows, d_cols
+    torch.cuda.empty_cache()
+
+    P, S = synth.make_parameters(n, n), synth.make_states(n, n, warm=True)
+    par, sta = smash_amd.ParametersDT.from_dict(mesh, P), smash_amd.StatesDT.from_dict(mesh, S)
+    out = smash_amd.OutputDT(setup, mesh)
+    # observations = forward run with parameters perturbed by +10 %
+    parq = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(n, n, perturb=0.1))
+    sol.set_options(setup.optimize)
+    sol.upload(parq, sta)
+    sol.sweep(False)
+    sol.download(False, parq, sta, out)
+    sol.set_qobs(out.qsim)
+    sol.upload(par, sta)
+    t_setup = time.perf_counter() - t_setup
+
+    adjoint = not a.forward_only
+    for _ in range(a.warmup):
+        sol.sweep(adjoint)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tm_acc = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        sol.sweep(adjoint)          # smashx_sweep synchronises its stream before returning
+        for k, v in sol.timing().items():
+            tm_acc[k] = tm_acc.get(k, 0.0) + v
+    barrier()
+    secs = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([secs], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        secs = float(t.item())
+        cs = torch.tensor([float(sol.ncells) * nt], dtype=torch.float64, device=dev)
+        dist.all_reduce(cs, op=dist.ReduceOp.SUM)
+        cellsteps = float(cs.item())
+    else:
+        cellsteps = float(sol.ncells) * nt
+    par_b, sta_b = par.copy(), sta.copy()
+    cost = sol.download(adjoint, par, sta, out, par_b, sta_b)
+
+    if rank == 0:
+        K = a.steps
+        ms_per_step = secs * 1e3 / K
+        value = cellsteps * K / secs
+        tm = {k: v / K for k, v in tm_acc.items()}
+        # dominant kernel and its roofline: algorithmic bytes = 8 B per cell-step per vertical pass
+        # (prcp + pet read once forward, once in the reverse pass: SURVEY 8d, 16 B per forward+adjoint cell-step)
+        kern = {"sx_k_vert_fwd": (tm["vert_fwd_ms"], tm["vert_fwd_launches"]),
+                "sx_k_vert_adj": (tm["vert_adj_ms"], tm["vert_adj_launches"]),
+                "sx_k_route_fwd": (tm["route_fwd_ms"], tm["route_fwd_launches"]),
+                "sx_k_route_adj": (tm["route_adj_ms"], tm["route_adj_launches"])}
+        dom = max(kern, key=lambda k: kern[k][0])
+        dom_ms, dom_n = kern[dom]
+        per_launch_steps = float(sol.ncells) * nt / max(tm["n_chunks"], 1)       # cell-steps one launch processes
+        if dom.startswith("sx_k_vert"):
+            alg_bytes = 8.0 * per_launch_steps
+            n_launch = max(dom_n, 1.0)
+            avg_ms = dom_ms / n_launch
+        else:
+            alg_bytes = 4.0 * per_launch_steps       # routing reads qt once; it is not the streaming kernel
+            n_launch = max(tm["n_chunks"], 1)
+            avg_ms = dom_ms / n_launch
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        sweep_bytes = (16.0 if adjoint else 8.0) * float(sol.ncells) * nt
+        line = {
+            "metric": "cell-timesteps/s, forward+adjoint sweep" if adjoint else "cell-timesteps/s, forward sweep",
+            "value": value, "unit": "cell-timesteps/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{n}x{n} synthetic catchment per GPU (D8 E/SE/S, all cells active), hourly x {nt} steps, "
+                                   f"{a.structure}, nse cost at {a.ng} gauges, one forward+adjoint sweep = cost + gradient of all "
+                                   "distributed parameters and initial states (BASELINE.json configs[2])",
+                       "grid": [n, n], "nt": nt, "structure": a.structure, "active_cells": sol.ncells,
+                       "chunk_steps": int(tm["chunk_steps"]), "n_chunks": int(tm["n_chunks"]),
+                       "routing_rounds": int(tm["n_rounds"]), "routing_groups": int(tm["n_groups"]),
+                       "parallelism": f"tiles{world}" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches_per_step": n_launch,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "sweep_frac": sweep_bytes / (tm["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "pointwise transcendental-heavy path: the VALU ceiling binds before HBM (DESIGN.md)"},
+            "kernel_ms_per_step": {k: round(v[0], 3) for k, v in kern.items()},
+            "device_sweep_ms": tm["sweep_ms"], "cost": cost, "setup_s": t_setup,
+            "hbm_plan_gb": tm["device_bytes"] / 1e9,
+        }
+        if not a.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(a.structure, a.cpu_grid, a.cpu_nt)
+            except Exception as e:  # pragma: no cover
+                line["cpu_baseline"] = {"value": None, "unit": "cell-timesteps/s", "cores": 1, "kind": "port",
+                                        "sample": f"failed: {e}"}
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

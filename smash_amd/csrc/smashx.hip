@@ -160,6 +160,10 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
             Tc = (int)std::max<long>(16, std::min<long>(nt16, t));
         }
         Tc = std::min(Tc, nt16);
+        {   // balance the chunks: same count, equal lengths
+            const int nch = (p->nt + Tc - 1) / Tc;
+            Tc = std::min(Tc, ((p->nt + nch - 1) / nch + 15) / 16 * 16);
+        }
         p->Tc = Tc;
         p->A.Tc = Tc;
         p->nchunks = (p->nt + Tc - 1) / Tc;

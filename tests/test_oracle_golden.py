@@ -36,7 +36,7 @@ def test_oracle_adjoint_bit_exact(name):
 def test_oracle_gradient_taylor():
     """Restatement of the reference's gradient_test idea (mw_adjoint_test.f90:108-189): the adjoint
     gradient agrees with a central finite difference of the cost along a random direction."""
-    g = gu.load("gr_b_16x16x96_nse_gaps")
+    g = gu.load("gr_a_12x12x48_nse_cold")
     o = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, adjoint=True)
     rng = np.random.default_rng(0)
     act = g.mesh.active_cell == 1
