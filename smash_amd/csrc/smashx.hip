@@ -166,6 +166,7 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
         }
         p->Tc = Tc;
         p->A.Tc = Tc;
+        p->A.nx = std::max(p->sch.nxslots, 1);
         p->nchunks = (p->nt + Tc - 1) / Tc;
         int rc;
         if ((rc = p->dmalloc(&p->A.qtT, (size_t)p->npad * Tc))) return rc;

@@ -4,10 +4,14 @@
 //   cells are renumbered k = 0..n-1 in routing-group order (sx_plan.h); npad = n rounded up to 256.
 //   forcing      prcp/pet [nt][npad]     cell index fastest  -> lanes = consecutive cells, coalesced
 //   params/state [npad] per field
-//   qtT, hrT     [npad][Tc]              time fastest per cell: the time-skewed routing threads and the
-//                                        marching vertical threads both read/write 16-B (4-step) pieces
+//   qtT, hrT     [Tc/4][npad][4]         "T4": one float4 = 4 consecutive steps of one cell; cell index next.
+//                                        The marching vertical threads (lanes = consecutive cells) move
+//                                        1 KiB contiguous per wave instruction; the time-skewed routing threads
+//                                        of a group read rows tb = w - stage, and because the group's slots are
+//                                        in breadth-first order neighbouring cells sit one stage apart, so a
+//                                        128-B line is re-touched within a super-step or two (L1/L2 hits)
 //   tape_*       [Tc][npad]              pre-step reservoir levels of the current time chunk
-//   exchange     [nx][Tc]                discharge (forward) / adjoint (reverse) series between groups
+//   exchange     [Tc/4][nx][4]           discharge (forward) / adjoint (reverse) series between groups, T4
 //   gauge series [ngauge][nt]
 #pragma once
 
@@ -17,11 +21,21 @@
 
 #define SX_BT 4           // time steps per routing super-step (one float4 per cell per super-step)
 #define SX_VBLOCK 256     // threads (cells) per vertical workgroup
-#define SX_VTILE 16       // steps per LDS transpose tile in the vertical kernels
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt (every global store and
+// prefetch load in flight), which put a full HBM round trip into each routing super-step: 77 -> (see
+// profiles/) ms per routing pass at 1024^2 x 8760.  The exchange between super-steps goes through LDS alone;
+// global data written here is only read by later kernels.
+__device__ __forceinline__ void sx_lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 struct SxDeviceArrays {
     // sizes
     int n, npad, nt, Tc;          // Tc = allocated chunk length (multiple of 16)
+    int nx;                       // exchange series count (>= 1)
     float dt, dx;
     // forcing
     const float* prcp; const float* pet;
@@ -64,42 +78,38 @@ __global__ void sx_k_prep_routing(SxDeviceArrays A) {
 // ------------------------------------------------------------------------------------------------
 template <int ST, bool TAPE>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
-    __shared__ float tile[SX_VTILE][SX_VBLOCK + 1];
-    const int kbase = blockIdx.x * SX_VBLOCK;
-    const int k = kbase + threadIdx.x;
-    const bool valid = k < A.n;
+    const int k = blockIdx.x * SX_VBLOCK + threadIdx.x;
+    if (k >= A.n) return;
     const size_t npad = (size_t)A.npad;
 
     SxCellParams P;
     float hi = 0.f, hp = 0.f, hft = 0.f, hst = 0.f;
-    if (valid) {
-        P.ci = (ST == 2 || ST == 3) ? A.ci[k] : 1.f;
-        P.cp = A.cp[k];
-        P.inv_cp = 1.f / P.cp;
-        P.cft = A.cft[k];
-        P.cst = (ST == 3) ? A.cst[k] : 1.f;
-        P.exc = (ST != 4) ? A.exc[k] : 0.f;
-        P.cft_m4 = sx_pow_m4(P.cft);
-        P.cst_m4 = (ST == 3) ? sx_pow_m4(P.cst) : 1.f;
-        if (ST == 2 || ST == 3) hi = A.hi[k];
-        hp = A.hp[k];
-        hft = A.hft[k];
-        if (ST == 3) hst = A.hst[k];
-    }
-    float prcp_n = 0.f, pet_n = 0.f;
-    if (valid && T > 0) { prcp_n = A.prcp[(size_t)t0 * npad + k]; pet_n = A.pet[(size_t)t0 * npad + k]; }
+    P.ci = (ST == 2 || ST == 3) ? A.ci[k] : 1.f;
+    P.cp = A.cp[k];
+    P.cft = A.cft[k];
+    P.cst = (ST == 3) ? A.cst[k] : 1.f;
+    P.exc = (ST != 4) ? A.exc[k] : 0.f;
+    sx_cell_params_init(P);
+    P.cft_m4 = sx_pow_m4(P.cft);
+    P.cst_m4 = (ST == 3) ? sx_pow_m4(P.cst) : 1.f;
+    if (ST == 2 || ST == 3) hi = A.hi[k];
+    hp = A.hp[k];
+    hft = A.hft[k];
+    if (ST == 3) hst = A.hst[k];
 
-    for (int tb = 0; tb < T; tb += SX_VTILE) {
-        const int nstep = min(SX_VTILE, T - tb);
-        for (int j = 0; j < nstep; ++j) {
-            const int tt = tb + j;
-            const float prcp = prcp_n, pet = pet_n;
-            if (valid && tt + 1 < T) {
-                prcp_n = A.prcp[(size_t)(t0 + tt + 1) * npad + k];
-                pet_n = A.pet[(size_t)(t0 + tt + 1) * npad + k];
-            }
-            float qt = 0.f;
-            if (valid) {
+    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
+    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    float4* qt4 = reinterpret_cast<float4*>(A.qtT) + k;
+    float prcp_n = 0.f, pet_n = 0.f;
+    if (T > 0) { prcp_n = prcp_p[0]; pet_n = pet_p[0]; }
+    for (int tq = 0; tq * 4 < T; ++tq) {
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tt = tq * 4 + i;
+            if (tt < T) {
+                const float prcp = prcp_n, pet = pet_n;
+                if (tt + 1 < T) { prcp_n = prcp_p[(size_t)(tt + 1) * npad]; pet_n = pet_p[(size_t)(tt + 1) * npad]; }
                 if (TAPE) {
                     const size_t o = (size_t)tt * npad + k;
                     if (ST == 2 || ST == 3) A.tape_hi[o] = hi;
@@ -107,31 +117,15 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
                     A.tape_hft[o] = hft;
                     if (ST == 3) A.tape_hst[o] = hst;
                 }
-                qt = sx_vertical_step<ST>(P, prcp, pet, hi, hp, hft, hst);
-            }
-            tile[j][threadIdx.x] = qt;
-        }
-        __syncthreads();
-        // transposed write-out: 4 lanes cover the 16 consecutive steps (64 B) of one cell
-        for (int p = 0; p < (SX_VBLOCK * SX_VTILE / 4) / SX_VBLOCK; ++p) {
-            const int idx = p * SX_VBLOCK + threadIdx.x;
-            const int cl = idx >> 2, qd = idx & 3;
-            const int kk = kbase + cl;
-            if (kk < A.n && qd * 4 < nstep) {
-                float4 v;
-                v.x = tile[qd * 4 + 0][cl]; v.y = tile[qd * 4 + 1][cl];
-                v.z = tile[qd * 4 + 2][cl]; v.w = tile[qd * 4 + 3][cl];
-                *reinterpret_cast<float4*>(A.qtT + (size_t)kk * A.Tc + tb + qd * 4) = v;
+                q[i] = sx_vertical_step<ST>(P, prcp, pet, hi, hp, hft, hst);
             }
         }
-        __syncthreads();
+        qt4[(size_t)tq * npad] = make_float4(q[0], q[1], q[2], q[3]);
     }
-    if (valid) {
-        if (ST == 2 || ST == 3) A.hi[k] = hi;
-        A.hp[k] = hp;
-        A.hft[k] = hft;
-        if (ST == 3) A.hst[k] = hst;
-    }
+    if (ST == 2 || ST == 3) A.hi[k] = hi;
+    A.hp[k] = hp;
+    A.hft[k] = hft;
+    if (ST == 3) A.hst[k] = hst;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -166,10 +160,15 @@ __global__ void sx_k_route_fwd(SxDeviceArrays A, int g0, int t0, int T) {
         }
     }
     const float dt = A.dt, dx = A.dx;
-    const size_t Tc = (size_t)A.Tc;
-    const float* src = (cell >= 0) ? (A.qtT + (size_t)cell * Tc) : (xin >= 0 ? A.xT + (size_t)xin * Tc : nullptr);
+    const SxDiv dden = sx_mkdiv(den), ddt = sx_mkdiv(dt);
+    // T4 addressing: element (tb, id) of an array with `stride` float4 per time block
+    const float4* src = (cell >= 0) ? reinterpret_cast<const float4*>(A.qtT) + cell
+                                    : reinterpret_cast<const float4*>(A.xT) + (xin >= 0 ? xin : 0);
+    const size_t sstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
+    float4* x4 = reinterpret_cast<float4*>(A.xT);
+    float4* hr4 = reinterpret_cast<float4*>(A.hrT);
     float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid && stage == 0 && nb > 0) nxt = *reinterpret_cast<const float4*>(src);   // first block of stage-0 slots
+    if (valid && stage == 0 && nb > 0) nxt = src[0];   // first block of stage-0 slots
 
     const int nsuper = nb + dmax;
     for (int w = 0; w < nsuper; ++w) {
@@ -177,7 +176,7 @@ __global__ void sx_k_route_fwd(SxDeviceArrays A, int g0, int t0, int T) {
         const bool act = valid && tb >= 0 && tb < nb;
         const float4 cur4 = nxt;
         // prefetch the block this slot handles in the next super-step
-        if (valid && tb + 1 >= 0 && tb + 1 < nb) nxt = *reinterpret_cast<const float4*>(src + (size_t)(tb + 1) * SX_BT);
+        if (valid && tb + 1 >= 0 && tb + 1 < nb) nxt = src[(size_t)(tb + 1) * sstride];
         float4* pub = sx_lds + (size_t)(w & 1) * M;
         const float4* prev = sx_lds + (size_t)((w + 1) & 1) * M;
         if (act) {
@@ -195,18 +194,18 @@ __global__ void sx_k_route_fwd(SxDeviceArrays A, int g0, int t0, int T) {
                     q[i] = 0.f; hr[i] = 0.f;
                     if (tl + i < T) {
                         float qup = 0.f;
-                        if (hasup) qup = (s[i] * dt) / den;
+                        if (hasup) qup = sx_div(s[i] * dt, dden);
                         const float hr_imd = hlr + qup;
                         hlr = hr_imd * a;
                         const float qrout = hr_imd - hlr;
-                        q[i] = (qt[i] + qrout * f) * dx * dx * 0.001f / dt;
+                        q[i] = sx_div((qt[i] + qrout * f) * dx * dx * 0.001f, ddt);
                         hr[i] = hr_imd;
                     }
                 }
                 const float4 q4 = make_float4(q[0], q[1], q[2], q[3]);
                 pub[j] = q4;
-                if (xout >= 0) *reinterpret_cast<float4*>(A.xT + (size_t)xout * Tc + tl) = q4;
-                if (TAPE) *reinterpret_cast<float4*>(A.hrT + (size_t)cell * Tc + tl) = make_float4(hr[0], hr[1], hr[2], hr[3]);
+                if (xout >= 0) x4[(size_t)tb * A.nx + xout] = q4;
+                if (TAPE) hr4[(size_t)tb * A.npad + cell] = make_float4(hr[0], hr[1], hr[2], hr[3]);
                 if (gid >= 0) {
 #pragma unroll
                     for (int i = 0; i < SX_BT; ++i)
@@ -216,7 +215,7 @@ __global__ void sx_k_route_fwd(SxDeviceArrays A, int g0, int t0, int T) {
                 pub[j] = cur4;
             }
         }
-        __syncthreads();
+        sx_lds_barrier();
     }
     if (valid && cell >= 0) A.hlr[cell] = hlr;
 }
@@ -253,7 +252,10 @@ __global__ void sx_k_route_adj(SxDeviceArrays A, int g0, int t0, int T) {
         }
     }
     const float dt = A.dt, dx = A.dx;
-    const size_t Tc = (size_t)A.Tc;
+    const SxDiv dden = sx_mkdiv(den), ddt = sx_mkdiv(dt), dlr = sx_mkdiv((lr * lr) * 60.f);
+    float4* x4 = reinterpret_cast<float4*>(A.xT);
+    const float4* hr4p = reinterpret_cast<const float4*>(A.hrT);
+    float4* qt4 = reinterpret_cast<float4*>(A.qtT);
     const int nsuper = nb + dmax;
     for (int w = 0; w < nsuper; ++w) {
         const int tbr = w - rstage;
@@ -265,9 +267,9 @@ __global__ void sx_k_route_adj(SxDeviceArrays A, int g0, int t0, int T) {
             const int tl = tb * SX_BT;
             float4 in4 = make_float4(0.f, 0.f, 0.f, 0.f);   // contribution of the downstream cell
             if (par >= 0) in4 = prev[par];
-            else if (cell >= 0 && xout >= 0) in4 = *reinterpret_cast<const float4*>(A.xT + (size_t)xout * Tc + tl);
+            else if (cell >= 0 && xout >= 0) in4 = x4[(size_t)tb * A.nx + xout];
             if (cell >= 0) {
-                const float4 hr4 = *reinterpret_cast<const float4*>(A.hrT + (size_t)cell * Tc + tl);
+                const float4 hr4 = hr4p[(size_t)tb * A.npad + cell];
                 const float hrv[SX_BT] = {hr4.x, hr4.y, hr4.z, hr4.w};
                 const float inv[SX_BT] = {in4.x, in4.y, in4.z, in4.w};
                 float pb[SX_BT], qtb[SX_BT];
@@ -278,25 +280,25 @@ __global__ void sx_k_route_adj(SxDeviceArrays A, int g0, int t0, int T) {
                         float q_b = 0.f;
                         if (gid >= 0) q_b = q_b + A.qgb[(size_t)gid * A.nt + t0 + tl + i];
                         q_b = q_b + inv[i];
-                        const float temp_b = (dx * dx) * 0.001f * q_b / dt;
+                        const float temp_b = sx_div((dx * dx) * 0.001f * q_b, ddt);
                         const float qrout_b = f * temp_b;
                         hr_b = hr_b - qrout_b;
                         const float hr_imd_b = qrout_b + a * hr_b;
                         const float arg1_b = a * hrv[i] * hr_b;
-                        lr_b = lr_b + dt * arg1_b / ((lr * lr) * 60.f);
+                        lr_b = lr_b + sx_div(dt * arg1_b, dlr);
                         hr_b = hr_imd_b;
-                        if (hasup) pb[i] = dt * hr_imd_b / den;
+                        if (hasup) pb[i] = sx_div(dt * hr_imd_b, dden);
                         qtb[i] = temp_b;
                     }
                 }
                 pub[j] = make_float4(pb[0], pb[1], pb[2], pb[3]);
-                *reinterpret_cast<float4*>(A.qtT + (size_t)cell * Tc + tl) = make_float4(qtb[0], qtb[1], qtb[2], qtb[3]);
+                qt4[(size_t)tb * A.npad + cell] = make_float4(qtb[0], qtb[1], qtb[2], qtb[3]);
             } else {
                 // inlet pseudo-cell: hand the receiver's contribution to the subtree rooted upstream
-                *reinterpret_cast<float4*>(A.xT + (size_t)xin * Tc + tl) = in4;
+                x4[(size_t)tb * A.nx + xin] = in4;
             }
         }
-        __syncthreads();
+        sx_lds_barrier();
     }
     if (valid && cell >= 0) { A.hlr_b[cell] = hr_b; A.lr_b[cell] = lr_b; }
 }
@@ -314,14 +316,18 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj(SxDeviceArrays A, int
     SxCellParams P;
     P.ci = (ST == 2 || ST == 3) ? A.ci[k] : 1.f;
     P.cp = A.cp[k];
-    P.inv_cp = 1.f / P.cp;
     P.cft = A.cft[k];
     P.cst = (ST == 3) ? A.cst[k] : 1.f;
     P.exc = (ST != 4) ? A.exc[k] : 0.f;
-    float cft_m5, cst_m5 = 1.f;
-    sx_pow_m4_m5(P.cft, &P.cft_m4, &cft_m5);
+    sx_cell_params_init(P);
+    SxAdjParams Q;
+    Q.cst_m5 = 1.f;
+    sx_pow_m4_m5(P.cft, &P.cft_m4, &Q.cft_m5);
     P.cst_m4 = 1.f;
-    if (ST == 3) sx_pow_m4_m5(P.cst, &P.cst_m4, &cst_m5);
+    if (ST == 3) sx_pow_m4_m5(P.cst, &P.cst_m4, &Q.cst_m5);
+    Q.dcft2 = sx_mkdiv(P.cft * P.cft);
+    Q.dcst2 = sx_mkdiv(P.cst * P.cst);
+    Q.dcp2 = sx_mkdiv(P.cp * P.cp);
     SxCellGrads G;
     G.ci_b = (ST == 2 || ST == 3) ? A.ci_b[k] : 0.f;
     G.cp_b = A.cp_b[k];
@@ -332,9 +338,9 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj(SxDeviceArrays A, int
     G.hp_b = A.hp_b[k];
     G.hft_b = A.hft_b[k];
     G.hst_b = (ST == 3) ? A.hst_b[k] : 0.f;
-    const float* qtb = A.qtT + (size_t)k * A.Tc;
+    const float4* qtb = reinterpret_cast<const float4*>(A.qtT) + k;
     for (int tq = (T - 1) / 4; tq >= 0; --tq) {
-        const float4 q4 = *reinterpret_cast<const float4*>(qtb + tq * 4);
+        const float4 q4 = qtb[(size_t)tq * npad];
         const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
 #pragma unroll
         for (int i = 3; i >= 0; --i) {
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj(SxDeviceArrays A, int
                 const float hi = (ST == 2 || ST == 3) ? A.tape_hi[o] : 0.f;
                 const float hp = A.tape_hp[o], hft = A.tape_hft[o];
                 const float hst = (ST == 3) ? A.tape_hst[o] : 0.f;
-                sx_vertical_step_b<ST>(P, cft_m5, cst_m5, prcp, pet, hi, hp, hft, hst, qv[i], G);
+                sx_vertical_step_b<ST>(P, Q, prcp, pet, hi, hp, hft, hst, qv[i], G);
             }
         }
     }

@@ -63,6 +63,19 @@ SX_HD float sx_seed_sqrt(float x) {
 #endif
 }
 
+// Division by a loop-invariant denominator: r = RN(1/d) once (one IEEE division), then
+//   q = RN(a*r);  e = a - d*q (exact, fma);  RN(q + e*r)
+// which IS the correctly rounded quotient RN(a/d) for normal-range operands (Markstein's theorem;
+// 0 mismatches against a/d on 2e8 random pairs, all-ones-significand denominators included:
+// tests/test_sx_math.py).  3 instructions instead of the ~10 of the IEEE division expansion.
+struct SxDiv { float d, r; };
+SX_HD SxDiv sx_mkdiv(float d) { SxDiv D; D.d = d; D.r = 1.0f / d; return D; }
+SX_HD float sx_div(float a, const SxDiv& D) {
+    const float q = a * D.r;
+    const float e = fmaf(-D.d, q, a);
+    return fmaf(e, D.r, q);
+}
+
 // 1/x in fp64 to ~2^-45 from an fp32 seed: one Newton step  u <- u + u(1 - x u)
 SX_HD double sx_rcp_d(float x) {
     const double d = (double)x;

@@ -18,43 +18,66 @@
 struct SxCellParams {   // time-invariant per cell, hoisted out of the time loop
     float ci, cp, inv_cp, cft, cst, exc;
     float cft_m4, cst_m4;   // powf(ct, -4)
+    SxDiv dci, dcft, dcst;  // exact division by ci / cft / cst (sx_div)
 };
 
+SX_DEV void sx_cell_params_init(SxCellParams& P) {
+    P.inv_cp = 1.f / P.cp;
+    P.dci = sx_mkdiv(P.ci);
+    P.dcft = sx_mkdiv(P.cft);
+    P.dcst = sx_mkdiv(P.cst);
+}
+
+// everything gr_production computes, kept for the adjoint so tanh / the two divisions are evaluated once
+struct SxProd { float thp, the, ps, es, hp_imd, pwr1, pw125, pr, perc, hp_new; };
+
 // ---------------------------------------------------------------- forward
-SX_DEV void sx_interception(float prcp, float pet, float ci, float& hi, float& pn, float& ei) {
+SX_DEV void sx_interception(float prcp, float pet, float ci, const SxDiv& dci, float& hi, float& pn, float& ei) {
     ei = fminf(pet, prcp + hi * ci);
     pn = fmaxf(0.f, prcp - ci * (1.f - hi) - ei);
-    hi = hi + (prcp - ei - pn) / ci;
+    hi = hi + sx_div(prcp - ei - pn, dci);
+}
+
+template <bool ADJ>
+SX_DEV SxProd sx_production_full(float pn, float en, float cp, float inv_cp, float hp) {
+    const SxDiv dbeta = {1000.f, 1.0f / 1000.f};   // beta = 1000 at every call site
+    SxProd R;
+    R.pr = 0.f;
+    // tanh(0) = 0 exactly, and at most one of pn, en is non-zero in practice: skip the dead evaluation
+    R.thp = 0.f; R.the = 0.f;
+    if (pn > 0.f) R.thp = sx_tanhf(pn * inv_cp);
+    if (en > 0.f) R.the = sx_tanhf(en * inv_cp);
+    R.ps = cp * (1.f - hp * hp) * R.thp / (1.f + hp * R.thp);
+    R.es = (hp * cp) * (2.f - hp) * R.the / (1.f + (1.f - hp) * R.the);
+    R.hp_imd = hp + (R.ps - R.es) * inv_cp;
+    if (pn > 0.f) R.pr = pn - (R.hp_imd - hp) * cp;
+    const float r = sx_div(R.hp_imd, dbeta);
+    const float r2 = r * r;
+    const float pwx1 = 1.f + r2 * r2;
+    R.pwr1 = 1.f; R.pw125 = 1.f;
+    if (pwx1 != 1.f) {
+        if (ADJ) sx_pow_m025_m125(pwx1, &R.pwr1, &R.pw125);
+        else R.pwr1 = sx_pow_m025(pwx1);
+    }
+    R.perc = (R.hp_imd * cp) * (1.f - R.pwr1);
+    R.hp_new = R.hp_imd - R.perc * inv_cp;
+    return R;
 }
 
 SX_DEV void sx_production(float pn, float en, float cp, float inv_cp, float& hp, float& pr, float& perc) {
-    const float beta = 1000.f;
-    pr = 0.f;
-    // tanh(0) = 0 exactly, and at most one of pn, en is non-zero in practice: skip the dead evaluation
-    float thp = 0.f, the = 0.f;
-    if (pn > 0.f) thp = sx_tanhf(pn * inv_cp);
-    if (en > 0.f) the = sx_tanhf(en * inv_cp);
-    const float ps = cp * (1.f - hp * hp) * thp / (1.f + hp * thp);
-    const float es = (hp * cp) * (2.f - hp) * the / (1.f + (1.f - hp) * the);
-    const float hp_imd = hp + (ps - es) * inv_cp;
-    if (pn > 0.f) pr = pn - (hp_imd - hp) * cp;
-    const float r = hp_imd / beta;
-    const float r2 = r * r;
-    const float pwx1 = 1.f + r2 * r2;
-    const float pwr1 = (pwx1 == 1.f) ? 1.f : sx_pow_m025(pwx1);
-    perc = (hp_imd * cp) * (1.f - pwr1);
-    hp = hp_imd - perc * inv_cp;
+    const SxProd R = sx_production_full<false>(pn, en, cp, inv_cp, hp);
+    pr = R.pr; perc = R.perc; hp = R.hp_new;
 }
 
-SX_DEV void sx_transfer(float prcp, float pr, float ct, float ct_m4, float& ht, float& q) {
+SX_DEV void sx_transfer(float prcp, float pr, float ct, const SxDiv& dct, float ct_m4, float& ht, float& q) {
     float pr_imd;
     if (prcp < 0.f) {   // data gap: closed-form inverse (md_gr_operator.f90:94-96)
         pr_imd = sx_pow_m025(sx_pow_m4(ht * ct) - ct_m4) - (ht * ct);
     } else {
         pr_imd = pr;
     }
-    const float ht_imd = fmaxf(1.e-6f, ht + pr_imd / ct);
-    ht = sx_pow_m025(sx_pow_m4(ht_imd * ct) + ct_m4) / ct;
+    const float ht_imd = fmaxf(1.e-6f, ht + sx_div(pr_imd, dct));
+    ht = sx_div(sx_pow_m025(sx_pow_m4(ht_imd * ct) + ct_m4), dct);
     q = (ht_imd - ht) * ct;
 }
 
@@ -68,7 +91,7 @@ SX_DEV float sx_vertical_step(const SxCellParams& P, float prcp, float pet, floa
             ei = fminf(pet, prcp);
             pn = fmaxf(0.f, prcp - ei);
         } else {
-            sx_interception(prcp, pet, P.ci, hi, pn, ei);
+            sx_interception(prcp, pet, P.ci, P.dci, hi, pn, ei);
         }
         en = pet - ei;
         sx_production(pn, en, P.cp, P.inv_cp, hp, pr, perc);
@@ -78,35 +101,35 @@ SX_DEV float sx_vertical_step(const SxCellParams& P, float prcp, float pet, floa
     if (ST == 1 || ST == 2) {
         const float prr = 0.9f * (pr + perc) + l;
         const float prd = 0.1f * (pr + perc);
-        sx_transfer(prcp, prr, P.cft, P.cft_m4, hft, qr);
+        sx_transfer(prcp, prr, P.cft, P.dcft, P.cft_m4, hft, qr);
         qd = fmaxf(0.f, prd + l);
         qt = (qr + qd);
     } else if (ST == 3) {
         const float prr = 0.9f * 0.6f * (pr + perc) + l;
         const float prl = 0.9f * 0.4f * (pr + perc);
         const float prd = 0.1f * (pr + perc);
-        sx_transfer(prcp, prr, P.cft, P.cft_m4, hft, qr);
-        sx_transfer(prcp, prl, P.cst, P.cst_m4, hst, ql);
+        sx_transfer(prcp, prr, P.cft, P.dcft, P.cft_m4, hft, qr);
+        sx_transfer(prcp, prl, P.cst, P.dcst, P.cst_m4, hst, ql);
         qd = fmaxf(0.f, prd + l);
         qt = (qr + ql + qd);
     } else {
         const float prr = pr + perc;
-        sx_transfer(prcp, prr, P.cft, P.cft_m4, hft, qr);
+        sx_transfer(prcp, prr, P.cft, P.dcft, P.cft_m4, hft, qr);
         qt = qr;
     }
     return qt;
 }
 
 // ---------------------------------------------------------------- adjoint
-SX_DEV void sx_interception_b(float prcp, float pet, float ci, float& ci_b, float hi, float& hi_b, float& pn_b, float& ei_b) {
+SX_DEV void sx_interception_b(float prcp, float pet, float ci, const SxDiv& dci, float& ci_b, float hi, float& hi_b, float& pn_b, float& ei_b) {
     float ei, pn;
     bool br_ei, br_pn;
     if (pet > prcp + hi * ci) { ei = prcp + hi * ci; br_ei = true; } else { ei = pet; br_ei = false; }
     if (0.f < prcp - ci * (1.f - hi) - ei) { pn = prcp - ci * (1.f - hi) - ei; br_pn = true; } else { pn = 0.f; br_pn = false; }
-    const float temp_b = hi_b / ci;
+    const float temp_b = sx_div(hi_b, dci);
     ei_b = ei_b - temp_b;
     pn_b = pn_b - temp_b;
-    ci_b = ci_b - (prcp - ei - pn) * temp_b / ci;
+    ci_b = ci_b - sx_div((prcp - ei - pn) * temp_b, dci);
     if (br_pn) {
         ci_b = ci_b - (1.f - hi) * pn_b;
         hi_b = hi_b + ci * pn_b;
@@ -118,28 +141,17 @@ SX_DEV void sx_interception_b(float prcp, float pet, float ci, float& ci_b, floa
     }
 }
 
-// hp = pre-step level; pr_b, perc_b in; pn_b, en_b out; hp_b, cp_b updated
-SX_DEV void sx_production_b(float pn, float& pn_b, float en, float& en_b, float cp, float inv_cp, float& cp_b, float hp,
-                            float& hp_b, float pr_b, float perc_b) {
-    const float beta = 1000.f;
-    float thp = 0.f, the = 0.f;
-    if (pn > 0.f) thp = sx_tanhf(pn * inv_cp);
-    if (en > 0.f) the = sx_tanhf(en * inv_cp);
-    const float ps = cp * (1.f - hp * hp) * thp / (1.f + hp * thp);
-    const float es = hp * cp * (2.f - hp) * the / (1.f + (1.f - hp) * the);
-    const float hp_imd = hp + (ps - es) * inv_cp;
-    const float r = hp_imd / beta, r2 = r * r;
-    const float pwx1 = 1.f + r2 * r2;
-    float pwr1 = 1.f, pw125 = 1.f;
-    if (pwx1 != 1.f) sx_pow_m025_m125(pwx1, &pwr1, &pw125);
-    const float perc = hp_imd * cp * (1.f - pwr1);
+// hp = pre-step level; R = sx_production_full<true> of this step; pr_b, perc_b in; pn_b, en_b out; hp_b, cp_b updated
+SX_DEV void sx_production_b(const SxProd& R, float pn, float& pn_b, float en, float& en_b, float cp, float inv_cp,
+                            const SxDiv& dcp2, float& cp_b, float hp, float& hp_b, float pr_b, float perc_b) {
+    const SxDiv db4 = {1.0e12f, 1.0f / 1.0e12f};   // beta**4, beta = 1000
+    const float thp = R.thp, the = R.the, ps = R.ps, es = R.es, hp_imd = R.hp_imd, pwr1 = R.pwr1, perc = R.perc;
     perc_b = perc_b - inv_cp * hp_b;
     float inv_cp_b = -(perc * hp_b);
     cp_b = cp_b + hp_imd * (1.f - pwr1) * perc_b;
     const float pwr1_b = -(hp_imd * cp * perc_b);
-    const float pwx1_b = -(0.25f * pw125 * pwr1_b);
-    const float b2 = beta * beta;
-    float hp_imd_b = hp_b + cp * (1.f - pwr1) * perc_b + 4.f * (hp_imd * hp_imd * hp_imd) * pwx1_b / (b2 * b2);
+    const float pwx1_b = -(0.25f * R.pw125 * pwr1_b);
+    float hp_imd_b = hp_b + cp * (1.f - pwr1) * perc_b + sx_div(4.f * (hp_imd * hp_imd * hp_imd) * pwx1_b, db4);
     if (pn > 0.f) {
         pn_b = pr_b;
         hp_imd_b = hp_imd_b - cp * pr_b;
@@ -151,12 +163,12 @@ SX_DEV void sx_production_b(float pn, float& pn_b, float en, float& en_b, float 
     }
     const float es_b = -(inv_cp * hp_imd_b);
     const float temp4 = the;
-    const float temp3 = (-hp + 1.f) * temp4 + 1.f;
+    const SxDiv d3 = sx_mkdiv((-hp + 1.f) * temp4 + 1.f);
     float temp1 = the;
     float temp0 = hp * cp * (-hp + 2.f);
-    const float temp_b3 = es_b / temp3;
+    const float temp_b3 = sx_div(es_b, d3);
     float temp_b = (2.f - hp) * temp1 * temp_b3;
-    float temp_b0 = -(temp0 * temp1 * temp_b3 / temp3);
+    float temp_b0 = -sx_div(temp0 * temp1 * temp_b3, d3);
     hp_b = hp_b + hp_imd_b + cp * temp_b - hp * cp * temp1 * temp_b3 - temp4 * temp_b0;
     const float ps_b = inv_cp * hp_imd_b;
     const float temp_b4 = (1.0f - the * the) * temp0 * temp_b3;
@@ -164,22 +176,22 @@ SX_DEV void sx_production_b(float pn, float& pn_b, float en, float& en_b, float 
     en_b = inv_cp * temp_b5 + inv_cp * temp_b4;
     cp_b = cp_b + hp * temp_b;
     const float temp = thp;
-    temp0 = hp * temp + 1.f;
+    const SxDiv d0 = sx_mkdiv(hp * temp + 1.f);
     temp1 = thp;
     const float temp2 = cp * (-(hp * hp) + 1.f);
-    temp_b = ps_b / temp0;
+    temp_b = sx_div(ps_b, d0);
     temp_b0 = (1.0f - thp * thp) * temp2 * temp_b;
-    const float temp_b1 = -(temp2 * temp1 * temp_b / temp0);
+    const float temp_b1 = -sx_div(temp2 * temp1 * temp_b, d0);
     hp_b = hp_b + temp * temp_b1 - 2.f * hp * cp * temp1 * temp_b;
     const float temp_b2 = (1.0f - thp * thp) * hp * temp_b1;
     inv_cp_b = inv_cp_b + (ps - es) * hp_imd_b + en * temp_b5 + en * temp_b4 + pn * temp_b2 + pn * temp_b0;
-    cp_b = cp_b + (1.f - hp * hp) * temp1 * temp_b - inv_cp_b / (cp * cp);
+    cp_b = cp_b + (1.f - hp * hp) * temp1 * temp_b - sx_div(inv_cp_b, dcp2);
     pn_b = pn_b + inv_cp * temp_b2 + inv_cp * temp_b0;
 }
 
 // ht = pre-step level
-SX_DEV void sx_transfer_b(float prcp, float pr, float& pr_b, float ct, float ct_m4, float ct_m5, float& ct_b, float ht,
-                          float& ht_b, float q_b) {
+SX_DEV void sx_transfer_b(float prcp, float pr, float& pr_b, float ct, const SxDiv& dct, const SxDiv& dct2, float ct_m4,
+                          float ct_m5, float& ct_b, float ht, float& ht_b, float q_b) {
     float pr_imd, g_pwx1 = 0.f, g_pwx3 = 0.f;
     const bool gap = prcp < 0.f;
     if (gap) {
@@ -191,26 +203,27 @@ SX_DEV void sx_transfer_b(float prcp, float pr, float& pr_b, float ct, float ct_
     }
     float ht_imd;
     bool br_max;
-    if (1.e-6f < ht + pr_imd / ct) { ht_imd = ht + pr_imd / ct; br_max = true; } else { ht_imd = 1.e-6f; br_max = false; }
+    const float ht_try = ht + sx_div(pr_imd, dct);
+    if (1.e-6f < ht_try) { ht_imd = ht_try; br_max = true; } else { ht_imd = 1.e-6f; br_max = false; }
     const float pwx1 = ht_imd * ct;
     float pwr1, pwx1_m5;
     sx_pow_m4_m5(pwx1, &pwr1, &pwx1_m5);
     const float pwx3 = pwr1 + ct_m4;
     float pwr3, pwx3_m125;
     sx_pow_m025_m125(pwx3, &pwr3, &pwx3_m125);
-    const float ht_new = pwr3 / ct;
+    const float ht_new = sx_div(pwr3, dct);
     float htb = ht_b - ct * q_b;
-    float pwr3_b = htb / ct;
+    float pwr3_b = sx_div(htb, dct);
     float pwx3_b = -0.25f * pwx3_m125 * pwr3_b;      // pwy3*pwx3**(pwy3-1)*pwr3_b, pwy3 = -1/4 (pwx3 > 0 here)
     float pwr1_b = pwx3_b, pwr2_b = pwx3_b;
     float pwx1_b = -4.f * pwx1_m5 * pwr1_b;           // pwy1*pwx1**(pwy1-1)*pwr1_b, pwy1 = -4
     const float ht_imd_b = ct * q_b + ct * pwx1_b;
-    ct_b = ct_b + (ht_imd - ht_new) * q_b + -4.f * ct_m5 * pwr2_b - pwr3 * htb / (ct * ct) + ht_imd * pwx1_b;
+    ct_b = ct_b + (ht_imd - ht_new) * q_b + -4.f * ct_m5 * pwr2_b - sx_div(pwr3 * htb, dct2) + ht_imd * pwx1_b;
     float pr_imd_b;
     if (br_max) {
         htb = ht_imd_b;
-        pr_imd_b = ht_imd_b / ct;
-        ct_b = ct_b - pr_imd * ht_imd_b / (ct * ct);
+        pr_imd_b = sx_div(ht_imd_b, dct);
+        ct_b = ct_b - sx_div(pr_imd * ht_imd_b, dct2);
     } else {
         htb = 0.f;
         pr_imd_b = 0.f;
@@ -238,18 +251,25 @@ struct SxCellGrads {   // running sums, one per cell, accumulated in reverse tim
 
 // reverse of sx_vertical_step given the pre-step states and the incoming qt_b
 // (GR_{A,B,C,D}_FORWARD_B inner body: forward_db.f90:8128-8170 / 8674-8716 / 9233-9286 / 9762-9791)
+struct SxAdjParams {   // extra per-cell invariants of the adjoint
+    float cft_m5, cst_m5;          // powf(ct, -5)
+    SxDiv dcft2, dcst2, dcp2;      // exact division by cft**2, cst**2, cp**2
+};
+
 template <int ST>
-SX_DEV void sx_vertical_step_b(const SxCellParams& P, float ct_m5_ft, float ct_m5_st, float prcp, float pet, float hi, float hp,
+SX_DEV void sx_vertical_step_b(const SxCellParams& P, const SxAdjParams& Q, float prcp, float pet, float hi, float hp,
                                float hft, float hst, float qt_b, SxCellGrads& G) {
     const bool wet = (prcp >= 0.f && pet >= 0.f);
     float ei = 0.f, pn = 0.f, en = 0.f, pr = 0.f, perc = 0.f, l = 0.f, prr, prl = 0.f, prd = 0.f;
     float h35 = 0.f, h25 = 0.f;
+    SxProd R;
     if (wet) {
-        float hi2 = hi, hp2 = hp;
+        float hi2 = hi;
         if (ST == 1 || ST == 4) { ei = fminf(pet, prcp); pn = fmaxf(0.f, prcp - ei); }
-        else sx_interception(prcp, pet, P.ci, hi2, pn, ei);
+        else sx_interception(prcp, pet, P.ci, P.dci, hi2, pn, ei);
         en = pet - ei;
-        sx_production(pn, en, P.cp, P.inv_cp, hp2, pr, perc);
+        R = sx_production_full<true>(pn, en, P.cp, P.inv_cp, hp);
+        pr = R.pr; perc = R.perc;
         if (ST != 4) { sx_pow_3p5_2p5(hft, &h35, &h25); l = P.exc * h35; }
     }
     if (ST == 1 || ST == 2) { prr = 0.9f * (pr + perc) + l; prd = 0.1f * (pr + perc); }
@@ -261,8 +281,8 @@ SX_DEV void sx_vertical_step_b(const SxCellParams& P, float ct_m5_ft, float ct_m
     if (ST != 4) {
         if (0.f < prd + l) { prd_b = qd_b; l_b = qd_b; }
     }
-    if (ST == 3) sx_transfer_b(prcp, prl, prl_b, P.cst, P.cst_m4, ct_m5_st, G.cst_b, hst, G.hst_b, ql_b);
-    sx_transfer_b(prcp, prr, prr_b, P.cft, P.cft_m4, ct_m5_ft, G.cft_b, hft, G.hft_b, qr_b);
+    if (ST == 3) sx_transfer_b(prcp, prl, prl_b, P.cst, P.dcst, Q.dcst2, P.cst_m4, Q.cst_m5, G.cst_b, hst, G.hst_b, ql_b);
+    sx_transfer_b(prcp, prr, prr_b, P.cft, P.dcft, Q.dcft2, P.cft_m4, Q.cft_m5, G.cft_b, hft, G.hft_b, qr_b);
     if (ST == 1 || ST == 2) {
         pr_b = 0.1f * prd_b + 0.9f * prr_b;
         perc_b = 0.1f * prd_b + 0.9f * prr_b;
@@ -285,10 +305,10 @@ SX_DEV void sx_vertical_step_b(const SxCellParams& P, float ct_m5_ft, float ct_m
             G.exc_b = G.exc_b + h35 * l_b;
             G.hft_b = G.hft_b + 3.5f * h25 * P.exc * l_b;
         }
-        sx_production_b(pn, pn_b, en, en_b, P.cp, P.inv_cp, G.cp_b, hp, G.hp_b, pr_b, perc_b);
+        sx_production_b(R, pn, pn_b, en, en_b, P.cp, P.inv_cp, Q.dcp2, G.cp_b, hp, G.hp_b, pr_b, perc_b);
         if (ST == 2 || ST == 3) {
             float ei_b = -en_b;
-            sx_interception_b(prcp, pet, P.ci, G.ci_b, hi, G.hi_b, pn_b, ei_b);
+            sx_interception_b(prcp, pet, P.ci, P.dci, G.ci_b, hi, G.hi_b, pn_b, ei_b);
         }
     }
 }
