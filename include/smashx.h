@@ -52,7 +52,8 @@ typedef struct {
     int ng;
     float dt;          /* s */
     float dx;          /* m */
-    int chunk_steps;   /* time-chunk length of the checkpointed adjoint; 0 = choose from free HBM */
+    int chunk_steps;   /* storage chunk: steps kept on the tape at once (recompute unit of the checkpointed adjoint); 0 = from free HBM */
+    int pipe_steps;    /* pipeline sub-chunk: vertical and routing kernels overlap chunk by chunk on two streams; 0 = no sub-chunking */
     int group_size;    /* routing workgroup size (cells + inlets per group); 0 = default */
     int device;        /* HIP device ordinal; -1 = current device */
 } smashx_config;
@@ -100,7 +101,7 @@ typedef struct {
     float route_adj_ms;
     float vert_adj_ms;
     int   vert_fwd_launches, route_fwd_launches, route_adj_launches, vert_adj_launches;
-    int   n_chunks, chunk_steps, n_rounds, n_groups;
+    int   n_chunks, chunk_steps, pipe_steps, n_rounds, n_groups;
     double device_bytes;     /* HBM held by the plan */
 } smashx_timing;
 

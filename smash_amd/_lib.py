@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmashx.so")
+LIB_PATH = os.environ.get("SMASHX_LIB", os.path.join(_HERE, "libsmashx.so"))   # override only for A/B experiments
 
 GNP, GNS = 16, 8
 
@@ -22,7 +22,7 @@ SYMBOLS = [
 
 class Config(C.Structure):
     _fields_ = [("structure", C.c_int), ("nrow", C.c_int), ("ncol", C.c_int), ("nt", C.c_int), ("ng", C.c_int),
-                ("dt", C.c_float), ("dx", C.c_float), ("chunk_steps", C.c_int), ("group_size", C.c_int),
+                ("dt", C.c_float), ("dx", C.c_float), ("chunk_steps", C.c_int), ("pipe_steps", C.c_int), ("group_size", C.c_int),
                 ("device", C.c_int)]
 
 
@@ -55,7 +55,7 @@ class Timing(C.Structure):
     _fields_ = [("sweep_ms", C.c_float), ("vert_fwd_ms", C.c_float), ("route_fwd_ms", C.c_float), ("cost_ms", C.c_float),
                 ("route_adj_ms", C.c_float), ("vert_adj_ms", C.c_float), ("vert_fwd_launches", C.c_int),
                 ("route_fwd_launches", C.c_int), ("route_adj_launches", C.c_int), ("vert_adj_launches", C.c_int),
-                ("n_chunks", C.c_int), ("chunk_steps", C.c_int), ("n_rounds", C.c_int), ("n_groups", C.c_int),
+                ("n_chunks", C.c_int), ("chunk_steps", C.c_int), ("pipe_steps", C.c_int), ("n_rounds", C.c_int), ("n_groups", C.c_int),
                 ("device_bytes", C.c_double)]
 
 

@@ -86,7 +86,9 @@ struct smashx_plan {
     bool chunk_ready = false, adj_ready = false;
     smashx_options opt{};
     std::vector<float> wgauge;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // vertical kernels, uploads/downloads ("V stream")
+    hipStream_t stream_r = nullptr;  // routing + cost kernels ("R stream"); overlaps the V stream chunk by chunk
+    int Tp = 0;                      // pipeline sub-chunk length inside a storage chunk
     std::vector<void*> allocs;
     double bytes = 0;
     SxDeviceArrays A{};
@@ -131,8 +133,9 @@ struct smashx_plan {
         if (pool_used == pool.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; pool.push_back(e); }
         return pool[pool_used++];
     }
-    void mark_begin(int kind) { Launch l; l.a = event(); l.b = nullptr; l.kind = kind; if (l.a) (void)hipEventRecord(l.a, stream); launches.push_back(l); }
-    void mark_end() { Launch& l = launches.back(); l.b = event(); if (l.b) (void)hipEventRecord(l.b, stream); }
+    hipStream_t cur = nullptr;       // stream of the launch being marked
+    void mark_begin(int kind, hipStream_t st) { cur = st; Launch l; l.a = event(); l.b = nullptr; l.kind = kind; if (l.a) (void)hipEventRecord(l.a, st); launches.push_back(l); }
+    void mark_end() { Launch& l = launches.back(); l.b = event(); if (l.b) (void)hipEventRecord(l.b, cur); }
 };
 
 namespace {
@@ -168,6 +171,13 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
         p->A.Tc = Tc;
         p->A.nx = std::max(p->sch.nxslots, 1);
         p->nchunks = (p->nt + Tc - 1) / Tc;
+        {   // optional pipeline sub-chunks (V stream || R stream), equal lengths, multiples of 16.  Default: none --
+            // measured at 1024^2 x 8760: overlapping the latency-bound routing groups with the vertical kernel
+            // costs more (routing fill per sub-chunk, wave slots taken from the vertical kernel) than it hides.
+            int want = p->cfg.pipe_steps > 0 ? p->cfg.pipe_steps : Tc;
+            const int nsub = std::max(1, (Tc + want / 2) / want);
+            p->Tp = std::min(Tc, ((Tc + nsub - 1) / nsub + 15) / 16 * 16);
+        }
         int rc;
         if ((rc = p->dmalloc(&p->A.qtT, (size_t)p->npad * Tc))) return rc;
         if ((rc = p->dmalloc(&p->A.xT, (size_t)std::max(p->sch.nxslots, 1) * Tc))) return rc;
@@ -194,49 +204,67 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
     return 0;
 }
 
+// view of the chunk buffers shifted to local step `off` (multiple of 4) of the current storage chunk
+SxDeviceArrays view_at(const smashx_plan* p, int off) {
+    SxDeviceArrays B = p->A;
+    const size_t q = (size_t)(off / 4);
+    B.qtT = p->A.qtT + q * p->npad * 4;
+    if (p->A.hrT) B.hrT = p->A.hrT + q * p->npad * 4;
+    B.xT = p->A.xT + q * p->A.nx * 4;
+    if (p->A.tape_hp) B.tape_hp = p->A.tape_hp + (size_t)off * p->npad;
+    if (p->A.tape_hft) B.tape_hft = p->A.tape_hft + (size_t)off * p->npad;
+    if (p->A.tape_hi) B.tape_hi = p->A.tape_hi + (size_t)off * p->npad;
+    if (p->A.tape_hst) B.tape_hst = p->A.tape_hst + (size_t)off * p->npad;
+    return B;
+}
+
 template <int ST>
-void launch_vert_fwd(smashx_plan* p, bool tape, int t0, int T) {
+void launch_vert_fwd(smashx_plan* p, const SxDeviceArrays& B, bool tape, int t0, int T) {
     const dim3 grid(p->npad / SX_VBLOCK), block(SX_VBLOCK);
-    p->mark_begin(0);
-    if (tape) hipLaunchKernelGGL((sx_k_vert_fwd<ST, true>), grid, block, 0, p->stream, p->A, t0, T);
-    else      hipLaunchKernelGGL((sx_k_vert_fwd<ST, false>), grid, block, 0, p->stream, p->A, t0, T);
+    p->mark_begin(0, p->stream);
+    if (tape) hipLaunchKernelGGL((sx_k_vert_fwd<ST, true>), grid, block, 0, p->stream, B, t0, T);
+    else      hipLaunchKernelGGL((sx_k_vert_fwd<ST, false>), grid, block, 0, p->stream, B, t0, T);
     p->mark_end();
 }
-void vert_fwd(smashx_plan* p, bool tape, int t0, int T) {
+void vert_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
+    const SxDeviceArrays B = view_at(p, off);
     switch (p->st) {
-        case 1: launch_vert_fwd<1>(p, tape, t0, T); break;
-        case 2: launch_vert_fwd<2>(p, tape, t0, T); break;
-        case 3: launch_vert_fwd<3>(p, tape, t0, T); break;
-        default: launch_vert_fwd<4>(p, tape, t0, T); break;
+        case 1: launch_vert_fwd<1>(p, B, tape, t0, T); break;
+        case 2: launch_vert_fwd<2>(p, B, tape, t0, T); break;
+        case 3: launch_vert_fwd<3>(p, B, tape, t0, T); break;
+        default: launch_vert_fwd<4>(p, B, tape, t0, T); break;
     }
 }
-void vert_adj(smashx_plan* p, int t0, int T) {
+void vert_adj(smashx_plan* p, int off, int t0, int T) {
+    const SxDeviceArrays B = view_at(p, off);
     const dim3 grid(p->npad / SX_VBLOCK), block(SX_VBLOCK);
-    p->mark_begin(3);
+    p->mark_begin(3, p->stream);
     switch (p->st) {
-        case 1: hipLaunchKernelGGL((sx_k_vert_adj<1>), grid, block, 0, p->stream, p->A, t0, T); break;
-        case 2: hipLaunchKernelGGL((sx_k_vert_adj<2>), grid, block, 0, p->stream, p->A, t0, T); break;
-        case 3: hipLaunchKernelGGL((sx_k_vert_adj<3>), grid, block, 0, p->stream, p->A, t0, T); break;
-        default: hipLaunchKernelGGL((sx_k_vert_adj<4>), grid, block, 0, p->stream, p->A, t0, T); break;
+        case 1: hipLaunchKernelGGL((sx_k_vert_adj<1>), grid, block, 0, p->stream, B, t0, T); break;
+        case 2: hipLaunchKernelGGL((sx_k_vert_adj<2>), grid, block, 0, p->stream, B, t0, T); break;
+        case 3: hipLaunchKernelGGL((sx_k_vert_adj<3>), grid, block, 0, p->stream, B, t0, T); break;
+        default: hipLaunchKernelGGL((sx_k_vert_adj<4>), grid, block, 0, p->stream, B, t0, T); break;
     }
     p->mark_end();
 }
-void route_fwd(smashx_plan* p, bool tape, int t0, int T) {
+void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
+    const SxDeviceArrays B = view_at(p, off);
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
     for (int r = 0; r < p->sch.nrounds; ++r) {
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
-        p->mark_begin(1);
-        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true>), dim3(ngr), dim3(p->M), lds, p->stream, p->A, g0, t0, T);
-        else      hipLaunchKernelGGL((sx_k_route_fwd<false>), dim3(ngr), dim3(p->M), lds, p->stream, p->A, g0, t0, T);
+        p->mark_begin(1, p->stream_r);
+        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, t0, T);
+        else      hipLaunchKernelGGL((sx_k_route_fwd<false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, t0, T);
         p->mark_end();
     }
 }
-void route_adj(smashx_plan* p, int t0, int T) {
+void route_adj(smashx_plan* p, int off, int t0, int T) {
+    const SxDeviceArrays B = view_at(p, off);
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
     for (int r = p->sch.nrounds - 1; r >= 0; --r) {
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
-        p->mark_begin(2);
-        hipLaunchKernelGGL(sx_k_route_adj, dim3(ngr), dim3(p->M), lds, p->stream, p->A, g0, t0, T);
+        p->mark_begin(2, p->stream_r);
+        hipLaunchKernelGGL(sx_k_route_adj, dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, t0, T);
         p->mark_end();
     }
 }
@@ -256,24 +284,28 @@ SxCostArgs cost_args(smashx_plan* p, float jobs_b) {
 int run_cost(smashx_plan* p, int adjoint, float cost_b) {
     if (p->ng == 0) return 0;
     SxCostArgs C = cost_args(p, cost_b);
-    p->mark_begin(4);
-    hipLaunchKernelGGL(sx_k_cost_sums, dim3(p->ng), dim3(64), 0, p->stream, C);
-    hipLaunchKernelGGL(sx_k_cost_final, dim3(1), dim3(1), 0, p->stream, C, adjoint);
+    p->mark_begin(4, p->stream_r);
+    hipLaunchKernelGGL(sx_k_cost_sums, dim3(p->ng), dim3(64), 0, p->stream_r, C);
+    hipLaunchKernelGGL(sx_k_cost_final, dim3(1), dim3(1), 0, p->stream_r, C, adjoint);
     if (adjoint) {
         const dim3 b(256), g1((p->nt + 255) / 256, p->ng), g2((p->nt + 255) / 256, p->ngc);
-        hipLaunchKernelGGL(sx_k_cost_seeds, g1, b, 0, p->stream, C);
-        hipLaunchKernelGGL(sx_k_cost_cellseeds, g2, b, 0, p->stream, C);
+        hipLaunchKernelGGL(sx_k_cost_seeds, g1, b, 0, p->stream_r, C);
+        hipLaunchKernelGGL(sx_k_cost_cellseeds, g2, b, 0, p->stream_r, C);
     }
     p->mark_end();
     return 0;
 }
 
-int restore_states(smashx_plan* p, float* const src[5]) {
-    float* dst[5] = {p->A.hi, p->A.hp, p->A.hft, p->A.hst, p->A.hlr};
+// the reservoir levels live on the V stream, the routing store hlr (index 4) on the R stream
+int copy_states(smashx_plan* p, float* const dst[5], float* const src[5]) {
     for (int i = 0; i < 5; ++i)
         if (uses_state(p->st, kStateFields[i]))
-            HIPCHK(hipMemcpyAsync(dst[i], src[i], (size_t)p->npad * 4, hipMemcpyDeviceToDevice, p->stream));
+            HIPCHK(hipMemcpyAsync(dst[i], src[i], (size_t)p->npad * 4, hipMemcpyDeviceToDevice, i == 4 ? p->stream_r : p->stream));
     return 0;
+}
+int restore_states(smashx_plan* p, float* const src[5]) {
+    float* dst[5] = {p->A.hi, p->A.hp, p->A.hft, p->A.hst, p->A.hlr};
+    return copy_states(p, dst, src);
 }
 
 }  // namespace
@@ -303,14 +335,14 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     p->cfg = *cfg;
     if (set_device(p)) { delete p; return SMASHX_E_HIP; }
     p->M = cfg->group_size > 0 ? cfg->group_size : 512;
-    if (p->M % 64 != 0 || p->M > 1024 || p->M < 64) { delete p; return fail(SMASHX_E_ARG, "group_size must be a multiple of 64 in [64, 1024]"); }
+    if (p->M % 64 != 0 || p->M > SX_MAXGROUP || p->M < 64) { delete p; return fail(SMASHX_E_ARG, "group_size must be a multiple of 64 in [64, 512]"); }
     const int rc0 = sx_build_schedule(cfg->nrow, cfg->ncol, mesh->flwdir, mesh->active_cell, cfg->ng, mesh->gauge_pos, p->M, p->sch);
     if (rc0 != 0) { std::string e = p->sch.error; delete p; return fail(rc0 == -5 ? SMASHX_E_MESH : SMASHX_E_ARG, e); }
     p->n = p->sch.n; p->npad = (p->n + SX_VBLOCK - 1) / SX_VBLOCK * SX_VBLOCK;
     p->nt = cfg->nt; p->ng = cfg->ng; p->st = cfg->structure; p->n2 = (long)cfg->nrow * cfg->ncol;
     int rc = 0;
 #define TRY(x) do { rc = (x); if (rc) { smashx_plan_destroy(p); return rc; } } while (0)
-    if (hipStreamCreate(&p->stream) != hipSuccess) { delete p; return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
+    if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->stream_r) != hipSuccess) { delete p; return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
     (void)hipEventCreate(&p->ev0); (void)hipEventCreate(&p->ev1);
     SxDeviceArrays& A = p->A;
     A.n = p->n; A.npad = p->npad; A.nt = p->nt; A.dt = cfg->dt; A.dx = cfg->dx; A.Tc = 0;
@@ -392,11 +424,13 @@ int smashx_plan_destroy(smashx_plan* p) {
     if (!p) return 0;
     (void)set_device(p);
     if (p->stream) (void)hipStreamSynchronize(p->stream);
+    if (p->stream_r) (void)hipStreamSynchronize(p->stream_r);
     for (void* q : p->allocs) (void)hipFree(q);
     for (hipEvent_t e : p->pool) (void)hipEventDestroy(e);
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->stream) (void)hipStreamDestroy(p->stream);
+    if (p->stream_r) (void)hipStreamDestroy(p->stream_r);
     delete p;
     return 0;
 }
@@ -522,47 +556,82 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     int rc = set_device(p); if (rc) return rc;
     if ((rc = ensure_chunk_buffers(p, adjoint != 0))) return rc;
     p->launches.clear(); p->pool_used = 0;
-    HIPCHK(hipEventRecord(p->ev0, p->stream));
+    hipStream_t sV = p->stream, sR = p->stream_r;
+    HIPCHK(hipEventRecord(p->ev0, sV));
+    HIPCHK(hipStreamWaitEvent(sR, p->ev0, 0));
     if ((rc = restore_states(p, p->st0))) return rc;
     const int C = p->nchunks;
+    auto nsub_of = [&](int T) { return (T + p->Tp - 1) / p->Tp; };
+    // forward over one storage chunk: V(j) on the V stream, R(j) on the R stream as soon as V(j) is done
+    auto forward_chunk = [&](int c, bool tape) -> int {
+        const int t0c = c * p->Tc, Tcur = chunk_len(p, c);
+        for (int jb = 0; jb < nsub_of(Tcur); ++jb) {
+            const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
+            vert_fwd(p, off, tape, t0c + off, T);
+            hipEvent_t e = p->event();
+            HIPCHK(hipEventRecord(e, sV));
+            HIPCHK(hipStreamWaitEvent(sR, e, 0));
+            route_fwd(p, off, tape, t0c + off, T);
+        }
+        return 0;
+    };
+    // before a storage chunk's buffers are overwritten, the V stream must see the R stream drained
+    auto v_waits_r = [&]() -> int {
+        hipEvent_t e = p->event();
+        HIPCHK(hipEventRecord(e, sR));
+        HIPCHK(hipStreamWaitEvent(sV, e, 0));
+        return 0;
+    };
     if (!adjoint) {
         for (int c = 0; c < C; ++c) {
-            const int t0 = c * p->Tc, T = chunk_len(p, c);
-            vert_fwd(p, false, t0, T);
-            route_fwd(p, false, t0, T);
+            if (c > 0 && (rc = v_waits_r())) return rc;
+            if ((rc = forward_chunk(c, false))) return rc;
         }
         if ((rc = run_cost(p, 0, 0.f))) return rc;
     } else {
         for (int c = 0; c < C; ++c) {
-            const int t0 = c * p->Tc, T = chunk_len(p, c);
             if (C > 1) {
-                float* src[5] = {p->A.hi, p->A.hp, p->A.hft, p->A.hst, p->A.hlr};
-                for (int i = 0; i < 5; ++i)
-                    if (uses_state(p->st, kStateFields[i]))
-                        HIPCHK(hipMemcpyAsync(p->ckpt + ((size_t)c * 5 + i) * p->npad, src[i], (size_t)p->npad * 4, hipMemcpyDeviceToDevice, p->stream));
+                float* cur[5] = {p->A.hi, p->A.hp, p->A.hft, p->A.hst, p->A.hlr};
+                float* dst[5];
+                for (int i = 0; i < 5; ++i) dst[i] = p->ckpt + ((size_t)c * 5 + i) * p->npad;
+                if (c > 0 && (rc = v_waits_r())) return rc;
+                if ((rc = copy_states(p, dst, cur))) return rc;
             }
-            vert_fwd(p, C == 1, t0, T);
-            route_fwd(p, C == 1, t0, T);
+            if ((rc = forward_chunk(c, C == 1))) return rc;
         }
         if ((rc = run_cost(p, 1, cost_b))) return rc;
-        float* g[11] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.lr_b, p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b, p->A.hlr_b};
-        for (auto q : g) HIPCHK(hipMemsetAsync(q, 0, (size_t)p->npad * 4, p->stream));
-        if (p->ng == 0) HIPCHK(hipMemsetAsync(p->A.qgb, 0, (size_t)std::max(p->ngc, 1) * p->nt * 4, p->stream));
+        float* gv[9] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b};
+        for (auto q : gv) HIPCHK(hipMemsetAsync(q, 0, (size_t)p->npad * 4, sV));
+        HIPCHK(hipMemsetAsync(p->A.lr_b, 0, (size_t)p->npad * 4, sR));
+        HIPCHK(hipMemsetAsync(p->A.hlr_b, 0, (size_t)p->npad * 4, sR));
+        if (p->ng == 0) HIPCHK(hipMemsetAsync(p->A.qgb, 0, (size_t)std::max(p->ngc, 1) * p->nt * 4, sR));
         for (int c = C - 1; c >= 0; --c) {
-            const int t0 = c * p->Tc, T = chunk_len(p, c);
-            if (C > 1) {
+            const int t0c = c * p->Tc, Tcur = chunk_len(p, c);
+            if (C > 1) {   // recompute this storage chunk with the tape on
                 float* src[5];
                 for (int i = 0; i < 5; ++i) src[i] = p->ckpt + ((size_t)c * 5 + i) * p->npad;
+                if ((rc = v_waits_r())) return rc;
                 if ((rc = restore_states(p, src))) return rc;
-                vert_fwd(p, true, t0, T);
-                route_fwd(p, true, t0, T);
+                if ((rc = forward_chunk(c, true))) return rc;
             }
-            route_adj(p, t0, T);
-            vert_adj(p, t0, T);
+            for (int jb = nsub_of(Tcur) - 1; jb >= 0; --jb) {
+                const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
+                route_adj(p, off, t0c + off, T);
+                hipEvent_t e = p->event();
+                HIPCHK(hipEventRecord(e, sR));
+                HIPCHK(hipStreamWaitEvent(sV, e, 0));
+                vert_adj(p, off, t0c + off, T);
+            }
         }
     }
-    HIPCHK(hipEventRecord(p->ev1, p->stream));
-    HIPCHK(hipStreamSynchronize(p->stream));
+    {
+        hipEvent_t e = p->event();
+        HIPCHK(hipEventRecord(e, sR));
+        HIPCHK(hipStreamWaitEvent(sV, e, 0));
+    }
+    HIPCHK(hipEventRecord(p->ev1, sV));
+    HIPCHK(hipStreamSynchronize(sV));
+    HIPCHK(hipStreamSynchronize(sR));
     HIPCHK(hipGetLastError());
     // timing
     smashx_timing& tm = p->timing;
@@ -579,7 +648,7 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
             default: tm.cost_ms += ms; break;
         }
     }
-    tm.n_chunks = p->nchunks; tm.chunk_steps = p->Tc; tm.n_rounds = p->sch.nrounds; tm.n_groups = p->sch.ngroups;
+    tm.n_chunks = p->nchunks; tm.chunk_steps = p->Tc; tm.pipe_steps = p->Tp; tm.n_rounds = p->sch.nrounds; tm.n_groups = p->sch.ngroups;
     tm.device_bytes = p->bytes;
     p->last_adjoint = adjoint;
     return 0;

@@ -133,9 +133,19 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
 // Slot j at stage s handles time block (w - s) in super-step w; its children (stage s-1) published that
 // block in super-step w-1.  upstream_discharge + linear_routing + the q update of
 // md_forward_structure.f90:150-156, in the reference's operation order.
+//
+// Global memory is kept off the critical path: super-steps are grouped by SX_MU; the inputs of macro-step
+// m+1 are requested at the start of macro-step m and the results of macro-step m are stored at the start
+// of macro-step m+1 (before the next requests), so the one vmcnt wait per macro-step only ever meets
+// operations that have been in flight for SX_MU super-steps.  The exchange between super-steps is LDS only.
 // ------------------------------------------------------------------------------------------------
+#ifndef SX_MU
+#define SX_MU 4
+#endif
+#define SX_MAXGROUP 512   // largest routing workgroup (group_size); 8 waves, registers are not the limit
+
 template <bool TAPE>
-__global__ void sx_k_route_fwd(SxDeviceArrays A, int g0, int t0, int T) {
+__global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, int g0, int t0, int T) {
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];   // [2][blockDim.x]
     const int g = g0 + blockIdx.x;
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
@@ -167,55 +177,85 @@ __global__ void sx_k_route_fwd(SxDeviceArrays A, int g0, int t0, int T) {
     const size_t sstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
     float4* x4 = reinterpret_cast<float4*>(A.xT);
     float4* hr4 = reinterpret_cast<float4*>(A.hrT);
-    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (valid && stage == 0 && nb > 0) nxt = src[0];   // first block of stage-0 slots
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const int nsuper = nb + dmax;
-    for (int w = 0; w < nsuper; ++w) {
-        const int tb = w - stage;
-        const bool act = valid && tb >= 0 && tb < nb;
-        const float4 cur4 = nxt;
-        // prefetch the block this slot handles in the next super-step
-        if (valid && tb + 1 >= 0 && tb + 1 < nb) nxt = src[(size_t)(tb + 1) * sstride];
-        float4* pub = sx_lds + (size_t)(w & 1) * M;
-        const float4* prev = sx_lds + (size_t)((w + 1) & 1) * M;
-        if (act) {
-            const int tl = tb * SX_BT;           // first step of the block, chunk-local
-            if (cell >= 0) {
-                float s[SX_BT] = {0.f, 0.f, 0.f, 0.f};
-                for (int c = 0; c < ccount; ++c) {
-                    const float4 v = prev[cstart + c];
-                    s[0] = s[0] + v.x; s[1] = s[1] + v.y; s[2] = s[2] + v.z; s[3] = s[3] + v.w;
-                }
-                const float qt[SX_BT] = {cur4.x, cur4.y, cur4.z, cur4.w};
-                float q[SX_BT], hr[SX_BT];
+    float4 nxt[SX_MU], outq[SX_MU], outh[SX_MU];
 #pragma unroll
-                for (int i = 0; i < SX_BT; ++i) {
-                    q[i] = 0.f; hr[i] = 0.f;
-                    if (tl + i < T) {
-                        float qup = 0.f;
-                        if (hasup) qup = sx_div(s[i] * dt, dden);
-                        const float hr_imd = hlr + qup;
-                        hlr = hr_imd * a;
-                        const float qrout = hr_imd - hlr;
-                        q[i] = sx_div((qt[i] + qrout * f) * dx * dx * 0.001f, ddt);
-                        hr[i] = hr_imd;
+    for (int u = 0; u < SX_MU; ++u) {
+        const int tb = u - stage;
+        nxt[u] = (valid && tb >= 0 && tb < nb) ? src[(size_t)tb * sstride] : zero4;
+        outq[u] = zero4; outh[u] = zero4;
+    }
+    const int nsuper = nb + dmax;
+    const int nmacro = (nsuper + SX_MU - 1) / SX_MU;
+    for (int mw = 0; mw <= nmacro; ++mw) {
+        float4 cur[SX_MU];
+#pragma unroll
+        for (int u = 0; u < SX_MU; ++u) cur[u] = nxt[u];
+        // results of the previous macro-step leave now
+        if (mw > 0 && cell >= 0) {
+#pragma unroll
+            for (int u = 0; u < SX_MU; ++u) {
+                const int tb = SX_MU * (mw - 1) + u - stage;
+                if (tb >= 0 && tb < nb) {
+                    if (xout >= 0) x4[(size_t)tb * A.nx + xout] = outq[u];
+                    if (TAPE) hr4[(size_t)tb * A.npad + cell] = outh[u];
+                    if (gid >= 0) {
+                        const float qv[4] = {outq[u].x, outq[u].y, outq[u].z, outq[u].w};
+#pragma unroll
+                        for (int i = 0; i < SX_BT; ++i)
+                            if (tb * SX_BT + i < T) A.qg[(size_t)gid * A.nt + t0 + tb * SX_BT + i] = qv[i];
                     }
                 }
-                const float4 q4 = make_float4(q[0], q[1], q[2], q[3]);
-                pub[j] = q4;
-                if (xout >= 0) x4[(size_t)tb * A.nx + xout] = q4;
-                if (TAPE) hr4[(size_t)tb * A.npad + cell] = make_float4(hr[0], hr[1], hr[2], hr[3]);
-                if (gid >= 0) {
-#pragma unroll
-                    for (int i = 0; i < SX_BT; ++i)
-                        if (tl + i < T) A.qg[(size_t)gid * A.nt + t0 + tl + i] = q[i];
-                }
-            } else {
-                pub[j] = cur4;
             }
         }
-        sx_lds_barrier();
+        if (mw == nmacro) break;
+        // inputs of the next macro-step are requested now
+#pragma unroll
+        for (int u = 0; u < SX_MU; ++u) {
+            const int tb = SX_MU * (mw + 1) + u - stage;
+            nxt[u] = (valid && tb >= 0 && tb < nb) ? src[(size_t)tb * sstride] : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < SX_MU; ++u) {
+            const int w = SX_MU * mw + u;
+            const int tb = w - stage;
+            const bool act = valid && tb >= 0 && tb < nb;
+            float4* pub = sx_lds + (size_t)(w & 1) * M;
+            const float4* prev = sx_lds + (size_t)((w + 1) & 1) * M;
+            if (act) {
+                const int tl = tb * SX_BT;           // first step of the block, chunk-local
+                if (cell >= 0) {
+                    float s[SX_BT] = {0.f, 0.f, 0.f, 0.f};
+                    for (int c = 0; c < ccount; ++c) {
+                        const float4 v = prev[cstart + c];
+                        s[0] = s[0] + v.x; s[1] = s[1] + v.y; s[2] = s[2] + v.z; s[3] = s[3] + v.w;
+                    }
+                    const float qt[SX_BT] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+                    float q[SX_BT], hr[SX_BT];
+#pragma unroll
+                    for (int i = 0; i < SX_BT; ++i) {
+                        q[i] = 0.f; hr[i] = 0.f;
+                        if (tl + i < T) {
+                            float qup = 0.f;
+                            if (hasup) qup = sx_div(s[i] * dt, dden);
+                            const float hr_imd = hlr + qup;
+                            hlr = hr_imd * a;
+                            const float qrout = hr_imd - hlr;
+                            q[i] = sx_div((qt[i] + qrout * f) * dx * dx * 0.001f, ddt);
+                            hr[i] = hr_imd;
+                        }
+                    }
+                    const float4 q4 = make_float4(q[0], q[1], q[2], q[3]);
+                    pub[j] = q4;
+                    outq[u] = q4;
+                    outh[u] = make_float4(hr[0], hr[1], hr[2], hr[3]);
+                } else {
+                    pub[j] = cur[u];
+                }
+            }
+            sx_lds_barrier();
+        }
     }
     if (valid && cell >= 0) A.hlr[cell] = hlr;
 }
@@ -224,8 +264,9 @@ __global__ void sx_k_route_fwd(SxDeviceArrays A, int g0, int t0, int T) {
 // routing adjoint: same groups, roots first, time descending.  Reverse of the q update, LINEAR_ROUTING_B
 // (forward_db.f90:6628-6652) and UPSTREAM_DISCHARGE_B (:6520-6564), as in GR_x_FORWARD_B :8649-8672.
 // Reads hrT (hr_imd of the recomputed forward) and the gauge seeds; writes qt_b over qtT.
+// Same macro-step staging of global memory as the forward kernel.
 // ------------------------------------------------------------------------------------------------
-__global__ void sx_k_route_adj(SxDeviceArrays A, int g0, int t0, int T) {
+__global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, int g0, int t0, int T) {
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];
     const int g = g0 + blockIdx.x;
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
@@ -256,49 +297,88 @@ __global__ void sx_k_route_adj(SxDeviceArrays A, int g0, int t0, int T) {
     float4* x4 = reinterpret_cast<float4*>(A.xT);
     const float4* hr4p = reinterpret_cast<const float4*>(A.hrT);
     float4* qt4 = reinterpret_cast<float4*>(A.qtT);
-    const int nsuper = nb + dmax;
-    for (int w = 0; w < nsuper; ++w) {
-        const int tbr = w - rstage;
-        const bool act = valid && tbr >= 0 && tbr < nb;
-        float4* pub = sx_lds + (size_t)(w & 1) * M;
-        const float4* prev = sx_lds + (size_t)((w + 1) & 1) * M;
-        if (act) {
-            const int tb = nb - 1 - tbr;
-            const int tl = tb * SX_BT;
-            float4 in4 = make_float4(0.f, 0.f, 0.f, 0.f);   // contribution of the downstream cell
-            if (par >= 0) in4 = prev[par];
-            else if (cell >= 0 && xout >= 0) in4 = x4[(size_t)tb * A.nx + xout];
-            if (cell >= 0) {
-                const float4 hr4 = hr4p[(size_t)tb * A.npad + cell];
-                const float hrv[SX_BT] = {hr4.x, hr4.y, hr4.z, hr4.w};
-                const float inv[SX_BT] = {in4.x, in4.y, in4.z, in4.w};
-                float pb[SX_BT], qtb[SX_BT];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool root_in = (cell >= 0 && par < 0 && xout >= 0);   // subtree root fed by an exchange series
+
+    float4 nhr[SX_MU], nin[SX_MU], outq[SX_MU];
 #pragma unroll
-                for (int i = SX_BT - 1; i >= 0; --i) {
-                    pb[i] = 0.f; qtb[i] = 0.f;
-                    if (tl + i < T) {
-                        float q_b = 0.f;
-                        if (gid >= 0) q_b = q_b + A.qgb[(size_t)gid * A.nt + t0 + tl + i];
-                        q_b = q_b + inv[i];
-                        const float temp_b = sx_div((dx * dx) * 0.001f * q_b, ddt);
-                        const float qrout_b = f * temp_b;
-                        hr_b = hr_b - qrout_b;
-                        const float hr_imd_b = qrout_b + a * hr_b;
-                        const float arg1_b = a * hrv[i] * hr_b;
-                        lr_b = lr_b + sx_div(dt * arg1_b, dlr);
-                        hr_b = hr_imd_b;
-                        if (hasup) pb[i] = sx_div(dt * hr_imd_b, dden);
-                        qtb[i] = temp_b;
-                    }
+    for (int u = 0; u < SX_MU; ++u) {
+        const int tbr = u - rstage;
+        const int tb = nb - 1 - tbr;
+        const bool ok = valid && tbr >= 0 && tbr < nb;
+        nhr[u] = (ok && cell >= 0) ? hr4p[(size_t)tb * A.npad + cell] : zero4;
+        nin[u] = (ok && root_in) ? x4[(size_t)tb * A.nx + xout] : zero4;
+        outq[u] = zero4;
+    }
+    const int nsuper = nb + dmax;
+    const int nmacro = (nsuper + SX_MU - 1) / SX_MU;
+    for (int mw = 0; mw <= nmacro; ++mw) {
+        float4 chr[SX_MU], cin[SX_MU];
+#pragma unroll
+        for (int u = 0; u < SX_MU; ++u) { chr[u] = nhr[u]; cin[u] = nin[u]; }
+        if (mw > 0 && valid) {
+#pragma unroll
+            for (int u = 0; u < SX_MU; ++u) {
+                const int tbr = SX_MU * (mw - 1) + u - rstage;
+                if (tbr >= 0 && tbr < nb) {
+                    const int tb = nb - 1 - tbr;
+                    if (cell >= 0) qt4[(size_t)tb * A.npad + cell] = outq[u];
+                    else x4[(size_t)tb * A.nx + xin] = outq[u];
                 }
-                pub[j] = make_float4(pb[0], pb[1], pb[2], pb[3]);
-                qt4[(size_t)tb * A.npad + cell] = make_float4(qtb[0], qtb[1], qtb[2], qtb[3]);
-            } else {
-                // inlet pseudo-cell: hand the receiver's contribution to the subtree rooted upstream
-                x4[(size_t)tb * A.nx + xin] = in4;
             }
         }
-        sx_lds_barrier();
+        if (mw == nmacro) break;
+#pragma unroll
+        for (int u = 0; u < SX_MU; ++u) {
+            const int tbr = SX_MU * (mw + 1) + u - rstage;
+            const int tb = nb - 1 - tbr;
+            const bool ok = valid && tbr >= 0 && tbr < nb;
+            nhr[u] = (ok && cell >= 0) ? hr4p[(size_t)tb * A.npad + cell] : zero4;
+            nin[u] = (ok && root_in) ? x4[(size_t)tb * A.nx + xout] : zero4;
+        }
+#pragma unroll
+        for (int u = 0; u < SX_MU; ++u) {
+            const int w = SX_MU * mw + u;
+            const int tbr = w - rstage;
+            const bool act = valid && tbr >= 0 && tbr < nb;
+            float4* pub = sx_lds + (size_t)(w & 1) * M;
+            const float4* prev = sx_lds + (size_t)((w + 1) & 1) * M;
+            if (act) {
+                const int tb = nb - 1 - tbr;
+                const int tl = tb * SX_BT;
+                float4 in4 = cin[u];                 // contribution of the downstream cell
+                if (par >= 0) in4 = prev[par];
+                if (cell >= 0) {
+                    const float hrv[SX_BT] = {chr[u].x, chr[u].y, chr[u].z, chr[u].w};
+                    const float inv[SX_BT] = {in4.x, in4.y, in4.z, in4.w};
+                    float pb[SX_BT], qtb[SX_BT];
+#pragma unroll
+                    for (int i = SX_BT - 1; i >= 0; --i) {
+                        pb[i] = 0.f; qtb[i] = 0.f;
+                        if (tl + i < T) {
+                            float q_b = 0.f;
+                            if (gid >= 0) q_b = q_b + A.qgb[(size_t)gid * A.nt + t0 + tl + i];
+                            q_b = q_b + inv[i];
+                            const float temp_b = sx_div((dx * dx) * 0.001f * q_b, ddt);
+                            const float qrout_b = f * temp_b;
+                            hr_b = hr_b - qrout_b;
+                            const float hr_imd_b = qrout_b + a * hr_b;
+                            const float arg1_b = a * hrv[i] * hr_b;
+                            lr_b = lr_b + sx_div(dt * arg1_b, dlr);
+                            hr_b = hr_imd_b;
+                            if (hasup) pb[i] = sx_div(dt * hr_imd_b, dden);
+                            qtb[i] = temp_b;
+                        }
+                    }
+                    pub[j] = make_float4(pb[0], pb[1], pb[2], pb[3]);
+                    outq[u] = make_float4(qtb[0], qtb[1], qtb[2], qtb[3]);
+                } else {
+                    // inlet pseudo-cell: hand the receiver's contribution to the subtree rooted upstream
+                    outq[u] = in4;
+                }
+            }
+            sx_lds_barrier();
+        }
     }
     if (valid && cell >= 0) { A.hlr_b[cell] = hr_b; A.lr_b[cell] = lr_b; }
 }

@@ -38,14 +38,14 @@ def _i32(a):
 class Solver:
     """A libsmashx plan: routing schedule + HBM-resident forcing for one (setup, mesh, input_data)."""
 
-    def __init__(self, setup, mesh, *, chunk_steps: int = 0, group_size: int = 0, device: int = -1):
+    def __init__(self, setup, mesh, *, chunk_steps: int = 0, pipe_steps: int = 0, group_size: int = 0, device: int = -1):
         L = _lib.lib()
         self.nrow, self.ncol, self.nt, self.ng = mesh.nrow, mesh.ncol, setup.ntime_step, mesh.ng
         self.structure = setup.structure
         if setup.structure not in STRUCTURES:
             raise _lib.SmashxError(_lib.E_UNSUPPORTED, f"structure {setup.structure!r} is not on the hot path yet")
         cfg = _lib.Config(STRUCTURES[setup.structure], mesh.nrow, mesh.ncol, setup.ntime_step, mesh.ng, setup.dt,
-                          mesh.dx, chunk_steps, group_size, device)
+                          mesh.dx, chunk_steps, pipe_steps, group_size, device)
         self._keep = [_i32(mesh.flwdir), _i32(mesh.flwacc), _i32(mesh.active_cell), _i32(mesh.path),
                       _i32(np.asarray(mesh.gauge_pos).reshape(-1, 2)), np.ascontiguousarray(mesh.area, np.float32)]
         m = _lib.Mesh(*[_ptr(a) for a in self._keep])

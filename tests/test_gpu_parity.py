@@ -93,13 +93,13 @@ def test_adjoint_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask"])
-@pytest.mark.parametrize("chunk,group", [(16, 64), (32, 128), (48, 512)])
-def test_chunking_and_grouping_do_not_change_results(name, chunk, group):
-    """Time-chunk checkpointing and the routing partition only reorder independent work: results must be
-    bit-identical to the single-chunk default."""
+@pytest.mark.parametrize("chunk,pipe,group", [(16, 0, 64), (32, 16, 128), (48, 32, 512), (0, 16, 256)])
+def test_chunking_and_grouping_do_not_change_results(name, chunk, pipe, group):
+    """Time-chunk checkpointing, the two-stream chunk pipeline and the routing partition only reorder
+    independent work: results must be bit-identical to the single-chunk default."""
     g = gu.load(name)
     ref = _run_adjoint(g)
-    alt = _run_adjoint(g, chunk_steps=chunk, group_size=group)
+    alt = _run_adjoint(g, chunk_steps=chunk, pipe_steps=pipe, group_size=group)
     assert np.array_equal(ref[2].qsim, alt[2].qsim)
     assert ref[2].cost == alt[2].cost
     for k in gu.STRUCT_PARAMS[g.structure]:
