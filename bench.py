@@ -28,6 +28,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 
+def pmc_traffic(kernel, cellsteps_per_launch):
+    """HBM bytes per launch of `kernel` from the PMC counters.  bench.py cannot collect PMC itself: the values
+    come from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command
+    (tools/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950), stored per
+    cell-step in profiles/r*_pmc_traffic.json and scaled to this run's launch size.  None if never measured."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1])).get(kernel)
+        return d["hbm_bytes_per_cellstep_corrected"] * cellsteps_per_launch if d else None
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,7 +205,7 @@ def main():
                        "routing_rounds": int(tm["n_rounds"]), "routing_groups": int(tm["n_groups"]),
                        "parallelism": f"tiles{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, per_launch_steps) if a.structure == "gr-b" else None,
                          "avg_launch_ms": avg_ms, "launches_per_step": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "sweep_frac": sweep_bytes / (tm["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,

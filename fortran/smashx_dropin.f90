@@ -1,0 +1,390 @@
+!  smashx_dropin.f90 -- ISO_C_BINDING shim that makes libsmashx a drop-in for the reference's differentiated
+!  core.  It defines the two EXTERNAL procedures the reference's wrapped boundary forwards to through an
+!  implicit interface,
+!
+!      base_forward      (replaces smash/solver/forward/forward.f90:1-80)
+!      base_forward_b    (replaces smash/solver/forward/forward_db.f90:10648-10936)
+!
+!  with the same argument lists, so mw_forward::forward / forward_b (mw_forward.f90:18-68), and every caller
+!  above them -- mw_optimize::optimize_lbfgsb (mw_optimize.f90:567,610,670), the f90wrap Python API -- run on
+!  the GPU unchanged.  Compiled against the reference's own derived-type modules (read in place, never
+!  copied) by oracle/ref/build_ref.sh into oracle/_ref/libsmash_dropin.so.  This file is ours.
+!
+!  What the shim does: marshals the allocatable components of the derived types to the flat C ABI of
+!  include/smashx.h with c_loc, converts the 1-based mesh%path / mesh%gauge_pos to 0-based copies, keeps one
+!  plan (routing schedule + HBM-resident forcing) alive across calls for as long as the same forcing arrays
+!  are passed, and copies results back into output%qsim / output%cost* / output%fstates / *_b.
+!  The reference has no error channel; on a libsmashx error the shim prints the message and stops.
+
+module smashx_c
+
+    use iso_c_binding
+
+    implicit none
+
+    integer(c_int), parameter :: SX_GNP = 16, SX_GNS = 8
+
+    type, bind(C) :: smashx_config
+        integer(c_int) :: structure, nrow, ncol, nt, ng
+        real(c_float) :: dt, dx
+        integer(c_int) :: chunk_steps, pipe_steps, group_size, device
+    end type smashx_config
+
+    type, bind(C) :: smashx_mesh
+        type(c_ptr) :: flwdir, flwacc, active_cell, path, gauge_pos, area
+    end type smashx_mesh
+
+    type, bind(C) :: smashx_options
+        integer(c_int) :: denormalize_forward, optimize_start_step, njf
+        integer(c_int) :: jobs_fun(8)
+        real(c_float) :: wjobs_fun(8)
+        integer(c_int) :: njr
+        integer(c_int) :: jreg_fun(4)
+        real(c_float) :: wjreg_fun(4)
+        real(c_float) :: wjreg
+        integer(c_int) :: optim_parameters(SX_GNP), optim_states(SX_GNS)
+        real(c_float) :: lb_parameters(SX_GNP), ub_parameters(SX_GNP), lb_states(SX_GNS), ub_states(SX_GNS)
+        type(c_ptr) :: wgauge
+    end type smashx_options
+
+    type, bind(C) :: smashx_parameters
+        type(c_ptr) :: f(SX_GNP)
+    end type smashx_parameters
+
+    type, bind(C) :: smashx_states
+        type(c_ptr) :: f(SX_GNS)
+    end type smashx_states
+
+    type, bind(C) :: smashx_costs
+        real(c_float) :: cost, cost_jobs, cost_jreg
+    end type smashx_costs
+
+    interface
+        function smashx_last_error() bind(C, name="smashx_last_error") result(p)
+            import :: c_ptr
+            type(c_ptr) :: p
+        end function
+        function smashx_plan_create(cfg, mesh, plan) bind(C, name="smashx_plan_create") result(rc)
+            import :: c_int, c_ptr, smashx_config, smashx_mesh
+            type(smashx_config), intent(in) :: cfg
+            type(smashx_mesh), intent(in) :: mesh
+            type(c_ptr), intent(out) :: plan
+            integer(c_int) :: rc
+        end function
+        function smashx_plan_destroy(plan) bind(C, name="smashx_plan_destroy") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan
+            integer(c_int) :: rc
+        end function
+        function smashx_set_forcing(plan, prcp, pet, sparse) bind(C, name="smashx_set_forcing") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, prcp, pet
+            integer(c_int), value :: sparse
+            integer(c_int) :: rc
+        end function
+        function smashx_set_qobs(plan, qobs) bind(C, name="smashx_set_qobs") result(rc)
+            import :: c_int, c_ptr
+            type(c_ptr), value :: plan, qobs
+            integer(c_int) :: rc
+        end function
+        function smashx_set_options(plan, opt) bind(C, name="smashx_set_options") result(rc)
+            import :: c_int, c_ptr, smashx_options
+            type(c_ptr), value :: plan
+            type(smashx_options), intent(in) :: opt
+            integer(c_int) :: rc
+        end function
+        function smashx_forward(plan, params, params_bgd, states, states_bgd, qsim, costs, fstates) &
+        & bind(C, name="smashx_forward") result(rc)
+            import :: c_int, c_ptr, smashx_parameters, smashx_states, smashx_costs
+            type(c_ptr), value :: plan, qsim
+            type(smashx_parameters) :: params, params_bgd
+            type(smashx_states) :: states, states_bgd, fstates
+            type(smashx_costs) :: costs
+            integer(c_int) :: rc
+        end function
+        function smashx_forward_b(plan, params, params_bgd, states, states_bgd, cost_b, qsim, costs, params_b, states_b) &
+        & bind(C, name="smashx_forward_b") result(rc)
+            import :: c_int, c_float, c_ptr, smashx_parameters, smashx_states, smashx_costs
+            type(c_ptr), value :: plan, qsim
+            type(smashx_parameters) :: params, params_bgd, params_b
+            type(smashx_states) :: states, states_bgd, states_b
+            real(c_float), value :: cost_b
+            type(smashx_costs) :: costs
+            integer(c_int) :: rc
+        end function
+    end interface
+
+    !  one cached plan (the reference calls forward/forward_b many times on the same setup/mesh/input_data)
+    type(c_ptr), save :: sx_plan = c_null_ptr
+    type(c_ptr), save :: sx_key_forcing = c_null_ptr
+    integer, save :: sx_key(6) = 0
+
+contains
+
+    subroutine sx_check(rc, where)
+        integer(c_int), intent(in) :: rc
+        character(len=*), intent(in) :: where
+        character(kind=c_char), pointer :: msg(:)
+        integer :: i
+        if (rc .ne. 0) then
+            call c_f_pointer(smashx_last_error(), msg, [512])
+            write (*, '(a,a,a,i0,a)', advance='no') "smashx: ", where, " failed (", rc, "): "
+            do i = 1, 512
+                if (msg(i) .eq. c_null_char) exit
+                write (*, '(a)', advance='no') msg(i)
+            end do
+            write (*, *)
+            error stop 1
+        end if
+    end subroutine sx_check
+
+    integer function sx_structure_id(structure) result(id)
+        character(len=*), intent(in) :: structure
+        select case (trim(structure))
+        case ("gr-a"); id = 1
+        case ("gr-b"); id = 2
+        case ("gr-c"); id = 3
+        case ("gr-d"); id = 4
+        case default; id = 0
+        end select
+    end function sx_structure_id
+
+    integer function sx_jobs_id(name) result(id)
+        character(len=*), intent(in) :: name
+        select case (trim(name))
+        case ("nse"); id = 1
+        case ("kge"); id = 2
+        case ("kge2"); id = 3
+        case ("se"); id = 4
+        case ("rmse"); id = 5
+        case ("logarithmic"); id = 6
+        case default; id = 99     !  signatures: rejected by smashx_set_options
+        end select
+    end function sx_jobs_id
+
+    integer function sx_jreg_id(name) result(id)
+        character(len=*), intent(in) :: name
+        select case (trim(name))
+        case ("prior"); id = 1
+        case ("smoothing"); id = 2
+        case ("hard_smoothing"); id = 3
+        case default; id = 99
+        end select
+    end function sx_jreg_id
+
+end module smashx_c
+
+!  plan management + option transfer shared by the two entry points
+module smashx_glue
+
+    use iso_c_binding
+    use md_constant
+    use mwd_setup
+    use mwd_mesh
+    use mwd_input_data
+    use mwd_parameters
+    use mwd_states
+    use smashx_c
+
+    implicit none
+
+contains
+
+subroutine smashx_prepare(setup, mesh, input_data)
+
+    implicit none
+
+    type(SetupDT), intent(in), target :: setup
+    type(MeshDT), intent(in), target :: mesh
+    type(Input_DataDT), intent(in), target :: input_data
+
+    type(smashx_config) :: cfg
+    type(smashx_mesh) :: cm
+    type(smashx_options) :: opt
+    integer(c_int), allocatable, target, save :: path0(:, :), gpos0(:, :)
+    real(c_float), allocatable, target, save :: wg(:)
+    type(c_ptr) :: fkey
+    integer :: key(6), j
+
+    if (setup%sparse_storage) then
+        fkey = c_loc(input_data%sparse_prcp)
+    else
+        fkey = c_loc(input_data%prcp)
+    end if
+    key = [sx_structure_id(setup%structure), mesh%nrow, mesh%ncol, setup%ntime_step, mesh%ng, merge(1, 0, setup%sparse_storage)]
+
+    if (.not. c_associated(sx_plan) .or. .not. c_associated(fkey, sx_key_forcing) .or. any(key .ne. sx_key)) then
+        if (c_associated(sx_plan)) call sx_check(smashx_plan_destroy(sx_plan), "plan_destroy")
+        sx_plan = c_null_ptr
+        cfg%structure = key(1); cfg%nrow = mesh%nrow; cfg%ncol = mesh%ncol; cfg%nt = setup%ntime_step; cfg%ng = mesh%ng
+        cfg%dt = setup%dt; cfg%dx = mesh%dx
+        cfg%chunk_steps = 0; cfg%pipe_steps = 0; cfg%group_size = 0; cfg%device = -1
+        if (allocated(path0)) deallocate (path0)
+        if (allocated(gpos0)) deallocate (gpos0)
+        allocate (path0(2, mesh%nrow*mesh%ncol), gpos0(max(mesh%ng, 1), 2))
+        path0 = mesh%path - 1
+        if (mesh%ng .gt. 0) gpos0(1:mesh%ng, :) = mesh%gauge_pos - 1
+        cm%flwdir = c_loc(mesh%flwdir); cm%flwacc = c_loc(mesh%flwacc); cm%active_cell = c_loc(mesh%active_cell)
+        cm%path = c_loc(path0); cm%gauge_pos = c_loc(gpos0)
+        cm%area = c_null_ptr
+        if (mesh%ng .gt. 0) cm%area = c_loc(mesh%area)
+        call sx_check(smashx_plan_create(cfg, cm, sx_plan), "plan_create")
+        if (setup%sparse_storage) then
+            call sx_check(smashx_set_forcing(sx_plan, c_loc(input_data%sparse_prcp), c_loc(input_data%sparse_pet), 1_c_int), &
+            & "set_forcing")
+        else
+            call sx_check(smashx_set_forcing(sx_plan, c_loc(input_data%prcp), c_loc(input_data%pet), 0_c_int), "set_forcing")
+        end if
+        sx_key_forcing = fkey
+        sx_key = key
+    end if
+
+    if (mesh%ng .gt. 0) call sx_check(smashx_set_qobs(sx_plan, c_loc(input_data%qobs)), "set_qobs")
+
+    opt%denormalize_forward = merge(1, 0, setup%optimize%denormalize_forward)
+    opt%optimize_start_step = setup%optimize%optimize_start_step
+    opt%njf = setup%optimize%njf
+    opt%jobs_fun = 0; opt%wjobs_fun = 0._c_float
+    do j = 1, min(setup%optimize%njf, 8)
+        opt%jobs_fun(j) = sx_jobs_id(setup%optimize%jobs_fun(j))
+        opt%wjobs_fun(j) = setup%optimize%wjobs_fun(j)
+    end do
+    opt%njr = setup%optimize%njr
+    opt%jreg_fun = 0; opt%wjreg_fun = 0._c_float
+    do j = 1, min(setup%optimize%njr, 4)
+        opt%jreg_fun(j) = sx_jreg_id(setup%optimize%jreg_fun(j))
+        opt%wjreg_fun(j) = setup%optimize%wjreg_fun(j)
+    end do
+    opt%wjreg = setup%optimize%wjreg
+    opt%optim_parameters = setup%optimize%optim_parameters
+    opt%optim_states = setup%optimize%optim_states
+    opt%lb_parameters = setup%optimize%lb_parameters
+    opt%ub_parameters = setup%optimize%ub_parameters
+    opt%lb_states = setup%optimize%lb_states
+    opt%ub_states = setup%optimize%ub_states
+    if (allocated(wg)) deallocate (wg)
+    allocate (wg(max(mesh%ng, 1)))
+    wg = 0._c_float
+    if (mesh%ng .gt. 0) wg(1:mesh%ng) = setup%optimize%wgauge
+    opt%wgauge = c_loc(wg)
+    call sx_check(smashx_set_options(sx_plan, opt), "set_options")
+
+end subroutine smashx_prepare
+
+subroutine smashx_pack_parameters(p, c)
+    implicit none
+    type(ParametersDT), intent(in), target :: p
+    type(smashx_parameters), intent(out) :: c
+    !  md_constant.f90:37-57 order
+    c%f(1) = c_loc(p%ci); c%f(2) = c_loc(p%cp); c%f(3) = c_loc(p%beta); c%f(4) = c_loc(p%cft)
+    c%f(5) = c_loc(p%cst); c%f(6) = c_loc(p%alpha); c%f(7) = c_loc(p%exc); c%f(8) = c_loc(p%b)
+    c%f(9) = c_loc(p%cusl1); c%f(10) = c_loc(p%cusl2); c%f(11) = c_loc(p%clsl); c%f(12) = c_loc(p%ks)
+    c%f(13) = c_loc(p%ds); c%f(14) = c_loc(p%dsm); c%f(15) = c_loc(p%ws); c%f(16) = c_loc(p%lr)
+end subroutine smashx_pack_parameters
+
+subroutine smashx_pack_states(s, c)
+    implicit none
+    type(StatesDT), intent(in), target :: s
+    type(smashx_states), intent(out) :: c
+    c%f(1) = c_loc(s%hi); c%f(2) = c_loc(s%hp); c%f(3) = c_loc(s%hft); c%f(4) = c_loc(s%hst)
+    c%f(5) = c_loc(s%husl1); c%f(6) = c_loc(s%husl2); c%f(7) = c_loc(s%hlsl); c%f(8) = c_loc(s%hlr)
+end subroutine smashx_pack_states
+
+end module smashx_glue
+
+subroutine base_forward(setup, mesh, input_data, parameters, parameters_bgd, states, states_bgd, output, cost)
+
+    use iso_c_binding
+    use md_constant
+    use mwd_setup
+    use mwd_mesh
+    use mwd_input_data
+    use mwd_parameters
+    use mwd_states
+    use mwd_output
+    use smashx_c
+    use smashx_glue
+
+    implicit none
+
+    type(SetupDT), intent(in), target :: setup
+    type(MeshDT), intent(in), target :: mesh
+    type(Input_DataDT), intent(in), target :: input_data
+    type(ParametersDT), intent(inout), target :: parameters
+    type(ParametersDT), intent(in), target :: parameters_bgd
+    type(StatesDT), intent(inout), target :: states
+    type(StatesDT), intent(in), target :: states_bgd
+    type(OutputDT), intent(inout), target :: output
+    real(sp), intent(inout) :: cost
+
+    type(smashx_parameters) :: cp, cpb
+    type(smashx_states) :: cs, csb, cf
+    type(smashx_costs) :: cc
+    type(c_ptr) :: qs
+
+    call smashx_prepare(setup, mesh, input_data)
+    call smashx_pack_parameters(parameters, cp)
+    call smashx_pack_parameters(parameters_bgd, cpb)
+    call smashx_pack_states(states, cs)
+    call smashx_pack_states(states_bgd, csb)
+    call smashx_pack_states(output%fstates, cf)
+    qs = c_null_ptr
+    if (mesh%ng .gt. 0) qs = c_loc(output%qsim)
+    call sx_check(smashx_forward(sx_plan, cp, cpb, cs, csb, qs, cc, cf), "forward")
+    cost = cc%cost
+    output%cost = cc%cost
+    output%cost_jobs = cc%cost_jobs
+    output%cost_jreg = cc%cost_jreg
+
+end subroutine base_forward
+
+subroutine base_forward_b(setup, mesh, input_data, parameters, parameters_b, parameters_bgd, parameters_bgd_b, &
+& states, states_b, states_bgd, states_bgd_b, output, output_b, cost, cost_b)
+
+    use iso_c_binding
+    use md_constant
+    use mwd_setup
+    use mwd_mesh
+    use mwd_input_data
+    use mwd_parameters
+    use mwd_states
+    use mwd_output
+    use smashx_c
+    use smashx_glue
+
+    implicit none
+
+    type(SetupDT), intent(in), target :: setup
+    type(MeshDT), intent(in), target :: mesh
+    type(Input_DataDT), intent(in), target :: input_data
+    type(ParametersDT), intent(inout), target :: parameters, parameters_b
+    type(ParametersDT), intent(in), target :: parameters_bgd
+    type(ParametersDT) :: parameters_bgd_b
+    type(StatesDT), intent(inout), target :: states, states_b
+    type(StatesDT), intent(in), target :: states_bgd
+    type(StatesDT) :: states_bgd_b
+    type(OutputDT), intent(inout), target :: output
+    type(OutputDT), intent(inout) :: output_b      !  scratch in the reference (OUTPUTDT_DIFF); untouched here
+    real(sp), intent(inout) :: cost, cost_b
+
+    type(smashx_parameters) :: cp, cpb, cpg
+    type(smashx_states) :: cs, csb, csg
+    type(smashx_costs) :: cc
+    type(c_ptr) :: qs
+
+    call smashx_prepare(setup, mesh, input_data)
+    call smashx_pack_parameters(parameters, cp)
+    call smashx_pack_parameters(parameters_bgd, cpb)
+    call smashx_pack_parameters(parameters_b, cpg)
+    call smashx_pack_states(states, cs)
+    call smashx_pack_states(states_bgd, csb)
+    call smashx_pack_states(states_b, csg)
+    qs = c_null_ptr
+    if (mesh%ng .gt. 0) qs = c_loc(output%qsim)
+    call sx_check(smashx_forward_b(sx_plan, cp, cpb, cs, csb, cost_b, qs, cc, cpg, csg), "forward_b")
+    cost = cc%cost
+    output%cost = cc%cost
+    output%cost_jobs = cc%cost_jobs
+    output%cost_jreg = cc%cost_jreg
+
+end subroutine base_forward_b

@@ -1,9 +1,7 @@
-﻿!mod$ v1 sum:9efc37de92630d16
+﻿!mod$ v1 sum:e2f98b0061450daf
 !need$ 0bde2ac47243ead2 i iso_c_binding
-!need$ 4d57810507808050 n mwd_parameters_manipulation
-!need$ ba196de66a1b48a6 n mwd_states_manipulation
 !need$ b74288d896965ed5 n mw_sparse_storage
-!need$ 669a078b745dce26 n mw_forward
+!need$ 5646c8d7b79c7ea8 n mw_optimize
 !need$ 86b12428149ac79a n md_constant
 !need$ 82a26416841665dd n mwd_setup
 !need$ b7e498e07543ba78 n mwd_mesh
@@ -11,9 +9,13 @@
 !need$ eda5fd194b829f52 n mwd_parameters
 !need$ c5f5068eb58aec21 n mwd_states
 !need$ 44a770df04028c8f n mwd_output
+!need$ 669a078b745dce26 n mw_forward
+!need$ 4d57810507808050 n mwd_parameters_manipulation
+!need$ ba196de66a1b48a6 n mwd_states_manipulation
 module ref_capi
 use mw_forward,only:forward
 use mw_forward,only:forward_b
+use mw_optimize,only:optimize_lbfgsb
 use,intrinsic::iso_c_binding,only:c_associated
 use,intrinsic::iso_c_binding,only:c_funloc
 use,intrinsic::iso_c_binding,only:c_funptr
@@ -159,7 +161,7 @@ integer(4),intent(in)::code
 character(20_4,1)::s
 end
 subroutine ref_run(icfg,rcfg,flwdir,flwacc,path,active_cell,gauge_pos,area,prcp,pet,qobs,params,params_bgd,states,states_bgd,wgauge,jobs_codes,wjobs,jreg_codes,wjreg_fun,optim_p,optim_s,lbp,ubp,lbs,ubs,qsim,costs,fstates,params_out,states_out,params_b,states_b,elapsed) bind(c,name="ref_run")
-integer(4),intent(in)::icfg(1_8:12_8)
+integer(4),intent(in)::icfg(1_8:16_8)
 real(4),intent(in)::rcfg(1_8:4_8)
 integer(4),intent(in)::flwdir(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8))
 integer(4),intent(in)::flwacc(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8))

@@ -41,6 +41,25 @@ build_variant () {  # $1 = subdir, $2 = lib name, rest = flags
 }
 
 build_variant obj_parity libsmash_ref.so      -O2 -ffp-contract=off
+
+# Drop-in library: the reference with base_forward / base_forward_b replaced by our ISO_C_BINDING shim
+# (fortran/smashx_dropin.f90) calling libsmashx.  The reference's own definitions are weakened in COPIES of
+# its objects, so everything else (mw_forward, mw_optimize's L-BFGS-B loop, base_forward_d, ...) is unchanged.
+build_dropin () {
+  local src="$OUT/obj_parity" obj="$OUT/obj_dropin" repo
+  repo="$(cd "$HERE/../.." && pwd)"
+  [ -f "$repo/smash_amd/libsmashx.so" ] || { echo "build_ref: libsmashx.so not built yet, skipping the drop-in"; return 0; }
+  rm -rf "$obj"; mkdir -p "$obj"
+  cp "$src"/*.o "$src"/*.mod "$obj"/
+  local OC=/opt/rocm/lib/llvm/bin/llvm-objcopy
+  $OC --weaken-symbol=base_forward_ "$obj/forward.o"
+  $OC --weaken-symbol=base_forward_b_ "$obj/forward_db.o"
+  $FC -cpp -O2 -ffp-contract=off -fPIC -module-dir "$obj" -I"$obj" -c "$repo/fortran/smashx_dropin.f90" -o "$obj/smashx_dropin.o"
+  $FC -shared -o "$OUT/libsmash_dropin.so" "$obj/smashx_dropin.o" $(ls "$obj"/*.o | grep -v smashx_dropin.o) \
+      -L"$repo/smash_amd" -lsmashx -Wl,-rpath,'$ORIGIN/../../smash_amd'
+  echo "built $OUT/libsmash_dropin.so"
+}
+build_dropin
 if [ "${REF_FAST:-1}" = "1" ]; then
   build_variant obj_fast   libsmash_ref_fast.so -O3 -march=x86-64-v3 -funroll-loops
 fi

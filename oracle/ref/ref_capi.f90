@@ -23,6 +23,7 @@ module ref_capi
     use mwd_states_manipulation
     use mw_sparse_storage
     use mw_forward, only: forward, forward_b
+    use mw_optimize, only: optimize_lbfgsb
 
     implicit none
 
@@ -57,7 +58,8 @@ contains
     !  icfg(2:5) nrow, ncol, nt, ng
     !  icfg(6)  sparse_storage (0/1)         icfg(7)  denormalize_forward (0/1)
     !  icfg(8)  optimize_start_step (1-based) icfg(9)  njf      icfg(10) njr
-    !  icfg(11) mode: 0 = forward, 1 = forward_b     icfg(12) nrep (timing repetitions, >=1)
+    !  icfg(11) mode: 0 = forward, 1 = forward_b, 2 = optimize_lbfgsb (mw_optimize.f90:484-676)
+    !  icfg(12) nrep (timing repetitions, >=1)     icfg(13) maxiter (mode 2)
     !  rcfg(1) dt  rcfg(2) dx  rcfg(3) wjreg  rcfg(4) cost_b
     !  Arrays are column-major exactly as the reference holds them; path and gauge_pos are 1-based.
     !  params/states are the (nrow,ncol,GNP)/(nrow,ncol,GNS) packings of get_parameters/get_states
@@ -67,7 +69,7 @@ contains
     & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
     & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed) bind(C, name="ref_run")
 
-        integer(c_int), intent(in) :: icfg(12)
+        integer(c_int), intent(in) :: icfg(16)
         real(c_float), intent(in) :: rcfg(4)
         integer(c_int), intent(in) :: flwdir(icfg(2), icfg(3)), flwacc(icfg(2), icfg(3))
         integer(c_int), intent(in) :: path(2, icfg(2)*icfg(3)), active_cell(icfg(2), icfg(3))
@@ -189,6 +191,12 @@ contains
             call system_clock(c0, crate)
             if (icfg(11) .eq. 0) then
                 call forward(setup, mesh, input_data, p, p_bgd, s, s_bgd, output, cost)
+            else if (icfg(11) .eq. 2) then
+                setup%optimize%denormalize_forward = .false.
+                setup%optimize%maxiter = icfg(13)
+                setup%optimize%verbose = .false.
+                call optimize_lbfgsb(setup, mesh, input_data, p, s, output)
+                cost = output%cost
             else
                 call forward_b(setup, mesh, input_data, p, p_b, p_bgd, p_bgd_b, &
                 & s, s_b, s_bgd, s_bgd_b, output, output_b, cost, cost_b)
@@ -205,7 +213,7 @@ contains
         call get_states(mesh, output%fstates, fstates)
         call get_parameters(mesh, p, params_out)
         call get_states(mesh, s, states_out)
-        if (icfg(11) .ne. 0) then
+        if (icfg(11) .eq. 1) then
             call get_parameters(mesh, p_b, params_b)
             call get_states(mesh, s_b, states_b)
         end if

@@ -24,11 +24,14 @@ GLB_S = np.array([1e-6] * 8, dtype=np.float32)
 GUB_S = np.array([0.999999] * 7 + [10000.0], dtype=np.float32)
 
 
-def lib_path(fast: bool = False) -> str:
-    return os.path.join(_HERE, "_ref", "libsmash_ref_fast.so" if fast else "libsmash_ref.so")
+def lib_path(fast=False) -> str:
+    """fast: False -> parity build (-O2 -ffp-contract=off); True -> the reference's own optimisation level;
+    "dropin" -> the reference with base_forward/base_forward_b replaced by fortran/smashx_dropin.f90 (GPU)."""
+    name = {False: "libsmash_ref.so", True: "libsmash_ref_fast.so", "dropin": "libsmash_dropin.so"}[fast]
+    return os.path.join(_HERE, "_ref", name)
 
 
-def available(fast: bool = False) -> bool:
+def available(fast=False) -> bool:
     return os.path.exists(lib_path(fast))
 
 
@@ -64,7 +67,7 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         states_bgd=None, sparse_storage=False, denormalize_forward=False, optimize_start_step=1,
         jobs_fun=("nse",), wjobs_fun=(1.0,), jreg_fun=(), wjreg_fun=(), wjreg=0.0, wgauge=None,
         optim_parameters=None, optim_states=None, lb_parameters=None, ub_parameters=None,
-        lb_states=None, ub_states=None, cost_b=1.0, nrep=1, fast=False):
+        lb_states=None, ub_states=None, cost_b=1.0, nrep=1, fast=False, optimize_maxiter=None):
     """Call the reference forward / forward_b (mw_forward.f90:18-68) on flat arrays.
 
     mesh: object with nrow, ncol, dx, flwdir, flwacc, path (0-based), active_cell, gauge_pos (0-based),
@@ -74,9 +77,10 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
     nrow, ncol, ng = mesh.nrow, mesh.ncol, mesh.ng
     nt = prcp.shape[2]
     jobs_fun, jreg_fun = list(jobs_fun), list(jreg_fun)
+    mode = 2 if optimize_maxiter is not None else int(adjoint)
     icfg = np.array([STRUCTURES[structure], nrow, ncol, nt, ng, int(sparse_storage),
                      int(denormalize_forward), optimize_start_step, len(jobs_fun), len(jreg_fun),
-                     int(adjoint), nrep], dtype=np.int32)
+                     mode, nrep, optimize_maxiter or 0, 0, 0, 0], dtype=np.int32)
     rcfg = np.array([dt, mesh.dx, wjreg, cost_b], dtype=np.float32)
     P = pack(params, PARAM_NAMES, nrow, ncol)
     S = pack(states, STATE_NAMES, nrow, ncol)

@@ -137,5 +137,33 @@ def main():
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def main_lbfgsb():
+    """Row f1: the reference's own optimize_lbfgsb (mw_optimize.f90:484-676) on the gr-b 24x24x120 case,
+    distributed mapping over cp, cft, exc, lr: cost after 0..4 iterations and the final parameter fields."""
+    c = [x for x in CASES if x["name"] == "gr_b_24x24x120_norm_jreg"][0]
+    mesh = synth.make_mesh(c["n"], c["n"], ng=c["ng"], mask_corner=c["mask"])
+    prcp, pet = synth.dense_forcing(mesh, c["nt"], gap_per_million=c["gaps"])
+    P = synth.make_parameters(c["n"], c["n"])
+    S = synth.make_states(c["n"], c["n"], warm=True)
+    Pq = synth.make_parameters(c["n"], c["n"], perturb=0.1)
+    qobs = refbind.run("gr-b", mesh, DT, prcp, pet, np.zeros((c["ng"], c["nt"]), np.float32), Pq, S)["qsim"].copy()
+    op = np.zeros(16, np.int32)
+    op[[1, 3, 6, 15]] = 1
+    d = dict(optim_parameters=op, maxiters=np.array([0, 1, 2, 3, 4]))
+    costs = []
+    for it in d["maxiters"]:
+        r = refbind.run("gr-b", mesh, DT, prcp, pet, qobs, P, S, optimize_maxiter=int(it), optim_parameters=op,
+                        jobs_fun=("nse",), wjobs_fun=(1.0,))
+        costs.append(r["cost"])
+    d["costs"] = np.array(costs, np.float32)
+    for k in ("cp", "cft", "exc", "lr"):
+        d["final_" + k] = r["parameters"][k]
+    d["qobs"] = qobs
+    np.savez_compressed(os.path.join(OUT, "lbfgsb", "opt_gr_b_24x24x120.npz"), **d)
+    print("lbfgsb costs:", costs)
+
+
 if __name__ == "__main__":
     main()
+    os.makedirs(os.path.join(OUT, "lbfgsb"), exist_ok=True)
+    main_lbfgsb()

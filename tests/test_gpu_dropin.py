@@ -1,0 +1,64 @@
+"""GPU: the reference's OWN Fortran boundary running on the HIP path.
+
+oracle/_ref/libsmash_dropin.so is the unmodified reference solver with only base_forward / base_forward_b
+replaced by the ISO_C_BINDING shim fortran/smashx_dropin.f90 (built by oracle/ref/build_ref.sh in the build
+container; the prebuilt library travels to the GPU box).  The same bind(C) driver that produced the golden
+vectors (oracle/ref/ref_capi.f90 -> mw_forward::forward / forward_b, mw_optimize::optimize_lbfgsb) is called
+on it, so these tests exercise exactly what a maintainer gets by relinking the reference against libsmashx.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import refbind
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not refbind.available("dropin"), reason="oracle/_ref/libsmash_dropin.so not built")]
+
+CASES = ["gr_a_12x12x48_nse", "gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask", "gr_d_48x48x480_nse"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_reference_forward_b_through_dropin(name):
+    g = gu.load(name)
+    f = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, fast="dropin", **g.opts)
+    b = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, adjoint=True, fast="dropin", **g.opts)
+    for i in range(g.mesh.ng):
+        assert gu.rel_l2(f["qsim"][i], g.fwd["qsim"][i]) <= gu.tol(g.noise["qsim"][i])
+        assert gu.rel_l2(b["qsim"][i], g.adj["qsim"][i]) <= gu.tol(g.noise["qsim"][i])
+    assert abs(f["cost"] - g.fwd["cost"]) <= gu.tol_cost(g.noise["cost"], g.fwd["cost"])
+    for k in gu.STRUCT_STATES[g.structure]:
+        assert gu.rel_l2(f["fstates"][k], g.fwd["fstates"][k]) <= gu.tol_fstate(k, g.noise["fstates"][k]), k
+        assert gu.rel_l2(b["states_b"][k], g.adj["states_b"][k]) <= gu.tol(g.noise["states_b"][k]), k
+    for k in gu.STRUCT_PARAMS[g.structure]:
+        assert gu.rel_l2(b["parameters_b"][k], g.adj["parameters_b"][k]) <= gu.tol(g.noise["parameters_b"][k]), k
+
+
+def test_sparse_storage_through_dropin():
+    g = gu.load("gr_c_16x16x96_kge_se_log_mask")
+    f = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, fast="dropin", sparse_storage=True, **g.opts)
+    for i in range(g.mesh.ng):
+        assert gu.rel_l2(f["qsim"][i], g.fwd["qsim"][i]) <= gu.tol(g.noise["qsim"][i])
+
+
+def test_reference_lbfgsb_loop_through_dropin():
+    """SURVEY row f1 / BASELINE config #4 in miniature: the reference's optimize_lbfgsb (host, fp64 L-BFGS-B,
+    mw_optimize.f90:484-676) driving GPU forward / forward_b sweeps through the drop-in boundary.  The iterates
+    are a chaotic function of the gradient's last bits, so the check is on the cost trajectory: identical at
+    iteration 0, and the same decrease (within 2 %) after 4 iterations as the all-CPU reference."""
+    from smash_amd import synth
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "opt_gr_b_24x24x120.npz"))
+    g = gu.load("gr_b_24x24x120_norm_jreg")
+    P = synth.make_parameters(24, 24)
+    S = synth.make_states(24, 24, warm=True)
+    costs = []
+    for it in z["maxiters"]:
+        r = refbind.run("gr-b", g.mesh, g.dt, g.prcp, g.pet, z["qobs"], P, S, optimize_maxiter=int(it),
+                        optim_parameters=z["optim_parameters"], jobs_fun=("nse",), wjobs_fun=(1.0,), fast="dropin")
+        costs.append(r["cost"])
+    ref = z["costs"]
+    assert abs(costs[0] - ref[0]) <= 3e-7 + 1e-5 * abs(ref[0]), (costs, ref)
+    assert costs[-1] < 0.8 * costs[0]
+    assert abs(costs[-1] - ref[-1]) <= 0.02 * abs(ref[0]), (costs, ref)
