@@ -49,7 +49,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", type=int, default=1024, help="cells per side of the per-GPU tile")
+    ap.add_argument("--grid", type=int, default=1024, help="cells per side of the per-GPU tile (weak scaling: fixed per GPU)")
+    ap.add_argument("--tile-rows", type=int, default=0, help="per-GPU tile rows (default --grid); 2048 x 1024 tiles on 8 GPUs = the 4096^2 grid")
+    ap.add_argument("--tile-cols", type=int, default=0)
+    ap.add_argument("--pipe", type=int, default=0, help="pipeline sub-chunk (default: none on 1 GPU, 1104 on tiles)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo only for rehearsing the N>1 path without RCCL")
     ap.add_argument("--nt", type=int, default=8760)
     ap.add_argument("--structure", default="gr-b")
     ap.add_argument("--chunk", type=int, default=0, help="time-chunk length (0 = from free HBM)")
@@ -96,8 +100,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -105,13 +113,30 @@ def main():
     from smash_amd import synth
     from smash_amd.solver import Solver
 
+    from smash_amd import tiles
     n, nt = a.grid, a.nt
+    trows, tcols = a.tile_rows or n, a.tile_cols or n
+    pr, pc = tiles.tile_grid(world)
+    nrow, ncol = pr * trows, pc * tcols            # the whole catchment; every rank owns one trows x tcols tile of it
     t_setup = time.perf_counter()
-    m = synth.make_mesh(n, n, ng=a.ng, seed=synth.SEED + rank)
-    setup = smash_amd.SetupDT(0, a.ng, structure=a.structure, dt=3600.0, ntime_step=nt)
+    m = synth.make_mesh(nrow, ncol, ng=a.ng)
+    rect = tiles.tile_rect(rank, nrow, ncol, pr, pc) if world > 1 else None
+    gp = np.asarray(m.gauge_pos)
+    loc = [i for i in range(m.ng) if rect is None or (rect[0] <= gp[i, 0] < rect[1] and rect[2] <= gp[i, 1] < rect[3])]
+    setup = smash_amd.SetupDT(0, len(loc), structure=a.structure, dt=3600.0, ntime_step=nt)
     setup.optimize.jobs_fun, setup.optimize.wjobs_fun = ["nse"], [1.0]
-    mesh = smash_amd.MeshDT.from_synth(setup, m)
-    sol = Solver(setup, mesh, chunk_steps=a.chunk, group_size=a.group, device=local)
+    setup.optimize.wgauge = np.full(len(loc), 1.0 / m.ng, np.float32)      # weights of the global cost (mean over all gauges)
+    mesh = smash_amd.MeshDT(setup, nrow, ncol, len(loc))
+    mesh.dx, mesh.flwdir, mesh.flwacc, mesh.path, mesh.active_cell = m.dx, m.flwdir, m.flwacc, m.path, m.active_cell
+    mesh.gauge_pos = np.asfortranarray(gp[loc].reshape(-1, 2))
+    mesh.area = np.asarray(m.area)[loc]
+    chunk, pipe = a.chunk, a.pipe
+    if world > 1:
+        # every rank must cut time identically (messages are per sub-chunk): fix the lengths instead of sizing from free HBM
+        chunk = chunk or ((nt + 15) // 16 * 16 if trows * tcols <= 1100000 else ((nt + 3) // 4 + 15) // 16 * 16)
+        pipe = pipe or 1104
+    sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=a.group, device=local, tile=rect)
+    n = None
     rows, cols = sol.cell_order()
     d_rows = torch.from_numpy(rows.astype(np.int64)).to(dev)
     d_cols = torch.from_numpy(cols.astype(np.int64)).to(dev)
@@ -125,16 +150,18 @@ def main():
     del d_rows, d_cols
     torch.cuda.empty_cache()
 
-    P, S = synth.make_parameters(n, n), synth.make_states(n, n, warm=True)
+    P, S = synth.make_parameters(nrow, ncol), synth.make_states(nrow, ncol, warm=True)
     par, sta = smash_amd.ParametersDT.from_dict(mesh, P), smash_amd.StatesDT.from_dict(mesh, S)
     out = smash_amd.OutputDT(setup, mesh)
     # observations = forward run with parameters perturbed by +10 %
-    parq = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(n, n, perturb=0.1))
+    parq = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(nrow, ncol, perturb=0.1))
     sol.set_options(setup.optimize)
+    exchange = tiles.TorchDistExchange(sol, nrow, ncol, pr, pc, dev) if world > 1 else None
     sol.upload(parq, sta)
     sol.sweep(False)
     sol.download(False, parq, sta, out)
-    sol.set_qobs(out.qsim)
+    if len(loc):
+        sol.set_qobs(out.qsim)
     sol.upload(par, sta)
     t_setup = time.perf_counter() - t_setup
 
@@ -157,16 +184,21 @@ def main():
     barrier()
     secs = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([secs], dtype=torch.float64, device=dev)
+        cdev = dev if a.backend == "nccl" else "cpu"
+        t = torch.tensor([secs], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         secs = float(t.item())
-        cs = torch.tensor([float(sol.ncells) * nt], dtype=torch.float64, device=dev)
+        cs = torch.tensor([float(sol.ncells) * nt], dtype=torch.float64, device=cdev)
         dist.all_reduce(cs, op=dist.ReduceOp.SUM)
         cellsteps = float(cs.item())
     else:
         cellsteps = float(sol.ncells) * nt
     par_b, sta_b = par.copy(), sta.copy()
     cost = sol.download(adjoint, par, sta, out, par_b, sta_b)
+    if world > 1:                                   # global cost = sum of the per-tile partial costs
+        ct = torch.tensor([cost], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
+        cost = float(ct.item())
 
     if rank == 0:
         K = a.steps
@@ -197,13 +229,13 @@ def main():
             "value": value, "unit": "cell-timesteps/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n}x{n} synthetic catchment per GPU (D8 E/SE/S, all cells active), hourly x {nt} steps, "
-                                   f"{a.structure}, nse cost at {a.ng} gauges, one forward+adjoint sweep = cost + gradient of all "
-                                   "distributed parameters and initial states (BASELINE.json configs[2])",
-                       "grid": [n, n], "nt": nt, "structure": a.structure, "active_cells": sol.ncells,
+            "config": {"workload": f"{nrow}x{ncol} synthetic catchment ({trows}x{tcols} cells per GPU, D8 E/SE/S, all cells active), "
+                                   f"hourly x {nt} steps, {a.structure}, nse cost at {a.ng} gauges, one forward+adjoint sweep = cost + "
+                                   "gradient of all distributed parameters and initial states (BASELINE.json configs[2]; tiled: configs[4])",
+                       "grid": [nrow, ncol], "tile": [trows, tcols], "nt": nt, "structure": a.structure, "active_cells": int(cellsteps / nt),
                        "chunk_steps": int(tm["chunk_steps"]), "n_chunks": int(tm["n_chunks"]),
                        "routing_rounds": int(tm["n_rounds"]), "routing_groups": int(tm["n_groups"]),
-                       "parallelism": f"tiles{world}" if world > 1 else "single"},
+                       "parallelism": f"tiles {pr}x{pc}, halo exchange of boundary discharge series (send/recv)" if world > 1 else "single"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, per_launch_steps) if a.structure == "gr-b" else None,
                          "avg_launch_ms": avg_ms, "launches_per_step": n_launch,

@@ -56,6 +56,8 @@ typedef struct {
     int pipe_steps;    /* pipeline sub-chunk: vertical and routing kernels overlap chunk by chunk on two streams; 0 = no sub-chunking */
     int group_size;    /* routing workgroup size (cells + inlets per group); 0 = default */
     int device;        /* HIP device ordinal; -1 = current device */
+    int tile[4];       /* multi-GPU: this rank owns rows [tile[0],tile[1]) x cols [tile[2],tile[3]) of the grid;
+                          all zero = the whole grid.  Mesh and parameter arrays stay global-sized. */
 } smashx_config;
 
 typedef struct {
@@ -148,6 +150,29 @@ int smashx_sweep(smashx_plan* plan, int adjoint, float cost_b);
 int smashx_download(smashx_plan* plan, int adjoint, smashx_parameters* params, smashx_states* states, float* qsim,
                     smashx_costs* costs, smashx_states* fstates, smashx_parameters* params_b, smashx_states* states_b);
 int smashx_get_timing(const smashx_plan* plan, smashx_timing* out);
+
+/* ---- multi-GPU tiles: discharge series that cross the tile boundary -------------------
+ * A cell whose D8 receiver lies in another tile publishes its discharge series ("out" edge); a cell of another
+ * tile draining into this one is an "in" edge.  Both lists are sorted by the flat (row + col*nrow) index of
+ * the SOURCE cell, so the two sides of a tile border enumerate a shared edge set in the same order.
+ * The plan packs / unpacks the series of one pipeline sub-chunk into the caller's device buffers and calls
+ * `fn` at the four points where data must move between ranks; the host (torch.distributed over RCCL in
+ * bench.py) does the send / recv.  Buffers: out_buf holds n_out * pipe_steps floats, in_buf n_in * pipe_steps.
+ *   phase 0  FWD_RECV  fill in_buf  (series of the in edges for this sub-chunk)   before routing forward
+ *   phase 1  FWD_SEND  out_buf is ready (series of the out edges)                 after  routing forward
+ *   phase 2  ADJ_RECV  fill out_buf (adjoint contributions for the out edges)     before routing adjoint
+ *   phase 3  ADJ_SEND  in_buf is ready (adjoint series of the in edges)           after  routing adjoint
+ * Layout of a buffer: [edge][ceil(nsteps/4)] float4 (4 consecutive steps each).  */
+typedef int (*smashx_halo_fn)(void* user, int phase, int t0, int nsteps);
+/* host-only (no GPU needed): builds the routing schedule of one tile and reports
+ * info = {cells, rounds, groups, slots, exchange series, deepest stage, n_out, n_in}; edge arrays may be NULL or
+ * must hold `cap` entries (flat row + col*nrow indices, sorted by source cell). */
+int smashx_tile_probe(const smashx_config* cfg, const smashx_mesh* mesh, int* info, int* out_src, int* out_dst,
+                      int* in_src, int* in_dst, int cap);
+int smashx_halo_counts(const smashx_plan* plan, int* n_out, int* n_in);
+int smashx_halo_edges(const smashx_plan* plan, int* out_src, int* out_dst, int* in_src, int* in_dst);
+int smashx_plan_chunking(smashx_plan* plan, int* chunk_steps, int* pipe_steps);   /* fixes and returns the chunk lengths */
+int smashx_set_halo(smashx_plan* plan, float* d_out_buf, float* d_in_buf, smashx_halo_fn fn, void* user);
 
 #ifdef __cplusplus
 }

@@ -16,14 +16,16 @@ SYMBOLS = [
     "smashx_last_error", "smashx_device_count", "smashx_plan_create", "smashx_plan_destroy", "smashx_plan_ncells",
     "smashx_plan_cell_order", "smashx_set_forcing", "smashx_set_forcing_device_block", "smashx_set_qobs",
     "smashx_set_options", "smashx_forward", "smashx_forward_b", "smashx_upload", "smashx_sweep", "smashx_download",
-    "smashx_get_timing",
+    "smashx_get_timing", "smashx_halo_counts", "smashx_halo_edges", "smashx_plan_chunking", "smashx_set_halo", "smashx_tile_probe",
 ]
+
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
 
 
 class Config(C.Structure):
     _fields_ = [("structure", C.c_int), ("nrow", C.c_int), ("ncol", C.c_int), ("nt", C.c_int), ("ng", C.c_int),
                 ("dt", C.c_float), ("dx", C.c_float), ("chunk_steps", C.c_int), ("pipe_steps", C.c_int), ("group_size", C.c_int),
-                ("device", C.c_int)]
+                ("device", C.c_int), ("tile", C.c_int * 4)]
 
 
 class Mesh(C.Structure):

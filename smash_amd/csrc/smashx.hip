@@ -71,6 +71,20 @@ __global__ void k_scatter(float* dst, const float* src, const int* idx, int n, f
     if (k < n) dst[idx[k]] = scaled ? scale * src[k] : src[k];
 }
 
+// boundary series <-> dense message buffer [edge][Tq] float4
+__global__ void k_halo_pack(float4* buf, const float4* x4, const int* slots, int nedge, int nx, int Tq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nedge * Tq) return;
+    const int e = i / Tq, tb = i % Tq;
+    buf[(size_t)e * Tq + tb] = x4[(size_t)tb * nx + slots[e]];
+}
+__global__ void k_halo_unpack(float4* x4, const float4* buf, const int* slots, int nedge, int nx, int Tq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nedge * Tq) return;
+    const int e = i / Tq, tb = i % Tq;
+    x4[(size_t)tb * nx + slots[e]] = buf[(size_t)e * Tq + tb];
+}
+
 struct Launch { hipEvent_t a, b; int kind; };
 
 }  // namespace
@@ -89,6 +103,11 @@ struct smashx_plan {
     hipStream_t stream = nullptr;    // vertical kernels, uploads/downloads ("V stream")
     hipStream_t stream_r = nullptr;  // routing + cost kernels ("R stream"); overlaps the V stream chunk by chunk
     int Tp = 0;                      // pipeline sub-chunk length inside a storage chunk
+    // tile boundary exchange
+    int n_out = 0, n_in = 0;
+    int *d_out_x = nullptr, *d_in_x = nullptr;
+    float *halo_out = nullptr, *halo_in = nullptr;   // caller-owned device buffers
+    smashx_halo_fn halo_fn = nullptr; void* halo_user = nullptr;
     std::vector<void*> allocs;
     double bytes = 0;
     SxDeviceArrays A{};
@@ -336,7 +355,9 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     if (set_device(p)) { delete p; return SMASHX_E_HIP; }
     p->M = cfg->group_size > 0 ? cfg->group_size : 512;
     if (p->M % 64 != 0 || p->M > SX_MAXGROUP || p->M < 64) { delete p; return fail(SMASHX_E_ARG, "group_size must be a multiple of 64 in [64, 512]"); }
-    const int rc0 = sx_build_schedule(cfg->nrow, cfg->ncol, mesh->flwdir, mesh->active_cell, cfg->ng, mesh->gauge_pos, p->M, p->sch);
+    const bool tiled = cfg->tile[1] > cfg->tile[0] && cfg->tile[3] > cfg->tile[2];
+    const int rc0 = sx_build_schedule(cfg->nrow, cfg->ncol, mesh->flwdir, mesh->active_cell, cfg->ng, mesh->gauge_pos, p->M,
+                                      tiled ? cfg->tile : nullptr, p->sch);
     if (rc0 != 0) { std::string e = p->sch.error; delete p; return fail(rc0 == -5 ? SMASHX_E_MESH : SMASHX_E_ARG, e); }
     p->n = p->sch.n; p->npad = (p->n + SX_VBLOCK - 1) / SX_VBLOCK * SX_VBLOCK;
     p->nt = cfg->nt; p->ng = cfg->ng; p->st = cfg->structure; p->n2 = (long)cfg->nrow * cfg->ncol;
@@ -357,6 +378,9 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     TRY(p->upload_vec(&d7, p->sch.s_parent)); A.s_parent = d7;
     TRY(p->upload_vec(&d8, p->sch.s_xout)); A.s_xout = d8;
     TRY(p->upload_vec(&p->d_cell_flat, p->sch.cell_flat));
+    p->n_out = (int)p->sch.out_x.size(); p->n_in = (int)p->sch.in_x.size();
+    TRY(p->upload_vec(&p->d_out_x, p->sch.out_x.empty() ? std::vector<int>(1, 0) : p->sch.out_x));
+    TRY(p->upload_vec(&p->d_in_x, p->sch.in_x.empty() ? std::vector<int>(1, 0) : p->sch.in_x));
     // per-cell mesh data
     std::vector<int> facc(p->npad, 1), cg(p->npad, -1);
     for (int k = 0; k < p->n; ++k) facc[k] = mesh->flwacc[p->sch.cell_flat[k]];
@@ -555,6 +579,7 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     if (!p->uploaded) return fail(SMASHX_E_STATE, "parameters/states not uploaded");
     int rc = set_device(p); if (rc) return rc;
     if ((rc = ensure_chunk_buffers(p, adjoint != 0))) return rc;
+    if ((p->n_out > 0 || p->n_in > 0) && !p->halo_fn) return fail(SMASHX_E_STATE, "tile has boundary series but no halo exchange is set (smashx_set_halo)");
     p->launches.clear(); p->pool_used = 0;
     hipStream_t sV = p->stream, sR = p->stream_r;
     HIPCHK(hipEventRecord(p->ev0, sV));
@@ -563,15 +588,50 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     const int C = p->nchunks;
     auto nsub_of = [&](int T) { return (T + p->Tp - 1) / p->Tp; };
     // forward over one storage chunk: V(j) on the V stream, R(j) on the R stream as soon as V(j) is done
+    const bool halo = p->halo_fn && (p->n_out > 0 || p->n_in > 0);
+    // move the boundary series of one sub-chunk between the exchange rows and the caller's message buffers
+    auto halo_move = [&](bool pack, bool out_edges, int off, int T) {
+        const int nedge = out_edges ? p->n_out : p->n_in;
+        if (nedge == 0) return;
+        const int Tq = (T + 3) / 4;
+        float4* x4 = reinterpret_cast<float4*>(p->A.xT) + (size_t)(off / 4) * p->A.nx;
+        float4* buf = reinterpret_cast<float4*>(out_edges ? p->halo_out : p->halo_in);
+        const int* slots = out_edges ? p->d_out_x : p->d_in_x;
+        const dim3 g((nedge * Tq + 255) / 256), b(256);
+        if (pack) hipLaunchKernelGGL(k_halo_pack, g, b, 0, sR, buf, x4, slots, nedge, p->A.nx, Tq);
+        else hipLaunchKernelGGL(k_halo_unpack, g, b, 0, sR, x4, buf, slots, nedge, p->A.nx, Tq);
+    };
+    auto hook = [&](int phase, int t0, int T) -> int {
+        const int rc2 = p->halo_fn(p->halo_user, phase, t0, T);
+        return rc2 ? fail(SMASHX_E_ARG, "halo callback failed") : 0;
+    };
     auto forward_chunk = [&](int c, bool tape) -> int {
-        const int t0c = c * p->Tc, Tcur = chunk_len(p, c);
-        for (int jb = 0; jb < nsub_of(Tcur); ++jb) {
+        const int t0c = c * p->Tc, Tcur = chunk_len(p, c), ns = nsub_of(Tcur);
+        auto launch_v = [&](int jb) -> int {
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
             vert_fwd(p, off, tape, t0c + off, T);
-            hipEvent_t e = p->event();
-            HIPCHK(hipEventRecord(e, sV));
-            HIPCHK(hipStreamWaitEvent(sR, e, 0));
+            return 0;
+        };
+        std::vector<hipEvent_t> ev(ns);
+        if ((rc = launch_v(0))) return rc;
+        ev[0] = p->event(); HIPCHK(hipEventRecord(ev[0], sV));
+        for (int jb = 0; jb < ns; ++jb) {
+            const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
+            if (halo && p->n_in > 0) {
+                if ((rc = hook(0, t0c + off, T))) return rc;      // in_buf now holds the upstream tiles' series
+                halo_move(false, false, off, T);
+            }
+            HIPCHK(hipStreamWaitEvent(sR, ev[jb], 0));
             route_fwd(p, off, tape, t0c + off, T);
+            if (jb + 1 < ns) {                                     // keep the V stream busy while we wait on the R stream
+                if ((rc = launch_v(jb + 1))) return rc;
+                ev[jb + 1] = p->event(); HIPCHK(hipEventRecord(ev[jb + 1], sV));
+            }
+            if (halo && p->n_out > 0) {
+                halo_move(true, true, off, T);
+                HIPCHK(hipStreamSynchronize(sR));
+                if ((rc = hook(1, t0c + off, T))) return rc;
+            }
         }
         return 0;
     };
@@ -616,11 +676,20 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
             }
             for (int jb = nsub_of(Tcur) - 1; jb >= 0; --jb) {
                 const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
+                if (halo && p->n_out > 0) {
+                    if ((rc = hook(2, t0c + off, T))) return rc;  // out_buf now holds the downstream tiles' adjoint contributions
+                    halo_move(false, true, off, T);
+                }
                 route_adj(p, off, t0c + off, T);
                 hipEvent_t e = p->event();
                 HIPCHK(hipEventRecord(e, sR));
                 HIPCHK(hipStreamWaitEvent(sV, e, 0));
                 vert_adj(p, off, t0c + off, T);
+                if (halo && p->n_in > 0) {
+                    halo_move(true, false, off, T);
+                    HIPCHK(hipStreamSynchronize(sR));
+                    if ((rc = hook(3, t0c + off, T))) return rc;
+                }
             }
         }
     }
@@ -651,6 +720,53 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     tm.n_chunks = p->nchunks; tm.chunk_steps = p->Tc; tm.pipe_steps = p->Tp; tm.n_rounds = p->sch.nrounds; tm.n_groups = p->sch.ngroups;
     tm.device_bytes = p->bytes;
     p->last_adjoint = adjoint;
+    return 0;
+}
+
+int smashx_tile_probe(const smashx_config* cfg, const smashx_mesh* mesh, int* info, int* out_src, int* out_dst,
+                      int* in_src, int* in_dst, int cap) {
+    if (!cfg || !mesh || !info) return fail(SMASHX_E_ARG, "null argument");
+    SxSchedule sch;
+    const bool tiled = cfg->tile[1] > cfg->tile[0] && cfg->tile[3] > cfg->tile[2];
+    const int M = cfg->group_size > 0 ? cfg->group_size : 512;
+    const int rc = sx_build_schedule(cfg->nrow, cfg->ncol, mesh->flwdir, mesh->active_cell, cfg->ng, mesh->gauge_pos, M,
+                                     tiled ? cfg->tile : nullptr, sch);
+    if (rc) return fail(rc == -5 ? SMASHX_E_MESH : SMASHX_E_ARG, sch.error);
+    const int no = (int)sch.out_x.size(), ni = (int)sch.in_x.size();
+    const int v[8] = {sch.n, sch.nrounds, sch.ngroups, sch.nslots, sch.nxslots, sch.max_stage, no, ni};
+    for (int i = 0; i < 8; ++i) info[i] = v[i];
+    if (no > cap || ni > cap) { if (out_src || in_src) return fail(SMASHX_E_ARG, "edge capacity too small"); return 0; }
+    for (int i = 0; i < no; ++i) { if (out_src) out_src[i] = sch.out_src[i]; if (out_dst) out_dst[i] = sch.out_dst[i]; }
+    for (int i = 0; i < ni; ++i) { if (in_src) in_src[i] = sch.in_src[i]; if (in_dst) in_dst[i] = sch.in_dst[i]; }
+    return 0;
+}
+
+int smashx_halo_counts(const smashx_plan* p, int* n_out, int* n_in) {
+    if (!p || !n_out || !n_in) return fail(SMASHX_E_ARG, "null argument");
+    *n_out = p->n_out; *n_in = p->n_in;
+    return 0;
+}
+
+int smashx_halo_edges(const smashx_plan* p, int* out_src, int* out_dst, int* in_src, int* in_dst) {
+    if (!p) return fail(SMASHX_E_ARG, "null plan");
+    for (int i = 0; i < p->n_out; ++i) { if (out_src) out_src[i] = p->sch.out_src[i]; if (out_dst) out_dst[i] = p->sch.out_dst[i]; }
+    for (int i = 0; i < p->n_in; ++i) { if (in_src) in_src[i] = p->sch.in_src[i]; if (in_dst) in_dst[i] = p->sch.in_dst[i]; }
+    return 0;
+}
+
+int smashx_plan_chunking(smashx_plan* p, int* chunk_steps, int* pipe_steps) {
+    if (!p) return fail(SMASHX_E_ARG, "null plan");
+    int rc = set_device(p); if (rc) return rc;
+    if ((rc = ensure_chunk_buffers(p, true))) return rc;
+    if (chunk_steps) *chunk_steps = p->Tc;
+    if (pipe_steps) *pipe_steps = p->Tp;
+    return 0;
+}
+
+int smashx_set_halo(smashx_plan* p, float* d_out_buf, float* d_in_buf, smashx_halo_fn fn, void* user) {
+    if (!p) return fail(SMASHX_E_ARG, "null plan");
+    if (fn && ((p->n_out > 0 && !d_out_buf) || (p->n_in > 0 && !d_in_buf))) return fail(SMASHX_E_ARG, "halo buffers missing");
+    p->halo_out = d_out_buf; p->halo_in = d_in_buf; p->halo_fn = fn; p->halo_user = user;
     return 0;
 }
 

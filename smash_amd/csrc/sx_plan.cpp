@@ -15,41 +15,61 @@ const int DCOL[8] = {0, 1, 1, 1, 0, -1, -1, -1};
 }  // namespace
 
 int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_cell, int ng, const int* gauge_pos,
-                      int group_size, SxSchedule& s) {
+                      int group_size, const int* rect, SxSchedule& s) {
     const int M = group_size;
     if (nrow <= 0 || ncol <= 0 || M < 16) { s.error = "bad sizes"; return -1; }
     const long n2 = (long)nrow * ncol;
     s.nrow = nrow; s.ncol = ncol; s.group_size = M;
 
-    // ---- active cells in column-major order (temporary index a), parents, children in D8 order ----
+    // ---- local active cells in column-major order (temporary index a), parents, children in D8 order ----
+    const int r0 = rect ? rect[0] : 0, r1 = rect ? rect[1] : nrow, c0 = rect ? rect[2] : 0, c1 = rect ? rect[3] : ncol;
+    auto inside = [&](int row, int col) { return row >= r0 && row < r1 && col >= c0 && col < c1; };
     std::vector<int> a_of_flat(n2, -1), flat_of_a;
-    flat_of_a.reserve(n2);
+    flat_of_a.reserve((size_t)(r1 - r0) * (c1 - c0));
     for (long c = 0; c < n2; ++c)
-        if (active_cell[c] == 1) { a_of_flat[c] = (int)flat_of_a.size(); flat_of_a.push_back((int)c); }
+        if (active_cell[c] == 1 && inside((int)(c % nrow), (int)(c / nrow))) { a_of_flat[c] = (int)flat_of_a.size(); flat_of_a.push_back((int)c); }
     const int n = (int)flat_of_a.size();
     s.n = n;
     if (n == 0) { s.error = "no active cell"; return -1; }
-    std::vector<int> parent(n, -1), code(n, 0);
+    // cells of other tiles draining into a local cell: virtual nodes n .. n+nr-1 (always inlets)
+    std::vector<int> rflat, rparent;
+    std::vector<int> parent(n, -1), code(n, 0), remote_parent_flat(n, -1);
     for (int a = 0; a < n; ++a) {
         const int c = flat_of_a[a], row = c % nrow, col = c / nrow, fd = flwdir[c];
         code[a] = fd;
+        if (rect)
+            for (int i = 0; i < 8; ++i) {   // neighbour at -D[i] drains into me iff its code == i+1
+                const int rn = row - DROW[i], cn = col - DCOL[i];
+                if (rn < 0 || rn >= nrow || cn < 0 || cn >= ncol || inside(rn, cn)) continue;
+                const long fn = rn + (long)cn * nrow;
+                if (active_cell[fn] == 1 && flwdir[fn] == i + 1) { rflat.push_back((int)fn); rparent.push_back(a); }
+            }
         if (fd < 1 || fd > 8) continue;
         const int r2 = row + DROW[fd - 1], c2 = col + DCOL[fd - 1];
         if (r2 < 0 || r2 >= nrow || c2 < 0 || c2 >= ncol) continue;
-        parent[a] = a_of_flat[r2 + (long)c2 * nrow];   // -1 when the receiver is inactive
+        const long f2 = r2 + (long)c2 * nrow;
+        if (active_cell[f2] != 1) continue;            // receiver inactive: catchment outlet
+        if (inside(r2, c2)) parent[a] = a_of_flat[f2];
+        else remote_parent_flat[a] = (int)f2;          // receiver lives in another tile
     }
+    const int nr = (int)rflat.size(), nv = n + nr;
+    code.resize(nv);
+    for (int q = 0; q < nr; ++q) code[n + q] = flwdir[rflat[q]];
     std::vector<int> nchild(n, 0), cbeg(n + 1, 0);
     for (int a = 0; a < n; ++a) if (parent[a] >= 0) nchild[parent[a]]++;
+    for (int q = 0; q < nr; ++q) nchild[rparent[q]]++;
     for (int a = 0; a < n; ++a) cbeg[a + 1] = cbeg[a] + nchild[a];
     std::vector<int> child(cbeg[n]), fill(n, 0);
     for (int a = 0; a < n; ++a) if (parent[a] >= 0) { const int p = parent[a]; child[cbeg[p] + fill[p]++] = a; }
+    for (int q = 0; q < nr; ++q) { const int p = rparent[q]; child[cbeg[p] + fill[p]++] = n + q; }
     for (int a = 0; a < n; ++a)   // order 1..8 as md_routing_operator.f90:37-53 sums them
         std::sort(child.begin() + cbeg[a], child.begin() + cbeg[a + 1], [&](int x, int y) { return code[x] < code[y]; });
 
     // ---- topological order (leaves first); a cycle (pit pair) cannot be scheduled ----
     std::vector<int> topo; topo.reserve(n);
     {
-        std::vector<int> indeg(nchild);
+        std::vector<int> indeg(n, 0);
+        for (int a = 0; a < n; ++a) if (parent[a] >= 0) indeg[parent[a]]++;
         for (int a = 0; a < n; ++a) if (indeg[a] == 0) topo.push_back(a);
         for (size_t i = 0; i < topo.size(); ++i) {
             const int p = parent[topo[i]];
@@ -59,7 +79,8 @@ int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_c
     }
 
     // ---- rounds: repeatedly peel off every maximal subtree whose weight (cells + inlets) fits a group ----
-    std::vector<int> round_of(n, -1), w(n, 0);
+    std::vector<int> round_of(nv, -1), w(nv, 0);
+    for (int q = 0; q < nr; ++q) round_of[n + q] = -2;   // remote: never scheduled here, always an inlet
     struct Root { int a; int weight; };
     std::vector<std::vector<std::vector<int>>> round_groups;   // round -> group -> list of roots
     int remaining = n, round = 0;
@@ -67,7 +88,7 @@ int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_c
     while (remaining > 0) {
         for (int a : todo) {
             long ww = 1;
-            for (int j = cbeg[a]; j < cbeg[a + 1]; ++j) ww += (round_of[child[j]] >= 0) ? 1 : w[child[j]];
+            for (int j = cbeg[a]; j < cbeg[a + 1]; ++j) ww += (round_of[child[j]] != -1) ? 1 : w[child[j]];
             w[a] = (int)std::min<long>(ww, (long)M + 1);
         }
         std::vector<Root> roots;
@@ -95,12 +116,23 @@ int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_c
 
     // ---- exchange series: one per subtree root that has a receiver in a later round ----
     // (roots without parent are catchment outlets: they publish nothing)
-    std::vector<int> xslot_of(n, -1);
+    std::vector<int> xslot_of(nv, -1);
     int nx = 0;
     for (int r = 0; r < s.nrounds; ++r)
         for (auto& g : round_groups[r])
-            for (int a : g) if (parent[a] >= 0) xslot_of[a] = nx++;
+            for (int a : g) if (parent[a] >= 0 || remote_parent_flat[a] >= 0) xslot_of[a] = nx++;
+    for (int q = 0; q < nr; ++q) xslot_of[n + q] = nx++;
     s.nxslots = nx;
+    {   // boundary series, sorted by source cell so both sides of a tile edge enumerate them identically
+        std::vector<int> o;
+        for (int a = 0; a < n; ++a) if (remote_parent_flat[a] >= 0) o.push_back(a);
+        std::sort(o.begin(), o.end(), [&](int x, int y) { return flat_of_a[x] < flat_of_a[y]; });
+        for (int a : o) { s.out_x.push_back(xslot_of[a]); s.out_src.push_back(flat_of_a[a]); s.out_dst.push_back(remote_parent_flat[a]); }
+        std::vector<int> in(nr);
+        std::iota(in.begin(), in.end(), 0);
+        std::sort(in.begin(), in.end(), [&](int x, int y) { return rflat[x] < rflat[y]; });
+        for (int q : in) { s.in_x.push_back(xslot_of[n + q]); s.in_src.push_back(rflat[q]); s.in_dst.push_back(flat_of_a[rparent[q]]); }
+    }
 
     // ---- group-local breadth-first order, stages, device cell numbering ----
     s.round_group_begin.assign(1, 0);
@@ -120,7 +152,7 @@ int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_c
                 if (node < 0) continue;   // inlet pseudo-cell: no children here
                 for (int j = cbeg[node]; j < cbeg[node + 1]; ++j) {
                     const int c = child[j];
-                    q_node.push_back(round_of[c] == r ? c : -1 - c);
+                    q_node.push_back((c < n && round_of[c] == r) ? c : -1 - c);
                     q_par.push_back((int)i); q_depth.push_back(q_depth[i] + 1);
                     ccount[i]++;
                 }

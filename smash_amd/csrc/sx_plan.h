@@ -32,9 +32,15 @@ struct SxSchedule {
     std::vector<int> s_parent;   // group-local index of the parent, -1 for a subtree root
     std::vector<int> s_xout;     // subtree roots: exchange series id they publish, else -1
     std::vector<int> gauge_k;    // ng: device cell of every gauge
+    // tile decomposition (multi-GPU): discharge series that cross the tile boundary, sorted by source cell
+    std::vector<int> out_x, out_src, out_dst;   // series this tile publishes for a receiver in another tile (flat indices)
+    std::vector<int> in_x, in_src, in_dst;      // series this tile needs from a cell in another tile
     std::string error;
 };
 
 // Returns 0 on success, negative on failure (s.error set).  All arrays column-major (row fastest).
+// rect = {row0, row1, col0, col1} (half-open) restricts the schedule to the cells of one tile of the grid;
+// cells of other tiles that drain into it become inlets fed by received series, cells draining out of it
+// publish theirs.  rect == nullptr: the whole grid.
 int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_cell, int ng, const int* gauge_pos,
-                      int group_size, SxSchedule& s);
+                      int group_size, const int* rect, SxSchedule& s);

@@ -27,6 +27,16 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+def make_config(setup, mesh, chunk_steps=0, pipe_steps=0, group_size=0, device=-1, tile=None):
+    cfg = _lib.Config()
+    cfg.structure, cfg.nrow, cfg.ncol = STRUCTURES[setup.structure], mesh.nrow, mesh.ncol
+    cfg.nt, cfg.ng, cfg.dt, cfg.dx = setup.ntime_step, mesh.ng, setup.dt, mesh.dx
+    cfg.chunk_steps, cfg.pipe_steps, cfg.group_size, cfg.device = chunk_steps, pipe_steps, group_size, device
+    for i in range(4):
+        cfg.tile[i] = int(tile[i]) if tile is not None else 0
+    return cfg
+
+
 def _f32(a):
     return np.asfortranarray(a, dtype=np.float32)
 
@@ -38,14 +48,16 @@ def _i32(a):
 class Solver:
     """A libsmashx plan: routing schedule + HBM-resident forcing for one (setup, mesh, input_data)."""
 
-    def __init__(self, setup, mesh, *, chunk_steps: int = 0, pipe_steps: int = 0, group_size: int = 0, device: int = -1):
+    def __init__(self, setup, mesh, *, chunk_steps: int = 0, pipe_steps: int = 0, group_size: int = 0, device: int = -1,
+                 tile=None):
+        """tile = (row0, row1, col0, col1): this plan only owns that rectangle of the grid (multi-GPU, see
+        smash_amd.tiles); mesh and field arrays stay global-sized."""
         L = _lib.lib()
         self.nrow, self.ncol, self.nt, self.ng = mesh.nrow, mesh.ncol, setup.ntime_step, mesh.ng
         self.structure = setup.structure
         if setup.structure not in STRUCTURES:
             raise _lib.SmashxError(_lib.E_UNSUPPORTED, f"structure {setup.structure!r} is not on the hot path yet")
-        cfg = _lib.Config(STRUCTURES[setup.structure], mesh.nrow, mesh.ncol, setup.ntime_step, mesh.ng, setup.dt,
-                          mesh.dx, chunk_steps, pipe_steps, group_size, device)
+        cfg = make_config(setup, mesh, chunk_steps, pipe_steps, group_size, device, tile)
         self._keep = [_i32(mesh.flwdir), _i32(mesh.flwacc), _i32(mesh.active_cell), _i32(mesh.path),
                       _i32(np.asarray(mesh.gauge_pos).reshape(-1, 2)), np.ascontiguousarray(mesh.area, np.float32)]
         m = _lib.Mesh(*[_ptr(a) for a in self._keep])
@@ -87,6 +99,35 @@ class Solver:
     def set_qobs(self, qobs):
         q = _f32(qobs)
         _lib.check(_lib.lib().smashx_set_qobs(self._h, _ptr(q)))
+
+    # -- tiles ---------------------------------------------------------------------------------
+    def halo_counts(self):
+        a, b = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().smashx_halo_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def halo_edges(self):
+        no, ni = self.halo_counts()
+        arr = [np.zeros(max(n, 1), np.int32) for n in (no, no, ni, ni)]
+        _lib.check(_lib.lib().smashx_halo_edges(self._h, *[_ptr(a) for a in arr]))
+        return arr[0][:no], arr[1][:no], arr[2][:ni], arr[3][:ni]
+
+    def chunking(self):
+        a, b = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().smashx_plan_chunking(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_halo(self, out_ptr, in_ptr, fn):
+        """fn(phase, t0, nsteps) -> 0; out_ptr / in_ptr: device addresses of the message buffers."""
+        def tramp(user, phase, t0, nsteps):
+            try:
+                return int(fn(phase, t0, nsteps) or 0)
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._halo_cb = _lib.HALO_FN(tramp)
+        _lib.check(_lib.lib().smashx_set_halo(self._h, C.c_void_p(out_ptr), C.c_void_p(in_ptr), self._halo_cb, None))
 
     def set_options(self, opt):
         o = _lib.Options()

@@ -119,22 +119,22 @@ def make_path(flwacc: np.ndarray) -> np.ndarray:
 def pick_gauges(flwacc: np.ndarray, ng: int):
     """Outlet + (ng-1) interior cells with the largest flow accumulation, kept apart by 1/8 of the grid."""
     nrow, ncol = flwacc.shape
-    a = np.ascontiguousarray(flwacc).reshape(-1)
-    order = np.argsort(-a.astype(np.int64), kind="stable")
-    pos, sep = [], max(1, max(nrow, ncol) // 8)
-    for idx in order:
-        r, c = divmod(int(idx), ncol)
-        if any(abs(r - r0) + abs(c - c0) < sep for r0, c0 in pos):
-            continue
-        pos.append((r, c))
-        if len(pos) == ng:
-            break
-    for idx in order:                       # tiny grids: relax the separation rule
-        if len(pos) == ng:
-            break
-        r, c = divmod(int(idx), ncol)
-        if (r, c) not in pos:
-            pos.append((r, c))
+    a = np.ascontiguousarray(flwacc).reshape(-1).astype(np.int64)
+    order = np.argsort(-a, kind="stable")
+    r, c = order // ncol, order % ncol
+    ok = a[order] > 0
+    sep = max(1, max(nrow, ncol) // 8)
+    pos = []
+    while len(pos) < ng and ok.any():
+        i = int(np.argmax(ok))                    # best remaining candidate
+        pos.append((int(r[i]), int(c[i])))
+        ok &= (np.abs(r - r[i]) + np.abs(c - c[i])) >= sep
+    k = 0
+    while len(pos) < ng and k < order.size:       # tiny grids: relax the separation rule
+        p = (int(r[k]), int(c[k]))
+        if p not in pos and a[order[k]] > 0:
+            pos.append(p)
+        k += 1
     return np.asfortranarray(np.array(pos, dtype=np.int32).reshape(ng, 2))
 
 

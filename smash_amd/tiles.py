@@ -1,0 +1,100 @@
+"""Domain decomposition of the catchment grid across GPUs.
+
+The grid is cut into Pr x Pc rectangular tiles, one rank (process, GPU) per tile.  Every rank builds the routing
+schedule of its own cells from the *global* flow directions (smashx plan with cfg.tile); a cell whose D8 receiver
+lies in another tile publishes its discharge series, the receiver's tile consumes it as an inlet -- the same
+exchange-series mechanism that links routing groups inside one GPU.  Per pipeline sub-chunk and per tile border
+one message of (edges x steps) floats moves downstream in the forward sweep and upstream (adjoint of the
+boundary discharge) in the reverse sweep: point-to-point send/recv over RCCL (torch.distributed backend "nccl"),
+no collective on the data path.  Gradients stay tile-local; the cost is the sum of per-tile partial costs.
+
+The flow network must make the tile graph acyclic (a river may not leave a tile and come back): true for the
+synthetic E/SE/S catchments; real catchments are cut along sub-catchment borders instead (not built here).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def tile_grid(world: int):
+    """Pr x Pc for 1, 2, 4, 8 ranks (2 x 4 at 8: BASELINE.json configs[4])."""
+    return {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}.get(world) or (1, world)
+
+
+def tile_rect(rank: int, nrow: int, ncol: int, pr: int, pc: int):
+    i, j = divmod(rank, pc)
+    r = [nrow * q // pr for q in range(pr + 1)]
+    c = [ncol * q // pc for q in range(pc + 1)]
+    return (r[i], r[i + 1], c[j], c[j + 1])
+
+
+def owner_of(flat, nrow: int, ncol: int, pr: int, pc: int):
+    """rank owning each flat (row + col*nrow) cell index."""
+    flat = np.asarray(flat, np.int64)
+    row, col = flat % nrow, flat // nrow
+    rb = np.array([nrow * q // pr for q in range(pr + 1)])
+    cb = np.array([ncol * q // pc for q in range(pc + 1)])
+    i = np.searchsorted(rb, row, side="right") - 1
+    j = np.searchsorted(cb, col, side="right") - 1
+    return (i * pc + j).astype(np.int64)
+
+
+class PeerLists:
+    """For one tile: which rows of the out / in message buffers go to / come from which peer rank."""
+
+    def __init__(self, solver, nrow, ncol, pr, pc):
+        out_src, out_dst, in_src, in_dst = solver.halo_edges()
+        self.n_out, self.n_in = len(out_src), len(in_src)
+        o_owner = owner_of(out_dst, nrow, ncol, pr, pc) if self.n_out else np.zeros(0, np.int64)
+        i_owner = owner_of(in_src, nrow, ncol, pr, pc) if self.n_in else np.zeros(0, np.int64)
+        self.out_peers = {int(p): np.flatnonzero(o_owner == p) for p in np.unique(o_owner)}
+        self.in_peers = {int(p): np.flatnonzero(i_owner == p) for p in np.unique(i_owner)}
+        self.out_src, self.out_dst, self.in_src, self.in_dst = out_src, out_dst, in_src, in_dst
+
+
+class TorchDistExchange:
+    """Halo exchange over torch.distributed point-to-point ops (RCCL on GPUs)."""
+
+    def __init__(self, solver, nrow, ncol, pr, pc, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.dev = torch, dist, device
+        self.host_staged = dist.get_backend() != "nccl"     # gloo (rehearsals without RCCL) moves host tensors
+        self.peers = PeerLists(solver, nrow, ncol, pr, pc)
+        _, self.tp = solver.chunking()
+        self.out_buf = torch.zeros(max(self.peers.n_out, 1) * self.tp, dtype=torch.float32, device=device)
+        self.in_buf = torch.zeros(max(self.peers.n_in, 1) * self.tp, dtype=torch.float32, device=device)
+        self.idx_out = {p: torch.from_numpy(ix).to(device) for p, ix in self.peers.out_peers.items()}
+        self.idx_in = {p: torch.from_numpy(ix).to(device) for p, ix in self.peers.in_peers.items()}
+        solver.set_halo(self.out_buf.data_ptr(), self.in_buf.data_ptr(), self)
+
+    def __call__(self, phase, t0, nsteps):
+        torch, dist = self.torch, self.dist
+        w = 4 * ((nsteps + 3) // 4)                       # floats per edge in this sub-chunk
+        # forward: recv on the in edges (0), send on the out edges (1); adjoint: recv on out (2), send on in (3)
+        use_out = phase in (1, 2)
+        buf = self.out_buf if use_out else self.in_buf
+        n = self.peers.n_out if use_out else self.peers.n_in
+        idx = self.idx_out if use_out else self.idx_in
+        view = buf[: n * w].view(n, w)
+        ops, tmps = [], {}
+        mdev = "cpu" if self.host_staged else self.dev
+        for p, ix in idx.items():
+            if phase in (1, 3):
+                tmps[p] = view[ix].contiguous().to(mdev)
+                ops.append(dist.P2POp(dist.isend, tmps[p], p))
+            else:
+                tmps[p] = torch.empty((len(ix), w), dtype=torch.float32, device=mdev)
+                ops.append(dist.P2POp(dist.irecv, tmps[p], p))
+        if ops:
+            if self.host_staged:
+                for r in [op.op(op.tensor, op.peer) for op in ops]:
+                    r.wait()
+            else:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+        if phase in (0, 2):
+            for p, ix in idx.items():
+                view[ix] = tmps[p].to(self.dev)
+        torch.cuda.current_stream().synchronize()
+        return 0

@@ -1,0 +1,124 @@
+"""GPU: the multi-GPU tile path on ONE card.  Each tile of the grid gets its own plan (as each rank would) and
+runs its forward + adjoint sweep in its own thread; the halo callback moves the boundary series between the
+plans through in-process queues instead of RCCL.  Everything else -- per-tile schedules, inlet / outlet
+series, pack / unpack kernels, the four exchange points of the sweep -- is exactly what bench.py --gpus N runs.
+Results must be BIT-IDENTICAL to the single-domain run: the decomposition only changes who computes a cell."""
+import queue
+import threading
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+class Loopback:
+    def __init__(self, rank, solver, nrow, ncol, pr, pc, box):
+        import torch
+        from smash_amd import tiles
+        self.torch, self.rank, self.box = torch, rank, box
+        self.peers = tiles.PeerLists(solver, nrow, ncol, pr, pc)
+        _, self.tp = solver.chunking()
+        self.out_buf = torch.zeros(max(self.peers.n_out, 1) * self.tp, dtype=torch.float32, device="cuda")
+        self.in_buf = torch.zeros(max(self.peers.n_in, 1) * self.tp, dtype=torch.float32, device="cuda")
+        self.calls = 0
+        solver.set_halo(self.out_buf.data_ptr(), self.in_buf.data_ptr(), self)
+
+    def __call__(self, phase, t0, nsteps):
+        torch = self.torch
+        self.calls += 1
+        w = 4 * ((nsteps + 3) // 4)
+        use_out = phase in (1, 2)
+        buf = self.out_buf if use_out else self.in_buf
+        n = self.peers.n_out if use_out else self.peers.n_in
+        idx = self.peers.out_peers if use_out else self.peers.in_peers
+        view = buf[: n * w].view(n, w)
+        kind = "f" if phase < 2 else "a"
+        for p, ix in idx.items():
+            ixt = torch.from_numpy(ix).cuda()
+            if phase in (1, 3):
+                self.box[(self.rank, p, kind)].put((t0, view[ixt].clone()))
+            else:
+                t0_, data = self.box[(p, self.rank, kind)].get(timeout=120)
+                assert t0_ == t0 and data.shape == (len(ix), w)
+                view[ixt] = data
+        torch.cuda.synchronize()
+        return 0
+
+
+def _tile_inputs(g, rect, ng_total):
+    import smash_amd
+    r0, r1, c0, c1 = rect
+    gp = np.asarray(g.mesh.gauge_pos)
+    loc = [i for i in range(g.mesh.ng) if r0 <= gp[i, 0] < r1 and c0 <= gp[i, 1] < c1]
+    setup = smash_amd.SetupDT(0, len(loc), structure=g.structure, dt=g.dt, ntime_step=g.nt)
+    setup.optimize.jobs_fun, setup.optimize.wjobs_fun = ["nse"], [1.0]
+    setup.optimize.wgauge = np.full(len(loc), 1.0 / ng_total, np.float32)
+    mesh = smash_amd.MeshDT(setup, g.mesh.nrow, g.mesh.ncol, len(loc))
+    mesh.dx, mesh.flwdir, mesh.flwacc, mesh.path, mesh.active_cell = g.mesh.dx, g.mesh.flwdir, g.mesh.flwacc, g.mesh.path, g.mesh.active_cell
+    mesh.gauge_pos = np.asfortranarray(gp[loc].reshape(-1, 2)) if loc else np.zeros((0, 2), np.int32, order="F")
+    mesh.area = np.asarray(g.mesh.area)[loc] if loc else np.zeros(0, np.float32)
+    return setup, mesh, loc
+
+
+@pytest.mark.parametrize("world,chunk,pipe", [(2, 0, 16), (4, 32, 16), (8, 0, 32)])
+def test_tiled_sweep_equals_single_domain(world, chunk, pipe):
+    import torch
+    torch.zeros(1, device="cuda")                 # initialise torch's HIP context in the main thread
+    import smash_amd
+    from smash_amd import tiles
+    from smash_amd.solver import Solver
+    from test_gpu_parity import _run_adjoint
+    g = gu.load("gr_b_64x64x720_nse")
+    g.nt = 96                                     # a short window keeps 8 plans on one card cheap
+    g.prcp, g.pet, g.qobs = np.asfortranarray(g.prcp[:, :, :96]), np.asfortranarray(g.pet[:, :, :96]), np.asfortranarray(g.qobs[:, :96])
+    g.opts = {}
+    _, _, ref_out, ref_pb, ref_sb = _run_adjoint(g)
+    pr, pc = tiles.tile_grid(world)
+    nrow, ncol = g.mesh.nrow, g.mesh.ncol
+    box = {(a, b, k): queue.Queue() for a in range(world) for b in range(world) for k in "fa"}
+    res, errs = {}, []
+
+    def run(rank):
+        try:
+            rect = tiles.tile_rect(rank, nrow, ncol, pr, pc)
+            setup, mesh, loc = _tile_inputs(g, rect, g.mesh.ng)
+            sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=128, tile=rect)
+            rows, cols = sol.cell_order()
+            sol.set_forcing(g.prcp, g.pet)
+            if loc:
+                sol.set_qobs(np.asfortranarray(g.qobs[loc]))
+            sol.set_options(setup.optimize)
+            ex = Loopback(rank, sol, nrow, ncol, pr, pc, box)
+            par = smash_amd.ParametersDT.from_dict(mesh, g.params)
+            sta = smash_amd.StatesDT.from_dict(mesh, g.states)
+            out = smash_amd.OutputDT(setup, mesh)
+            pb, sb = par.copy(), sta.copy()
+            sol.upload(par, sta)
+            sol.sweep(True, 1.0)
+            sol.download(True, par, sta, out, pb, sb)
+            res[rank] = (loc, out, pb, sb, rows, cols, ex.calls)
+        except Exception as e:  # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs and len(res) == world
+    cost = 0.0
+    for rank, (loc, out, pb, sb, rows, cols, calls) in res.items():
+        cost += out.cost
+        for i, gi in enumerate(loc):
+            assert np.array_equal(out.qsim[i], ref_out.qsim[gi]), (rank, gi)
+        for k in gu.STRUCT_PARAMS[g.structure]:
+            assert np.array_equal(getattr(pb, k)[rows, cols], getattr(ref_pb, k)[rows, cols]), (rank, k)
+        for k in gu.STRUCT_STATES[g.structure]:
+            assert np.array_equal(getattr(sb, k)[rows, cols], getattr(ref_sb, k)[rows, cols]), (rank, k)
+    assert abs(cost - ref_out.cost) <= 1e-6 * abs(ref_out.cost) + 1e-7
+    assert sum(r[6] for r in res.values()) > 0       # the exchange really ran
