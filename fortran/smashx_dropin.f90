@@ -28,6 +28,7 @@ module smashx_c
         integer(c_int) :: structure, nrow, ncol, nt, ng
         real(c_float) :: dt, dx
         integer(c_int) :: chunk_steps, pipe_steps, group_size, device
+        integer(c_int) :: tile(4)
     end type smashx_config
 
     type, bind(C) :: smashx_mesh
@@ -219,6 +220,7 @@ subroutine smashx_prepare(setup, mesh, input_data)
         cfg%structure = key(1); cfg%nrow = mesh%nrow; cfg%ncol = mesh%ncol; cfg%nt = setup%ntime_step; cfg%ng = mesh%ng
         cfg%dt = setup%dt; cfg%dx = mesh%dx
         cfg%chunk_steps = 0; cfg%pipe_steps = 0; cfg%group_size = 0; cfg%device = -1
+        cfg%tile = 0
         if (allocated(path0)) deallocate (path0)
         if (allocated(gpos0)) deallocate (gpos0)
         allocate (path0(2, mesh%nrow*mesh%ncol), gpos0(max(mesh%ng, 1), 2))

@@ -32,6 +32,33 @@ __device__ __forceinline__ void sx_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// Loads that must be global_load (vmcnt only).  When a pointer is selected between two buffers hipcc loses the
+// address space and emits flat_load, which also counts on lgkmcnt -- the counter the LDS barrier waits on -- so
+// every super-step barrier waited for the staged HBM loads (the routing tail rounds ran at ~2 us per super-step).
+typedef float sx_f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 sx_gload4(const float4* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const sx_f4v v = *(const __attribute__((address_space(1))) sx_f4v*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ float sx_gload1(const float* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(1))) float*)p;
+#else
+    return *p;
+#endif
+}
+
+// "The staged loads of the previous macro-step must have landed HERE": consuming the registers in an opaque asm
+// makes hipcc place its vmcnt wait at this point -- before the next macro-step's loads are issued -- instead of at
+// the first arithmetic use, where the in-order vmcnt(0) would also wait for the loads issued just before it.
+__device__ __forceinline__ void sx_pin(float4& v) {
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : : "memory");
+}
+
 struct SxDeviceArrays {
     // sizes
     int n, npad, nt, Tc;          // Tc = allocated chunk length (multiple of 16)
@@ -183,7 +210,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
 #pragma unroll
     for (int u = 0; u < SX_MU; ++u) {
         const int tb = u - stage;
-        nxt[u] = (valid && tb >= 0 && tb < nb) ? src[(size_t)tb * sstride] : zero4;
+        nxt[u] = (valid && tb >= 0 && tb < nb) ? sx_gload4(src + (size_t)tb * sstride) : zero4;
         outq[u] = zero4; outh[u] = zero4;
     }
     const int nsuper = nb + dmax;
@@ -191,7 +218,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
     for (int mw = 0; mw <= nmacro; ++mw) {
         float4 cur[SX_MU];
 #pragma unroll
-        for (int u = 0; u < SX_MU; ++u) cur[u] = nxt[u];
+        for (int u = 0; u < SX_MU; ++u) { cur[u] = nxt[u]; sx_pin(cur[u]); }
         // results of the previous macro-step leave now
         if (mw > 0 && cell >= 0) {
 #pragma unroll
@@ -214,7 +241,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
             const int tb = SX_MU * (mw + 1) + u - stage;
-            nxt[u] = (valid && tb >= 0 && tb < nb) ? src[(size_t)tb * sstride] : zero4;
+            nxt[u] = (valid && tb >= 0 && tb < nb) ? sx_gload4(src + (size_t)tb * sstride) : zero4;
         }
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
@@ -226,8 +253,16 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
             if (act) {
                 const int tl = tb * SX_BT;           // first step of the block, chunk-local
                 if (cell >= 0) {
-                    float s[SX_BT] = {0.f, 0.f, 0.f, 0.f};
-                    for (int c = 0; c < ccount; ++c) {
+                    // upstream sum in D8 order; the first two children (almost every cell has <= 2) are fetched
+                    // together so their LDS latencies overlap; "+ 0" for an absent child is exact
+                    float s[SX_BT];
+                    {
+                        const float4 v0 = prev[min(cstart, M - 1)], v1 = prev[min(cstart + 1, M - 1)];
+                        const bool h0 = ccount > 0, h1 = ccount > 1;
+                        s[0] = (h0 ? v0.x : 0.f) + (h1 ? v1.x : 0.f); s[1] = (h0 ? v0.y : 0.f) + (h1 ? v1.y : 0.f);
+                        s[2] = (h0 ? v0.z : 0.f) + (h1 ? v1.z : 0.f); s[3] = (h0 ? v0.w : 0.f) + (h1 ? v1.w : 0.f);
+                    }
+                    for (int c = 2; c < ccount; ++c) {
                         const float4 v = prev[cstart + c];
                         s[0] = s[0] + v.x; s[1] = s[1] + v.y; s[2] = s[2] + v.z; s[3] = s[3] + v.w;
                     }
@@ -235,16 +270,17 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
                     float q[SX_BT], hr[SX_BT];
 #pragma unroll
                     for (int i = 0; i < SX_BT; ++i) {
-                        q[i] = 0.f; hr[i] = 0.f;
-                        if (tl + i < T) {
-                            float qup = 0.f;
-                            if (hasup) qup = sx_div(s[i] * dt, dden);
-                            const float hr_imd = hlr + qup;
-                            hlr = hr_imd * a;
-                            const float qrout = hr_imd - hlr;
-                            q[i] = sx_div((qt[i] + qrout * f) * dx * dx * 0.001f, ddt);
-                            hr[i] = hr_imd;
-                        }
+                        // steps beyond T (only in the last block of a chunk) are computed and discarded
+                        const bool live = tl + i < T;
+                        float qup = sx_div(s[i] * dt, dden);
+                        qup = hasup ? qup : 0.f;
+                        const float hr_imd = hlr + qup;
+                        const float hnew = hr_imd * a;
+                        const float qrout = hr_imd - hnew;
+                        q[i] = sx_div((qt[i] + qrout * f) * dx * dx * 0.001f, ddt);
+                        q[i] = live ? q[i] : 0.f;
+                        hr[i] = live ? hr_imd : 0.f;
+                        hlr = live ? hnew : hlr;
                     }
                     const float4 q4 = make_float4(q[0], q[1], q[2], q[3]);
                     pub[j] = q4;
@@ -300,22 +336,40 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool root_in = (cell >= 0 && par < 0 && xout >= 0);   // subtree root fed by an exchange series
 
-    float4 nhr[SX_MU], nin[SX_MU], outq[SX_MU];
+    // gauge cells also fetch their adjoint seeds (qsim_b summed per cell) with the staged loads, so the
+    // super-step loop itself contains no global memory operation and no vmcnt wait
+    const float* seedp = (gid >= 0) ? A.qgb + (size_t)gid * A.nt + t0 : nullptr;
+    auto load_seed = [&](int tb) -> float4 {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gid >= 0) {
+            const int tl = tb * SX_BT;
+            if (tl + 0 < T) v.x = sx_gload1(seedp + tl + 0);
+            if (tl + 1 < T) v.y = sx_gload1(seedp + tl + 1);
+            if (tl + 2 < T) v.z = sx_gload1(seedp + tl + 2);
+            if (tl + 3 < T) v.w = sx_gload1(seedp + tl + 3);
+        }
+        return v;
+    };
+    float4 nhr[SX_MU], nin[SX_MU], nsd[SX_MU], outq[SX_MU];
 #pragma unroll
     for (int u = 0; u < SX_MU; ++u) {
         const int tbr = u - rstage;
         const int tb = nb - 1 - tbr;
         const bool ok = valid && tbr >= 0 && tbr < nb;
-        nhr[u] = (ok && cell >= 0) ? hr4p[(size_t)tb * A.npad + cell] : zero4;
-        nin[u] = (ok && root_in) ? x4[(size_t)tb * A.nx + xout] : zero4;
+        nhr[u] = (ok && cell >= 0) ? sx_gload4(hr4p + (size_t)tb * A.npad + cell) : zero4;
+        nin[u] = (ok && root_in) ? sx_gload4(x4 + (size_t)tb * A.nx + xout) : zero4;
+        nsd[u] = ok ? load_seed(tb) : zero4;
         outq[u] = zero4;
     }
     const int nsuper = nb + dmax;
     const int nmacro = (nsuper + SX_MU - 1) / SX_MU;
     for (int mw = 0; mw <= nmacro; ++mw) {
-        float4 chr[SX_MU], cin[SX_MU];
+        float4 chr[SX_MU], cin[SX_MU], csd[SX_MU];
 #pragma unroll
-        for (int u = 0; u < SX_MU; ++u) { chr[u] = nhr[u]; cin[u] = nin[u]; }
+        for (int u = 0; u < SX_MU; ++u) {
+            chr[u] = nhr[u]; cin[u] = nin[u]; csd[u] = nsd[u];
+            sx_pin(chr[u]); sx_pin(cin[u]); sx_pin(csd[u]);
+        }
         if (mw > 0 && valid) {
 #pragma unroll
             for (int u = 0; u < SX_MU; ++u) {
@@ -333,8 +387,9 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
             const int tbr = SX_MU * (mw + 1) + u - rstage;
             const int tb = nb - 1 - tbr;
             const bool ok = valid && tbr >= 0 && tbr < nb;
-            nhr[u] = (ok && cell >= 0) ? hr4p[(size_t)tb * A.npad + cell] : zero4;
-            nin[u] = (ok && root_in) ? x4[(size_t)tb * A.nx + xout] : zero4;
+            nhr[u] = (ok && cell >= 0) ? sx_gload4(hr4p + (size_t)tb * A.npad + cell) : zero4;
+            nin[u] = (ok && root_in) ? sx_gload4(x4 + (size_t)tb * A.nx + xout) : zero4;
+            nsd[u] = ok ? load_seed(tb) : zero4;
         }
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
@@ -351,24 +406,25 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
                 if (cell >= 0) {
                     const float hrv[SX_BT] = {chr[u].x, chr[u].y, chr[u].z, chr[u].w};
                     const float inv[SX_BT] = {in4.x, in4.y, in4.z, in4.w};
+                    const float sdv[SX_BT] = {csd[u].x, csd[u].y, csd[u].z, csd[u].w};
                     float pb[SX_BT], qtb[SX_BT];
 #pragma unroll
                     for (int i = SX_BT - 1; i >= 0; --i) {
-                        pb[i] = 0.f; qtb[i] = 0.f;
-                        if (tl + i < T) {
-                            float q_b = 0.f;
-                            if (gid >= 0) q_b = q_b + A.qgb[(size_t)gid * A.nt + t0 + tl + i];
-                            q_b = q_b + inv[i];
-                            const float temp_b = sx_div((dx * dx) * 0.001f * q_b, ddt);
-                            const float qrout_b = f * temp_b;
-                            hr_b = hr_b - qrout_b;
-                            const float hr_imd_b = qrout_b + a * hr_b;
-                            const float arg1_b = a * hrv[i] * hr_b;
-                            lr_b = lr_b + sx_div(dt * arg1_b, dlr);
-                            hr_b = hr_imd_b;
-                            if (hasup) pb[i] = sx_div(dt * hr_imd_b, dden);
-                            qtb[i] = temp_b;
-                        }
+                        const bool live = tl + i < T;
+                        float q_b = 0.f;
+                        if (gid >= 0) q_b = q_b + sdv[i];
+                        q_b = q_b + inv[i];
+                        const float temp_b = sx_div((dx * dx) * 0.001f * q_b, ddt);
+                        const float qrout_b = f * temp_b;
+                        const float hb1 = hr_b - qrout_b;
+                        const float hr_imd_b = qrout_b + a * hb1;
+                        const float arg1_b = a * hrv[i] * hb1;
+                        const float lnew = lr_b + sx_div(dt * arg1_b, dlr);
+                        const float pbi = sx_div(dt * hr_imd_b, dden);
+                        lr_b = live ? lnew : lr_b;
+                        hr_b = live ? hr_imd_b : hr_b;
+                        pb[i] = (live && hasup) ? pbi : 0.f;
+                        qtb[i] = live ? temp_b : 0.f;
                     }
                     pub[j] = make_float4(pb[0], pb[1], pb[2], pb[3]);
                     outq[u] = make_float4(qtb[0], qtb[1], qtb[2], qtb[3]);
