@@ -59,6 +59,8 @@ __device__ __forceinline__ void sx_pin(float4& v) {
     asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w) : : "memory");
 }
 
+__device__ __forceinline__ void sx_pin1(float& v) { asm volatile("" : "+v"(v) : : "memory"); }
+
 struct SxDeviceArrays {
     // sizes
     int n, npad, nt, Tc;          // Tc = allocated chunk length (multiple of 16)
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
         for (int i = 0; i < 4; ++i) {
             const int tt = tq * 4 + i;
             if (tt < T) {
-                const float prcp = prcp_n, pet = pet_n;
+                float prcp = prcp_n, pet = pet_n;
+                sx_pin1(prcp); sx_pin1(pet);     // the wait for this step's forcing goes here, before the next loads
                 if (tt + 1 < T) { prcp_n = prcp_p[(size_t)(tt + 1) * npad]; pet_n = pet_p[(size_t)(tt + 1) * npad]; }
                 if (TAPE) {
                     const size_t o = (size_t)tt * npad + k;
@@ -444,8 +447,11 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
 // taped pre-step levels; parameter gradients accumulate per cell in reverse time order like
 // parameters_b%x(row,col) does in the reference (forward_db.f90:8699-8702).
 // ------------------------------------------------------------------------------------------------
+#ifndef SX_VADJ_WAVES
+#define SX_VADJ_WAVES 1
+#endif
 template <int ST>
-__global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
+__global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
     const int k = blockIdx.x * SX_VBLOCK + threadIdx.x;
     if (k >= A.n) return;
     const size_t npad = (size_t)A.npad;
@@ -474,22 +480,27 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj(SxDeviceArrays A, int
     G.hp_b = A.hp_b[k];
     G.hft_b = A.hft_b[k];
     G.hst_b = (ST == 3) ? A.hst_b[k] : 0.f;
-    const float4* qtb = reinterpret_cast<const float4*>(A.qtT) + k;
-    for (int tq = (T - 1) / 4; tq >= 0; --tq) {
-        const float4 q4 = qtb[(size_t)tq * npad];
-        const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
-#pragma unroll
-        for (int i = 3; i >= 0; --i) {
-            const int tt = tq * 4 + i;
-            if (tt < T) {
-                const size_t o = (size_t)tt * npad + k;
-                const float prcp = A.prcp[(size_t)(t0 + tt) * npad + k], pet = A.pet[(size_t)(t0 + tt) * npad + k];
-                const float hi = (ST == 2 || ST == 3) ? A.tape_hi[o] : 0.f;
-                const float hp = A.tape_hp[o], hft = A.tape_hft[o];
-                const float hst = (ST == 3) ? A.tape_hst[o] : 0.f;
-                sx_vertical_step_b<ST>(P, Q, prcp, pet, hi, hp, hft, hst, qv[i], G);
-            }
-        }
+    // one-step-ahead software prefetch of everything a step reads (forcing, taped levels, qt_b)
+    const float* qtb = A.qtT + (size_t)k * 4;
+    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
+    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    float n_prcp = 0.f, n_pet = 0.f, n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
+    auto fetch = [&](int tt) {
+        const size_t o = (size_t)tt * npad;
+        n_prcp = prcp_p[o]; n_pet = pet_p[o];
+        if (ST == 2 || ST == 3) n_hi = A.tape_hi[o + k];
+        n_hp = A.tape_hp[o + k]; n_hft = A.tape_hft[o + k];
+        if (ST == 3) n_hst = A.tape_hst[o + k];
+        n_q = qtb[(size_t)(tt >> 2) * npad * 4 + (tt & 3)];
+    };
+    if (T > 0) fetch(T - 1);
+    for (int tt = T - 1; tt >= 0; --tt) {
+        float prcp = n_prcp, pet = n_pet, hi = n_hi, hp = n_hp, hft = n_hft, hst = n_hst, q = n_q;
+        sx_pin1(prcp); sx_pin1(pet); sx_pin1(hp); sx_pin1(hft); sx_pin1(q);
+        if (ST == 2 || ST == 3) sx_pin1(hi);
+        if (ST == 3) sx_pin1(hst);
+        if (tt > 0) fetch(tt - 1);
+        sx_vertical_step_b<ST>(P, Q, prcp, pet, hi, hp, hft, hst, q, G);
     }
     if (ST == 2 || ST == 3) { A.ci_b[k] = G.ci_b; A.hi_b[k] = G.hi_b; }
     A.cp_b[k] = G.cp_b;

@@ -47,8 +47,10 @@ SX_DEV SxProd sx_production_full(float pn, float en, float cp, float inv_cp, flo
     R.thp = 0.f; R.the = 0.f;
     if (pn > 0.f) R.thp = sx_tanhf(pn * inv_cp);
     if (en > 0.f) R.the = sx_tanhf(en * inv_cp);
-    R.ps = cp * (1.f - hp * hp) * R.thp / (1.f + hp * R.thp);
-    R.es = (hp * cp) * (2.f - hp) * R.the / (1.f + (1.f - hp) * R.the);
+    // with tanh = 0 the quotient is (+-0)/1: skip the division (dry steps: 90 %; nights: 45 %)
+    R.ps = 0.f; R.es = 0.f;
+    if (pn > 0.f) R.ps = cp * (1.f - hp * hp) * R.thp / (1.f + hp * R.thp);
+    if (en > 0.f) R.es = (hp * cp) * (2.f - hp) * R.the / (1.f + (1.f - hp) * R.the);
     R.hp_imd = hp + (R.ps - R.es) * inv_cp;
     if (pn > 0.f) R.pr = pn - (R.hp_imd - hp) * cp;
     const float r = sx_div(R.hp_imd, dbeta);
@@ -162,30 +164,46 @@ SX_DEV void sx_production_b(const SxProd& R, float pn, float& pn_b, float en, fl
         pn_b = 0.f;
     }
     const float es_b = -(inv_cp * hp_imd_b);
-    const float temp4 = the;
-    const SxDiv d3 = sx_mkdiv((-hp + 1.f) * temp4 + 1.f);
-    float temp1 = the;
-    float temp0 = hp * cp * (-hp + 2.f);
-    const float temp_b3 = sx_div(es_b, d3);
-    float temp_b = (2.f - hp) * temp1 * temp_b3;
-    float temp_b0 = -sx_div(temp0 * temp1 * temp_b3, d3);
-    hp_b = hp_b + hp_imd_b + cp * temp_b - hp * cp * temp1 * temp_b3 - temp4 * temp_b0;
     const float ps_b = inv_cp * hp_imd_b;
-    const float temp_b4 = (1.0f - the * the) * temp0 * temp_b3;
-    const float temp_b5 = (1.0f - the * the) * (1.f - hp) * temp_b0;
-    en_b = inv_cp * temp_b5 + inv_cp * temp_b4;
-    cp_b = cp_b + hp * temp_b;
-    const float temp = thp;
-    const SxDiv d0 = sx_mkdiv(hp * temp + 1.f);
-    temp1 = thp;
+    float temp0 = hp * cp * (-hp + 2.f);
+    float temp_b, temp_b0, temp_b4, temp_b5;
+    if (en > 0.f) {
+        const float temp4 = the, temp1 = the;
+        const SxDiv d3 = sx_mkdiv((-hp + 1.f) * temp4 + 1.f);
+        const float temp_b3 = sx_div(es_b, d3);
+        temp_b = (2.f - hp) * temp1 * temp_b3;
+        temp_b0 = -sx_div(temp0 * temp1 * temp_b3, d3);
+        hp_b = hp_b + hp_imd_b + cp * temp_b - hp * cp * temp1 * temp_b3 - temp4 * temp_b0;
+        temp_b4 = (1.0f - the * the) * temp0 * temp_b3;
+        temp_b5 = (1.0f - the * the) * (1.f - hp) * temp_b0;
+        en_b = inv_cp * temp_b5 + inv_cp * temp_b4;
+        cp_b = cp_b + hp * temp_b;
+    } else {
+        // tanh(en/cp) = 0: the general expressions reduce to these exactly (every dropped term is +-0)
+        temp_b4 = temp0 * es_b;
+        temp_b5 = 0.f;
+        hp_b = hp_b + hp_imd_b;
+        en_b = inv_cp * temp_b4;
+    }
+    float temp_b2;
     const float temp2 = cp * (-(hp * hp) + 1.f);
-    temp_b = sx_div(ps_b, d0);
-    temp_b0 = (1.0f - thp * thp) * temp2 * temp_b;
-    const float temp_b1 = -sx_div(temp2 * temp1 * temp_b, d0);
-    hp_b = hp_b + temp * temp_b1 - 2.f * hp * cp * temp1 * temp_b;
-    const float temp_b2 = (1.0f - thp * thp) * hp * temp_b1;
-    inv_cp_b = inv_cp_b + (ps - es) * hp_imd_b + en * temp_b5 + en * temp_b4 + pn * temp_b2 + pn * temp_b0;
-    cp_b = cp_b + (1.f - hp * hp) * temp1 * temp_b - sx_div(inv_cp_b, dcp2);
+    if (pn > 0.f) {
+        const float temp = thp, temp1 = thp;
+        const SxDiv d0 = sx_mkdiv(hp * temp + 1.f);
+        temp_b = sx_div(ps_b, d0);
+        temp_b0 = (1.0f - thp * thp) * temp2 * temp_b;
+        const float temp_b1 = -sx_div(temp2 * temp1 * temp_b, d0);
+        hp_b = hp_b + temp * temp_b1 - 2.f * hp * cp * temp1 * temp_b;
+        temp_b2 = (1.0f - thp * thp) * hp * temp_b1;
+        inv_cp_b = inv_cp_b + (ps - es) * hp_imd_b + en * temp_b5 + en * temp_b4 + pn * temp_b2 + pn * temp_b0;
+        cp_b = cp_b + (1.f - hp * hp) * temp1 * temp_b - sx_div(inv_cp_b, dcp2);
+    } else {
+        // tanh(pn/cp) = 0 and pn = 0
+        temp_b0 = temp2 * ps_b;
+        temp_b2 = 0.f;
+        inv_cp_b = inv_cp_b + (ps - es) * hp_imd_b + en * temp_b5 + en * temp_b4;
+        cp_b = cp_b - sx_div(inv_cp_b, dcp2);
+    }
     pn_b = pn_b + inv_cp * temp_b2 + inv_cp * temp_b0;
 }
 
