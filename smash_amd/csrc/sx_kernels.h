@@ -270,20 +270,28 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
                         s[0] = s[0] + v.x; s[1] = s[1] + v.y; s[2] = s[2] + v.z; s[3] = s[3] + v.w;
                     }
                     const float qt[SX_BT] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
-                    float q[SX_BT], hr[SX_BT];
+                    float q[SX_BT], hr[SX_BT], qup[SX_BT], qro[SX_BT];
+                    // three phases so that only the two-operation store recurrence is serial: the divisions of the
+                    // four steps are independent and overlap (a lone wave pays the full latency of every dependent op)
+#pragma unroll
+                    for (int i = 0; i < SX_BT; ++i) {
+                        const float d = sx_div(s[i] * dt, dden);
+                        qup[i] = hasup ? d : 0.f;
+                    }
 #pragma unroll
                     for (int i = 0; i < SX_BT; ++i) {
                         // steps beyond T (only in the last block of a chunk) are computed and discarded
                         const bool live = tl + i < T;
-                        float qup = sx_div(s[i] * dt, dden);
-                        qup = hasup ? qup : 0.f;
-                        const float hr_imd = hlr + qup;
+                        const float hr_imd = hlr + qup[i];
                         const float hnew = hr_imd * a;
-                        const float qrout = hr_imd - hnew;
-                        q[i] = sx_div((qt[i] + qrout * f) * dx * dx * 0.001f, ddt);
-                        q[i] = live ? q[i] : 0.f;
+                        qro[i] = hr_imd - hnew;
                         hr[i] = live ? hr_imd : 0.f;
                         hlr = live ? hnew : hlr;
+                    }
+#pragma unroll
+                    for (int i = 0; i < SX_BT; ++i) {
+                        const float v = sx_div((qt[i] + qro[i] * f) * dx * dx * 0.001f, ddt);
+                        q[i] = (tl + i < T) ? v : 0.f;
                     }
                     const float4 q4 = make_float4(q[0], q[1], q[2], q[3]);
                     pub[j] = q4;
@@ -411,23 +419,31 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
                     const float inv[SX_BT] = {in4.x, in4.y, in4.z, in4.w};
                     const float sdv[SX_BT] = {csd[u].x, csd[u].y, csd[u].z, csd[u].w};
                     float pb[SX_BT], qtb[SX_BT];
+                    float tmpb[SX_BT], qrb[SX_BT], himb[SX_BT], a1b[SX_BT];
 #pragma unroll
-                    for (int i = SX_BT - 1; i >= 0; --i) {
-                        const bool live = tl + i < T;
+                    for (int i = SX_BT - 1; i >= 0; --i) {          // independent of the carried adjoint state
                         float q_b = 0.f;
                         if (gid >= 0) q_b = q_b + sdv[i];
                         q_b = q_b + inv[i];
-                        const float temp_b = sx_div((dx * dx) * 0.001f * q_b, ddt);
-                        const float qrout_b = f * temp_b;
-                        const float hb1 = hr_b - qrout_b;
-                        const float hr_imd_b = qrout_b + a * hb1;
-                        const float arg1_b = a * hrv[i] * hb1;
-                        const float lnew = lr_b + sx_div(dt * arg1_b, dlr);
-                        const float pbi = sx_div(dt * hr_imd_b, dden);
+                        tmpb[i] = sx_div((dx * dx) * 0.001f * q_b, ddt);
+                        qrb[i] = f * tmpb[i];
+                    }
+#pragma unroll
+                    for (int i = SX_BT - 1; i >= 0; --i) {          // the serial part: hr_b recurrence (3 operations per step)
+                        const bool live = tl + i < T;
+                        const float hb1 = hr_b - qrb[i];
+                        himb[i] = qrb[i] + a * hb1;
+                        a1b[i] = a * hrv[i] * hb1;
+                        hr_b = live ? himb[i] : hr_b;
+                    }
+#pragma unroll
+                    for (int i = SX_BT - 1; i >= 0; --i) {          // lr_b keeps its reverse-time summation order
+                        const bool live = tl + i < T;
+                        const float lnew = lr_b + sx_div(dt * a1b[i], dlr);
+                        const float pbi = sx_div(dt * himb[i], dden);
                         lr_b = live ? lnew : lr_b;
-                        hr_b = live ? hr_imd_b : hr_b;
                         pb[i] = (live && hasup) ? pbi : 0.f;
-                        qtb[i] = live ? temp_b : 0.f;
+                        qtb[i] = live ? tmpb[i] : 0.f;
                     }
                     pub[j] = make_float4(pb[0], pb[1], pb[2], pb[3]);
                     outq[u] = make_float4(qtb[0], qtb[1], qtb[2], qtb[3]);
