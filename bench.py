@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--group", type=int, default=0, help="routing group size (0 = default)")
     ap.add_argument("--ng", type=int, default=8)
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--trace-groups", default="", help="diagnostics: write per-round start/end times of the routing groups (JSON) here")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=192)
     ap.add_argument("--cpu-nt", type=int, default=120)
@@ -135,6 +136,8 @@ def main():
         # every rank must cut time identically (messages are per sub-chunk): fix the lengths instead of sizing from free HBM
         chunk = chunk or ((nt + 15) // 16 * 16 if trows * tcols <= 1100000 else ((nt + 3) // 4 + 15) // 16 * 16)
         pipe = pipe or 1104
+    if a.trace_groups:
+        os.environ["SMASHX_TRACE_GROUPS"] = "1"
     sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=a.group, device=local, tile=rect)
     n = None
     rows, cols = sol.cell_order()
@@ -200,6 +203,21 @@ def main():
         dist.all_reduce(ct, op=dist.ReduceOp.SUM)
         cost = float(ct.item())
 
+    if rank == 0 and a.trace_groups:
+        ticks, rnd = sol.group_times()
+        rep = {}
+        for ps, name in enumerate(("forward", "adjoint")):
+            t = ticks[ps].astype(np.float64) / 100e3          # ms at 100 MHz
+            if not t[:, 0].any():
+                continue
+            o = t[:, 0][t[:, 0] > 0].min()
+            rep[name] = {"span_ms": float(t[:, 1].max() - o), "rounds": [
+                {"round": int(r), "groups": int((rnd == r).sum()),
+                 "first_start_ms": float(t[rnd == r, 0].min() - o), "last_start_ms": float(t[rnd == r, 0].max() - o),
+                 "first_end_ms": float(t[rnd == r, 1].min() - o), "last_end_ms": float(t[rnd == r, 1].max() - o),
+                 "mean_run_ms": float((t[rnd == r, 1] - t[rnd == r, 0]).mean())} for r in np.unique(rnd)]}
+        with open(a.trace_groups, "w") as f:
+            json.dump(rep, f, indent=1)
     if rank == 0:
         K = a.steps
         ms_per_step = secs * 1e3 / K

@@ -174,6 +174,13 @@ int smashx_halo_edges(const smashx_plan* plan, int* out_src, int* out_dst, int* 
 int smashx_plan_chunking(smashx_plan* plan, int* chunk_steps, int* pipe_steps);   /* fixes and returns the chunk lengths */
 int smashx_set_halo(smashx_plan* plan, float* d_out_buf, float* d_in_buf, smashx_halo_fn fn, void* user);
 
+/* ---- diagnostics ---------------------------------------------------------------------------------------
+ * Start / end ticks (100 MHz device wall clock) of every routing group in the last forward (pass 0) and adjoint
+ * (pass 1) routing launches: out[2][groups][2]; round_of_group[groups] may be NULL.  Only recorded when the plan
+ * was created with SMASHX_TRACE_GROUPS=1 in the environment (otherwise SMASHX_E_STATE).  The environment variable
+ * SMASHX_CHAIN_ROUNDS=0 restores one routing launch per round (default: all rounds chained in one launch). */
+int smashx_debug_group_times(smashx_plan* plan, long long* out, int* round_of_group);
+
 #ifdef __cplusplus
 }
 #endif

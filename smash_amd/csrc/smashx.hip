@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -103,6 +104,9 @@ struct smashx_plan {
     hipStream_t stream = nullptr;    // vertical kernels, uploads/downloads ("V stream")
     hipStream_t stream_r = nullptr;  // routing + cost kernels ("R stream"); overlaps the V stream chunk by chunk
     int Tp = 0;                      // pipeline sub-chunk length inside a storage chunk
+    int chain_from = 1;              // first chained round
+    bool chain_used = false;         // a chained launch ran in the current sweep: check the stall flag afterwards
+    bool chain = true;               // all routing rounds in one launch (progress counters), see sx_kernels.h
     // tile boundary exchange
     int n_out = 0, n_in = 0;
     int *d_out_x = nullptr, *d_in_x = nullptr;
@@ -266,24 +270,48 @@ void vert_adj(smashx_plan* p, int off, int t0, int T) {
     }
     p->mark_end();
 }
+// Routing launches of one pass.  Rounds below p->chain_from keep one launch per round (they are wide and
+// HBM-bound); the narrow, latency-bound rounds from chain_from on run chained inside a single launch
+// (sx_kernels.h "rounds chained inside one launch"), which turns their sum into roughly the longest of them.
 void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
     const SxDeviceArrays B = view_at(p, off);
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
-    for (int r = 0; r < p->sch.nrounds; ++r) {
+    const int nr = p->sch.nrounds;
+    const int cf = (p->chain && nr - p->chain_from >= 2) ? p->chain_from : nr;
+    for (int r = 0; r < cf; ++r) {
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
         p->mark_begin(1, p->stream_r);
-        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, t0, T);
-        else      hipLaunchKernelGGL((sx_k_route_fwd<false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, t0, T);
+        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
+        else      hipLaunchKernelGGL((sx_k_route_fwd<false, false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
         p->mark_end();
+    }
+    if (cf < nr) {
+        const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
+        (void)hipMemsetAsync(p->A.prog, 0, (size_t)p->sch.ngroups * sizeof(int), p->stream_r);
+        p->mark_begin(1, p->stream_r);
+        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(g1 - g0), dim3(p->M), lds, p->stream_r, B, g0, g1, t0, T);
+        else      hipLaunchKernelGGL((sx_k_route_fwd<false, true>), dim3(g1 - g0), dim3(p->M), lds, p->stream_r, B, g0, g1, t0, T);
+        p->mark_end();
+        p->chain_used = true;
     }
 }
 void route_adj(smashx_plan* p, int off, int t0, int T) {
     const SxDeviceArrays B = view_at(p, off);
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
-    for (int r = p->sch.nrounds - 1; r >= 0; --r) {
+    const int nr = p->sch.nrounds;
+    const int cf = (p->chain && nr - p->chain_from >= 2) ? p->chain_from : nr;
+    if (cf < nr) {
+        const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
+        (void)hipMemsetAsync(p->A.prog, 0, (size_t)p->sch.ngroups * sizeof(int), p->stream_r);
+        p->mark_begin(2, p->stream_r);
+        hipLaunchKernelGGL((sx_k_route_adj<true>), dim3(g1 - g0), dim3(p->M), lds, p->stream_r, B, g0, g1, t0, T);
+        p->mark_end();
+        p->chain_used = true;
+    }
+    for (int r = cf - 1; r >= 0; --r) {
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
         p->mark_begin(2, p->stream_r);
-        hipLaunchKernelGGL(sx_k_route_adj, dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, t0, T);
+        hipLaunchKernelGGL((sx_k_route_adj<false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
         p->mark_end();
     }
 }
@@ -377,6 +405,24 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     TRY(p->upload_vec(&d6, p->sch.s_ccount)); A.s_ccount = d6;
     TRY(p->upload_vec(&d7, p->sch.s_parent)); A.s_parent = d7;
     TRY(p->upload_vec(&d8, p->sch.s_xout)); A.s_xout = d8;
+    {   // chained rounds (the rounds from SMASHX_CHAIN_FROM, default 1, share one launch); SMASHX_CHAIN_ROUNDS=0
+        // restores the launch-per-round schedule for A/B measurements and bisection
+        int *d9, *d10;
+        TRY(p->upload_vec(&d9, p->sch.x_prod_group)); A.x_prod = d9;
+        TRY(p->upload_vec(&d10, p->sch.x_cons_group)); A.x_cons = d10;
+        TRY(p->dmalloc(&A.prog, (size_t)p->sch.ngroups + 1));
+        A.ngroups = p->sch.ngroups;
+        const char* e = getenv("SMASHX_CHAIN_ROUNDS");
+        p->chain = !(e && e[0] == '0');
+        const char* cfm = getenv("SMASHX_CHAIN_FROM");
+        p->chain_from = cfm ? std::max(0, atoi(cfm)) : 1;
+        A.gtime = nullptr;
+        const char* tr = getenv("SMASHX_TRACE_GROUPS");
+        if (tr && tr[0] == '1') {
+            TRY(p->dmalloc(&A.gtime, (size_t)4 * p->sch.ngroups));
+            if (hipMemset(A.gtime, 0, (size_t)4 * p->sch.ngroups * sizeof(long long)) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipMemset"); }
+        }
+    }
     TRY(p->upload_vec(&p->d_cell_flat, p->sch.cell_flat));
     p->n_out = (int)p->sch.out_x.size(); p->n_in = (int)p->sch.in_x.size();
     TRY(p->upload_vec(&p->d_out_x, p->sch.out_x.empty() ? std::vector<int>(1, 0) : p->sch.out_x));
@@ -584,6 +630,8 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     hipStream_t sV = p->stream, sR = p->stream_r;
     HIPCHK(hipEventRecord(p->ev0, sV));
     HIPCHK(hipStreamWaitEvent(sR, p->ev0, 0));
+    p->chain_used = false;
+    HIPCHK(hipMemsetAsync(p->A.prog + p->sch.ngroups, 0, sizeof(int), sR));   // stall flag of the chained launches
     if ((rc = restore_states(p, p->st0))) return rc;
     const int C = p->nchunks;
     auto nsub_of = [&](int T) { return (T + p->Tp - 1) / p->Tp; };
@@ -702,6 +750,11 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     HIPCHK(hipStreamSynchronize(sV));
     HIPCHK(hipStreamSynchronize(sR));
     HIPCHK(hipGetLastError());
+    if (p->chain_used) {
+        int stalled = 0;
+        HIPCHK(hipMemcpy(&stalled, p->A.prog + p->sch.ngroups, sizeof(int), hipMemcpyDeviceToHost));
+        if (stalled) return fail(SMASHX_E_HIP, "chained routing launch stalled waiting for an upstream group (results invalid); set SMASHX_CHAIN_ROUNDS=0");
+    }
     // timing
     smashx_timing& tm = p->timing;
     std::memset(&tm, 0, sizeof(tm));
@@ -720,6 +773,19 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     tm.n_chunks = p->nchunks; tm.chunk_steps = p->Tc; tm.pipe_steps = p->Tp; tm.n_rounds = p->sch.nrounds; tm.n_groups = p->sch.ngroups;
     tm.device_bytes = p->bytes;
     p->last_adjoint = adjoint;
+    return 0;
+}
+
+// diagnostics: start/end ticks (100 MHz wall clock) of every routing group in the last forward (pass 0) and
+// adjoint (pass 1) routing launches; needs SMASHX_TRACE_GROUPS=1 at plan creation.  out: [2][ngroups][2].
+int smashx_debug_group_times(smashx_plan* p, long long* out, int* round_of_group) {
+    if (!p || !out) return fail(SMASHX_E_ARG, "null argument");
+    if (!p->A.gtime) return fail(SMASHX_E_STATE, "group tracing is off (SMASHX_TRACE_GROUPS=1)");
+    int rc = set_device(p); if (rc) return rc;
+    HIPCHK(hipMemcpy(out, p->A.gtime, (size_t)4 * p->sch.ngroups * sizeof(long long), hipMemcpyDeviceToHost));
+    if (round_of_group)
+        for (int r = 0; r < p->sch.nrounds; ++r)
+            for (int g = p->sch.round_group_begin[r]; g < p->sch.round_group_begin[r + 1]; ++g) round_of_group[g] = r;
     return 0;
 }
 

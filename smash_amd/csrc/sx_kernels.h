@@ -61,6 +61,39 @@ __device__ __forceinline__ void sx_pin(float4& v) {
 
 __device__ __forceinline__ void sx_pin1(float& v) { asm volatile("" : "+v"(v) : : "memory"); }
 
+// ---- rounds chained inside one launch (DESIGN.md "Chained rounds") --------------------------------------
+// A group of round r only needs, for time block b, what the groups of earlier rounds published for block b,
+// so consecutive rounds can run in ONE launch as a wavefront over (round, time): a producer group counts the
+// blocks it has published in prog[g], a consumer polls that counter before it requests a block.
+// Coherence (the 8 XCD L2s are not coherent with each other): the series themselves use ordinary loads and
+// stores -- agent-coherent (sc1) accesses cost ~8 us each on MI355X and stalled every macro-step -- and the
+// counter carries release / acquire at agent scope: every SX_PK macro-steps the producer, once all its waves
+// have drained their stores (vmcnt(0), then the workgroup barrier), writes its L2 back (release fence) and
+// bumps the counter; a consumer that sees the counter move invalidates its caches (acquire fence) before it
+// requests the newly published blocks.
+// Forward progress: workgroups are dispatched in blockIdx order and only ever wait for a lower blockIdx.
+typedef __attribute__((address_space(1))) int sx_gint;
+#ifndef SX_PK
+#define SX_PK 16              // macro-steps between two publications (x SX_MU x SX_BT = 256 time steps); 2..16 measured, fences dominate
+#endif
+#define SX_SPIN_LIMIT (1 << 22)   // polls (~1 us each at least) before a stalled chain is reported instead of hanging
+__device__ __forceinline__ void sx_wait_prog(const int* prog, int need, int& seen, int* stalled) {
+    if (seen >= need) return;
+    int spins = 0;
+    while (seen < need) {
+        seen = __hip_atomic_load((const sx_gint*)prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen < need) {
+            if (++spins > SX_SPIN_LIMIT) { __hip_atomic_store((sx_gint*)stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); seen = 0x7fffffff; break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void sx_publish(int* prog, int blocks) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_store((sx_gint*)prog, blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct SxDeviceArrays {
     // sizes
     int n, npad, nt, Tc;          // Tc = allocated chunk length (multiple of 16)
@@ -85,6 +118,10 @@ struct SxDeviceArrays {
     // schedule
     const int *g_slot_begin, *g_dmax;
     const int *s_cell, *s_stage, *s_cstart, *s_ccount, *s_parent, *s_xout;
+    const int *x_prod, *x_cons;   // per exchange series: publishing group / group holding the inlet (-1: other tile)
+    int* prog;                    // [ngroups + 1] blocks published by each group in the running launch; last = stall flag
+    int ngroups;
+    long long* gtime;             // diagnostics (SMASHX_TRACE_GROUPS=1): [2 passes][ngroups][start, end] wall_clock64 ticks, else null
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -174,14 +211,15 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
 #endif
 #define SX_MAXGROUP 512   // largest routing workgroup (group_size); 8 waves, registers are not the limit
 
-template <bool TAPE>
-__global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, int g0, int t0, int T) {
+template <bool TAPE, bool CHAIN>
+__global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, int g0, int gend, int t0, int T) {
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];   // [2][blockDim.x]
     const int g = g0 + blockIdx.x;
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
     const int j = threadIdx.x, M = blockDim.x;
     const bool valid = j < m;
     const int nb = (T + SX_BT - 1) / SX_BT;
+    if (A.gtime && j == 0) A.gtime[2 * g] = wall_clock64();
 
     int cell = -1, stage = 0, cstart = 0, ccount = 0, xout = -1, xin = -1, gid = -1;
     float a = 0.f, f = 0.f, den = 1.f, hlr = 0.f;
@@ -208,12 +246,18 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
     float4* x4 = reinterpret_cast<float4*>(A.xT);
     float4* hr4 = reinterpret_cast<float4*>(A.hrT);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // chained rounds: an inlet whose series is published inside this launch follows its producer's counter
+    const int* wprog = nullptr;
+    int seen = 0;
+    if (CHAIN && xin >= 0) { const int pg = A.x_prod[xin]; if (pg >= g0 && pg < gend) wprog = A.prog + pg; }
+    auto fetch = [&](int tb) -> float4 { return sx_gload4(src + (size_t)tb * sstride); };
 
     float4 nxt[SX_MU], outq[SX_MU], outh[SX_MU];
+    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - stage, nb), seen, A.prog + A.ngroups);
 #pragma unroll
     for (int u = 0; u < SX_MU; ++u) {
         const int tb = u - stage;
-        nxt[u] = (valid && tb >= 0 && tb < nb) ? sx_gload4(src + (size_t)tb * sstride) : zero4;
+        nxt[u] = (valid && tb >= 0 && tb < nb) ? fetch(tb) : zero4;
         outq[u] = zero4; outh[u] = zero4;
     }
     const int nsuper = nb + dmax;
@@ -222,6 +266,8 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
         float4 cur[SX_MU];
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) { cur[u] = nxt[u]; sx_pin(cur[u]); }
+        // chained: the stores of the previous macro-step (four super-steps old) have completed past this point
+        if (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // results of the previous macro-step leave now
         if (mw > 0 && cell >= 0) {
 #pragma unroll
@@ -241,10 +287,11 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
         }
         if (mw == nmacro) break;
         // inputs of the next macro-step are requested now
+        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - stage, nb), seen, A.prog + A.ngroups);
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
             const int tb = SX_MU * (mw + 1) + u - stage;
-            nxt[u] = (valid && tb >= 0 && tb < nb) ? sx_gload4(src + (size_t)tb * sstride) : zero4;
+            nxt[u] = (valid && tb >= 0 && tb < nb) ? fetch(tb) : zero4;
         }
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
@@ -302,9 +349,18 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
                 }
             }
             sx_lds_barrier();
+            // every wave has passed this macro-step's vmcnt(0): what the roots (stage dmax) stored one macro-step
+            // ago -- blocks below SX_MU (mw-1) - dmax -- has reached L2 and can be released
+            if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0) sx_publish(A.prog + g, done); }
         }
     }
     if (valid && cell >= 0) A.hlr[cell] = hlr;
+    if (A.gtime && j == 0) A.gtime[2 * g + 1] = wall_clock64();
+    if (CHAIN) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j == 0) sx_publish(A.prog + g, nb);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -313,13 +369,16 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
 // Reads hrT (hr_imd of the recomputed forward) and the gauge seeds; writes qt_b over qtT.
 // Same macro-step staging of global memory as the forward kernel.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, int g0, int t0, int T) {
+template <bool CHAIN>
+__global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, int g0, int gend, int t0, int T) {
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];
-    const int g = g0 + blockIdx.x;
+    // chained rounds run roots-of-the-basin first: the producers of adjoint series get the low block indices
+    const int g = CHAIN ? gend - 1 - (int)blockIdx.x : g0 + (int)blockIdx.x;
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
     const int j = threadIdx.x, M = blockDim.x;
     const bool valid = j < m;
     const int nb = (T + SX_BT - 1) / SX_BT;
+    if (A.gtime && j == 0) A.gtime[2 * (A.ngroups + g)] = wall_clock64();
 
     int cell = -1, rstage = 0, par = -1, xout = -1, xin = -1, gid = -1;
     float a = 0.f, f = 0.f, den = 1.f, lr = 1.f, hr_b = 0.f, lr_b = 0.f;
@@ -361,14 +420,20 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
         }
         return v;
     };
+    // chained rounds: a subtree root follows the counter of the group that holds its inlet (a later round)
+    const int* wprog = nullptr;
+    int seen = 0;
+    if (CHAIN && root_in) { const int cg = A.x_cons[xout]; if (cg >= g0 && cg < gend) wprog = A.prog + cg; }
+    auto fetch_in = [&](int tb) -> float4 { return sx_gload4(x4 + (size_t)tb * A.nx + xout); };
     float4 nhr[SX_MU], nin[SX_MU], nsd[SX_MU], outq[SX_MU];
+    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - rstage, nb), seen, A.prog + A.ngroups);
 #pragma unroll
     for (int u = 0; u < SX_MU; ++u) {
         const int tbr = u - rstage;
         const int tb = nb - 1 - tbr;
         const bool ok = valid && tbr >= 0 && tbr < nb;
         nhr[u] = (ok && cell >= 0) ? sx_gload4(hr4p + (size_t)tb * A.npad + cell) : zero4;
-        nin[u] = (ok && root_in) ? sx_gload4(x4 + (size_t)tb * A.nx + xout) : zero4;
+        nin[u] = (ok && root_in) ? fetch_in(tb) : zero4;
         nsd[u] = ok ? load_seed(tb) : zero4;
         outq[u] = zero4;
     }
@@ -381,6 +446,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
             chr[u] = nhr[u]; cin[u] = nin[u]; csd[u] = nsd[u];
             sx_pin(chr[u]); sx_pin(cin[u]); sx_pin(csd[u]);
         }
+        if (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (mw > 0 && valid) {
 #pragma unroll
             for (int u = 0; u < SX_MU; ++u) {
@@ -393,13 +459,14 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
             }
         }
         if (mw == nmacro) break;
+        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - rstage, nb), seen, A.prog + A.ngroups);
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
             const int tbr = SX_MU * (mw + 1) + u - rstage;
             const int tb = nb - 1 - tbr;
             const bool ok = valid && tbr >= 0 && tbr < nb;
             nhr[u] = (ok && cell >= 0) ? sx_gload4(hr4p + (size_t)tb * A.npad + cell) : zero4;
-            nin[u] = (ok && root_in) ? sx_gload4(x4 + (size_t)tb * A.nx + xout) : zero4;
+            nin[u] = (ok && root_in) ? fetch_in(tb) : zero4;
             nsd[u] = ok ? load_seed(tb) : zero4;
         }
 #pragma unroll
@@ -453,9 +520,17 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
                 }
             }
             sx_lds_barrier();
+            // inlet slots sit at reverse stage <= dmax: reverse blocks below SX_MU (mw-1) - dmax are complete
+            if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0) sx_publish(A.prog + g, done); }
         }
     }
     if (valid && cell >= 0) { A.hlr_b[cell] = hr_b; A.lr_b[cell] = lr_b; }
+    if (A.gtime && j == 0) A.gtime[2 * (A.ngroups + g) + 1] = wall_clock64();
+    if (CHAIN) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j == 0) sx_publish(A.prog + g, nb);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

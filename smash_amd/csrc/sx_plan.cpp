@@ -140,6 +140,8 @@ int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_c
     std::vector<int> k_of_a(n, -1);
     int knext = 0;
     s.max_stage = 0;
+    s.x_prod_group.assign(std::max(nx, 1), -1);
+    s.x_cons_group.assign(std::max(nx, 1), -1);
     std::vector<int> q_node, q_par, q_depth;   // BFS queue: node (>=0 cell a, <0 inlet of cell -1-a), local parent, depth
     for (int r = 0; r < s.nrounds; ++r) {
         for (auto& g : round_groups[r]) {
@@ -172,6 +174,9 @@ int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_c
                 s.s_ccount.push_back(ccount[i]);
                 s.s_parent.push_back(q_par[i]);
                 s.s_xout.push_back((node >= 0 && q_par[i] < 0) ? xslot_of[node] : -1);
+                const int gi = (int)s.g_slot_begin.size() - 1;
+                if (node >= 0 && q_par[i] < 0 && xslot_of[node] >= 0) s.x_prod_group[xslot_of[node]] = gi;
+                if (node < 0) s.x_cons_group[xslot_of[-1 - node]] = gi;
             }
             s.g_slot_begin.push_back((int)s.s_cell.size());
         }

@@ -32,6 +32,9 @@ struct SxSchedule {
     std::vector<int> s_parent;   // group-local index of the parent, -1 for a subtree root
     std::vector<int> s_xout;     // subtree roots: exchange series id they publish, else -1
     std::vector<int> gauge_k;    // ng: device cell of every gauge
+    // per exchange series: the group whose subtree root publishes it / the group holding its inlet slot
+    // (-1: the other end lives in another tile).  Lets consecutive rounds run inside one launch.
+    std::vector<int> x_prod_group, x_cons_group;
     // tile decomposition (multi-GPU): discharge series that cross the tile boundary, sorted by source cell
     std::vector<int> out_x, out_src, out_dst;   // series this tile publishes for a receiver in another tile (flat indices)
     std::vector<int> in_x, in_src, in_dst;      // series this tile needs from a cell in another tile

@@ -117,6 +117,14 @@ class Solver:
         _lib.check(_lib.lib().smashx_plan_chunking(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def group_times(self):
+        """Diagnostics (SMASHX_TRACE_GROUPS=1): (ticks[2][groups][2] at 100 MHz, round_of_group[groups])."""
+        ng = self.timing()["n_groups"]
+        out = np.zeros((2, ng, 2), np.int64)
+        rnd = np.zeros(ng, np.int32)
+        _lib.check(_lib.lib().smashx_debug_group_times(self._h, out.ctypes.data_as(C.POINTER(C.c_longlong)), _ptr(rnd)))
+        return out, rnd
+
     def set_halo(self, out_ptr, in_ptr, fn):
         """fn(phase, t0, nsteps) -> 0; out_ptr / in_ptr: device addresses of the message buffers."""
         def tramp(user, phase, t0, nsteps):
