@@ -180,6 +180,10 @@ int smashx_set_halo(smashx_plan* plan, float* d_out_buf, float* d_in_buf, smashx
  * was created with SMASHX_TRACE_GROUPS=1 in the environment (otherwise SMASHX_E_STATE).  The environment variable
  * SMASHX_CHAIN_ROUNDS=0 restores one routing launch per round (default: all rounds chained in one launch). */
 int smashx_debug_group_times(smashx_plan* plan, long long* out, int* round_of_group);
+/* Device self-test of the 6-instruction division the kernels use for per-step denominators (sx_math.h sx_fdiv)
+ * against the IEEE quotient on n pseudo-random pairs, b in [blo, bhi): out[0] = mismatching calls, out[1] = of
+ * those, off by more than one ulp. */
+int smashx_selftest_math(int device, long long n, unsigned seed, float blo, float bhi, long long* out);
 
 #ifdef __cplusplus
 }

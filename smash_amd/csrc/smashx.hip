@@ -86,6 +86,24 @@ __global__ void k_halo_unpack(float4* x4, const float4* buf, const int* slots, i
     x4[(size_t)tb * nx + slots[e]] = buf[(size_t)e * Tq + tb];
 }
 
+// self-test of sx_fdiv against the IEEE division on pseudo-random operands: a = +-2^[-20,10) x [1,2), b in [blo, bhi)
+__global__ void k_selftest_div(unsigned long long n, unsigned seed, float blo, float bhi, unsigned long long* out) {
+    unsigned long long bad = 0, bad2 = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long h = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 29;
+        const unsigned m1 = (unsigned)h & 0x7fffffu, m2 = (unsigned)(h >> 23) & 0x7fffffu;
+        const int e1 = (int)((h >> 46) % 30) - 20;
+        const float a0 = ldexpf(__uint_as_float(0x3f800000u | m1), e1);
+        const float a = ((h >> 63) & 1) ? -a0 : a0;
+        const float b = blo + (bhi - blo) * ((float)m2 * (1.0f / 8388608.0f));
+        const float q = sx_fdiv(a, b), ref = a / b;
+        if (q != ref) { ++bad; if (fabsf(q - ref) > fabsf(ref) * 2.4e-7f) ++bad2; }
+    }
+    if (bad) atomicAdd(out, bad);
+    if (bad2) atomicAdd(out + 1, bad2);
+}
+
 struct Launch { hipEvent_t a, b; int kind; };
 
 }  // namespace
@@ -786,6 +804,23 @@ int smashx_debug_group_times(smashx_plan* p, long long* out, int* round_of_group
     if (round_of_group)
         for (int r = 0; r < p->sch.nrounds; ++r)
             for (int g = p->sch.round_group_begin[r]; g < p->sch.round_group_begin[r + 1]; ++g) round_of_group[g] = r;
+    return 0;
+}
+
+// device self-test: counts calls where sx_fdiv (sx_math.h) differs from the IEEE quotient a/b for n pseudo-random
+// operand pairs with b in [blo, bhi); out[0] = mismatches, out[1] = mismatches larger than one ulp.
+int smashx_selftest_math(int device, long long n, unsigned seed, float blo, float bhi, long long* out) {
+    if (!out || n <= 0) return fail(SMASHX_E_ARG, "bad argument");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_selftest_div, dim3(2048), dim3(256), 0, 0, (unsigned long long)n, seed, blo, bhi, d);
+    unsigned long long h[2] = {0, 0};
+    hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(SMASHX_E_HIP, hipGetErrorString(e));
+    out[0] = (long long)h[0]; out[1] = (long long)h[1];
     return 0;
 }
 

@@ -76,6 +76,33 @@ SX_HD float sx_div(float a, const SxDiv& D) {
     return fmaf(e, D.r, q);
 }
 
+// Division by a denominator that changes every step (1 + hp*tanh, the two quotients inside tanh).  hipcc expands
+// a/b into the 11-instruction IEEE sequence (two v_div_scale, v_rcp, four fma, v_div_fmas, v_div_fixup); the
+// operands here are always in the normal range, so the same Markstein correction as sx_div works on a reciprocal
+// refined by one Newton step from the 1-ulp hardware seed: r = RN(1/b) unless 1/b lies within 2^-46 of a rounding
+// boundary, and then q is the correctly rounded quotient.  6 instructions; mismatches against a/b are counted on
+// the device by smashx_selftest_math (tests/test_gpu_parity.py: < 1e-6 of calls, 1 ulp).
+SX_HD float sx_fdiv(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r = __builtin_amdgcn_rcpf(b);
+    r = fmaf(fmaf(-b, r, 1.0f), r, r);
+    const float q = a * r;
+    return fmaf(fmaf(-b, q, a), r, q);
+#else
+    return a / b;
+#endif
+}
+SX_HD SxDiv sx_mkdiv_fast(float d) {
+    SxDiv D; D.d = d;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(d);
+    D.r = fmaf(fmaf(-d, r, 1.0f), r, r);
+#else
+    D.r = 1.0f / d;
+#endif
+    return D;
+}
+
 // 1/x in fp64 to ~2^-45 from an fp32 seed: one Newton step  u <- u + u(1 - x u)
 SX_HD double sx_rcp_d(float x) {
     const double d = (double)x;
@@ -166,7 +193,7 @@ SX_HD float sx_expm1f(float x) {
     hxs = x * hfx;
     r1 = one + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
     t = 3.0f - r1 * hfx;
-    e = hxs * ((r1 - t) / (6.0f - x * t));
+    e = hxs * sx_fdiv(r1 - t, 6.0f - x * t);
     if (k == 0) return x - (x * e - hxs);
     e = (x * (e - c) - c);
     e -= hxs;
@@ -200,8 +227,8 @@ SX_HD float sx_tanhf(float x) {
         if (ix == 0) return x;
         if (ix < 0x24000000u) return x * (1.0f + x);
         const float ax = sx_u2f(ix);
-        if (ix >= 0x3f800000u) { t = sx_expm1f(2.0f * ax); z = 1.0f - 2.0f / (t + 2.0f); }
-        else                   { t = sx_expm1f(-2.0f * ax); z = -t / (t + 2.0f); }
+        if (ix >= 0x3f800000u) { t = sx_expm1f(2.0f * ax); z = 1.0f - sx_fdiv(2.0f, t + 2.0f); }
+        else                   { t = sx_expm1f(-2.0f * ax); z = sx_fdiv(-t, t + 2.0f); }
     } else {
         z = 1.0f - 1e-30f;
     }

@@ -49,8 +49,8 @@ SX_DEV SxProd sx_production_full(float pn, float en, float cp, float inv_cp, flo
     if (en > 0.f) R.the = sx_tanhf(en * inv_cp);
     // with tanh = 0 the quotient is (+-0)/1: skip the division (dry steps: 90 %; nights: 45 %)
     R.ps = 0.f; R.es = 0.f;
-    if (pn > 0.f) R.ps = cp * (1.f - hp * hp) * R.thp / (1.f + hp * R.thp);
-    if (en > 0.f) R.es = (hp * cp) * (2.f - hp) * R.the / (1.f + (1.f - hp) * R.the);
+    if (pn > 0.f) R.ps = sx_fdiv(cp * (1.f - hp * hp) * R.thp, 1.f + hp * R.thp);
+    if (en > 0.f) R.es = sx_fdiv((hp * cp) * (2.f - hp) * R.the, 1.f + (1.f - hp) * R.the);
     R.hp_imd = hp + (R.ps - R.es) * inv_cp;
     if (pn > 0.f) R.pr = pn - (R.hp_imd - hp) * cp;
     const float r = sx_div(R.hp_imd, dbeta);
@@ -169,7 +169,7 @@ SX_DEV void sx_production_b(const SxProd& R, float pn, float& pn_b, float en, fl
     float temp_b, temp_b0, temp_b4, temp_b5;
     if (en > 0.f) {
         const float temp4 = the, temp1 = the;
-        const SxDiv d3 = sx_mkdiv((-hp + 1.f) * temp4 + 1.f);
+        const SxDiv d3 = sx_mkdiv_fast((-hp + 1.f) * temp4 + 1.f);
         const float temp_b3 = sx_div(es_b, d3);
         temp_b = (2.f - hp) * temp1 * temp_b3;
         temp_b0 = -sx_div(temp0 * temp1 * temp_b3, d3);
@@ -189,7 +189,7 @@ SX_DEV void sx_production_b(const SxProd& R, float pn, float& pn_b, float en, fl
     const float temp2 = cp * (-(hp * hp) + 1.f);
     if (pn > 0.f) {
         const float temp = thp, temp1 = thp;
-        const SxDiv d0 = sx_mkdiv(hp * temp + 1.f);
+        const SxDiv d0 = sx_mkdiv_fast(hp * temp + 1.f);
         temp_b = sx_div(ps_b, d0);
         temp_b0 = (1.0f - thp * thp) * temp2 * temp_b;
         const float temp_b1 = -sx_div(temp2 * temp1 * temp_b, d0);

@@ -160,3 +160,20 @@ def test_unsupported_options_fail_loudly():
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+@pytest.mark.parametrize("blo,bhi", [(1.0, 2.0), (1.0, 4.0), (5.0, 7.0)])
+def test_device_division_matches_ieee(blo, bhi):
+    """sx_fdiv (6 instructions) against hipcc's IEEE a/b on the denominators the kernels feed it:
+    1 + h*tanh in [1, 2], t + 2 in [1, 4], 6 - x*t near 6.  Never off by more than one ulp, and the
+    one-ulp cases must be rarer than the ~1.5e-3 of calls where the correctly rounded powf already
+    differs from glibc (tests/test_sx_math.py)."""
+    import ctypes as C
+    from smash_amd import _lib
+    n = 200_000_000
+    out = (C.c_longlong * 2)()
+    fn = _lib.lib().smashx_selftest_math
+    fn.argtypes = [C.c_int, C.c_longlong, C.c_uint, C.c_float, C.c_float, C.POINTER(C.c_longlong)]
+    _lib.check(fn(0, n, 12345, blo, bhi, out))
+    assert out[1] == 0
+    assert out[0] <= n * 1e-6, (out[0], n)
