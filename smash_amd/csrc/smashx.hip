@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "sx_cost.h"
+#include "sx_jreg.h"
 #include "sx_kernels.h"
 #include "sx_plan.h"
 
@@ -150,6 +151,18 @@ struct smashx_plan {
     float *d_area = nullptr, *d_wgauge = nullptr, *d_qobs = nullptr, *d_qsim_b = nullptr, *d_cost_out = nullptr;
     SxGaugeSums* d_sums = nullptr; SxCostCoef* d_coef = nullptr;
     float jobs = 0.f;
+    // regularisation (sx_jreg.h): planes 0..15 = parameters, 16..23 = states
+    bool tiled = false;
+    int* d_active = nullptr;
+    hipStream_t stream_j = nullptr;
+    hipEvent_t ev_j = nullptr;
+    float* d_jx[SMASHX_GNP + SMASHX_GNS] = {nullptr};     // values as compute_cost sees them (normalised when denormalize_forward)
+    float* d_jb[SMASHX_GNP + SMASHX_GNS] = {nullptr};     // background
+    float* d_jg[SMASHX_GNP + SMASHX_GNS] = {nullptr};     // d(wjreg jreg)/d(field): what COMPUTE_COST_B leaves in parameters_b / states_b
+    float* d_jterm = nullptr; size_t jterm_planes = 0;
+    float* d_jsum = nullptr;
+    SxJregChains jchains{};
+    bool jr_ready = false;                                 // planes of the current upload are on the device
     // timing
     std::vector<Launch> launches;
     std::vector<hipEvent_t> pool; size_t pool_used = 0;
@@ -405,12 +418,14 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     const int rc0 = sx_build_schedule(cfg->nrow, cfg->ncol, mesh->flwdir, mesh->active_cell, cfg->ng, mesh->gauge_pos, p->M,
                                       tiled ? cfg->tile : nullptr, p->sch);
     if (rc0 != 0) { std::string e = p->sch.error; delete p; return fail(rc0 == -5 ? SMASHX_E_MESH : SMASHX_E_ARG, e); }
+    p->tiled = tiled;
     p->n = p->sch.n; p->npad = (p->n + SX_VBLOCK - 1) / SX_VBLOCK * SX_VBLOCK;
     p->nt = cfg->nt; p->ng = cfg->ng; p->st = cfg->structure; p->n2 = (long)cfg->nrow * cfg->ncol;
     int rc = 0;
 #define TRY(x) do { rc = (x); if (rc) { smashx_plan_destroy(p); return rc; } } while (0)
     if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->stream_r) != hipSuccess) { delete p; return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
     (void)hipEventCreate(&p->ev0); (void)hipEventCreate(&p->ev1);
+    if (hipStreamCreate(&p->stream_j) != hipSuccess || hipEventCreate(&p->ev_j) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
     SxDeviceArrays& A = p->A;
     A.n = p->n; A.npad = p->npad; A.nt = p->nt; A.dt = cfg->dt; A.dx = cfg->dx; A.Tc = 0;
     // schedule tables
@@ -442,6 +457,8 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         }
     }
     TRY(p->upload_vec(&p->d_cell_flat, p->sch.cell_flat));
+    TRY(p->upload_vec(&p->d_active, std::vector<int>(mesh->active_cell, mesh->active_cell + p->n2)));
+    TRY(p->dmalloc(&p->d_jsum, (size_t)SX_JREG_MAXCHAIN));
     p->n_out = (int)p->sch.out_x.size(); p->n_in = (int)p->sch.in_x.size();
     TRY(p->upload_vec(&p->d_out_x, p->sch.out_x.empty() ? std::vector<int>(1, 0) : p->sch.out_x));
     TRY(p->upload_vec(&p->d_in_x, p->sch.in_x.empty() ? std::vector<int>(1, 0) : p->sch.in_x));
@@ -519,6 +536,8 @@ int smashx_plan_destroy(smashx_plan* p) {
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->stream) (void)hipStreamDestroy(p->stream);
     if (p->stream_r) (void)hipStreamDestroy(p->stream_r);
+    if (p->stream_j) { (void)hipStreamSynchronize(p->stream_j); (void)hipStreamDestroy(p->stream_j); }
+    if (p->ev_j) (void)hipEventDestroy(p->ev_j);
     delete p;
     return 0;
 }
@@ -591,8 +610,13 @@ int smashx_set_options(smashx_plan* p, const smashx_options* o) {
     for (int j = 0; j < o->njf; ++j)
         if (o->jobs_fun[j] < SMASHX_NSE || o->jobs_fun[j] > SMASHX_LOGARITHMIC)
             return fail(SMASHX_E_UNSUPPORTED, "signature-based jobs_fun are outside the hot path (SURVEY.md 8a a9)");
-    if (o->njr > 0) return fail(SMASHX_E_UNSUPPORTED, "jreg (prior/smoothing) is row f2 of SURVEY.md 8f: not built yet");
+    for (int j = 0; j < o->njr; ++j)
+        if (o->jreg_fun[j] < SMASHX_PRIOR || o->jreg_fun[j] > SMASHX_HARD_SMOOTHING)
+            return fail(SMASHX_E_UNSUPPORTED, "unknown jreg_fun (prior / smoothing / hard_smoothing, mwd_cost.f90:199-224)");
+    if (o->njr > 0 && p->tiled)
+        return fail(SMASHX_E_UNSUPPORTED, "jreg on a tiled plan: the regulariser is one ordered sum over the whole grid; evaluate it on an untiled plan");
     p->opt = *o;
+    p->jr_ready = false;
     p->opt.wgauge = nullptr;
     for (int g = 0; g < p->ng; ++g) {
         const float w = o->wgauge ? o->wgauge[g] : 1.f / p->ng;
@@ -604,9 +628,74 @@ int smashx_set_options(smashx_plan* p, const smashx_options* o) {
     return 0;
 }
 
+namespace {
+int jreg_optim(const smashx_plan* p, int idx) {
+    return idx < SMASHX_GNP ? p->opt.optim_parameters[idx] : p->opt.optim_states[idx - SMASHX_GNP];
+}
+float jreg_span(const smashx_plan* p, int idx) {
+    return idx < SMASHX_GNP ? p->opt.ub_parameters[idx] - p->opt.lb_parameters[idx]
+                            : p->opt.ub_states[idx - SMASHX_GNP] - p->opt.lb_states[idx - SMASHX_GNP];
+}
+// compute_jreg (and COMPUTE_JREG_B when adjoint) on the regularisation stream: independent of the simulation
+int run_jreg(smashx_plan* p, int adjoint, float cost_b) {
+    if (!p->jr_ready) return fail(SMASHX_E_STATE, "jreg is on but the current upload carried no background fields");
+    hipStream_t sJ = p->stream_j;
+    const dim3 b(256), gfull((unsigned)((p->n2 + 255) / 256));
+    const int nrow = p->cfg.nrow, ncol = p->cfg.ncol;
+    SxJregChains& ch = p->jchains;
+    ch.nchain = 2 * p->opt.njr;
+    long planes = 0;
+    for (int i = 0; i < p->opt.njr; ++i)
+        for (int grp = 0; grp < 2; ++grp) {
+            const int c = 2 * i + grp, lo = grp ? SMASHX_GNP : 0, hi = grp ? SMASHX_GNP + SMASHX_GNS : SMASHX_GNP;
+            ch.first[c] = planes; ch.nplane[c] = 0;
+            for (int idx = lo; idx < hi; ++idx) if (jreg_optim(p, idx) > 0) { ch.nplane[c]++; planes++; }
+        }
+    if ((size_t)planes > p->jterm_planes) {
+        int rc = p->dmalloc(&p->d_jterm, (size_t)planes * p->n2); if (rc) return rc;   // (the smaller buffer stays owned by the plan)
+        p->jterm_planes = (size_t)planes;
+    }
+    for (int i = 0; i < p->opt.njr; ++i)
+        for (int grp = 0; grp < 2; ++grp) {
+            const int c = 2 * i + grp, lo = grp ? SMASHX_GNP : 0, hi = grp ? SMASHX_GNP + SMASHX_GNS : SMASHX_GNP;
+            long slot = ch.first[c];
+            for (int idx = lo; idx < hi; ++idx) {
+                if (jreg_optim(p, idx) <= 0) continue;
+                float* t = p->d_jterm + (size_t)slot++ * p->n2;
+                if (p->opt.jreg_fun[i] == SMASHX_PRIOR)
+                    hipLaunchKernelGGL(sx_k_prior_terms, gfull, b, 0, sJ, t, p->d_jx[idx], p->d_jb[idx], p->n2);
+                else
+                    hipLaunchKernelGGL(sx_k_smooth_terms, gfull, b, 0, sJ, t, p->d_jx[idx], p->d_jb[idx],
+                                       p->opt.jreg_fun[i] == SMASHX_SMOOTHING ? 1 : 0, p->d_active, nrow, ncol);
+            }
+        }
+    hipLaunchKernelGGL(sx_k_seq_sum, dim3(ch.nchain), dim3(64), 0, sJ, p->d_jterm, ch, p->n2, p->d_jsum);
+    if (adjoint) {
+        const float jreg_b = p->opt.wjreg * cost_b;                       // COMPUTE_COST_B: cost = jobs + wjreg * jreg
+        for (int idx = 0; idx < SMASHX_GNP + SMASHX_GNS; ++idx)
+            if (jreg_optim(p, idx) > 0) HIPCHK(hipMemsetAsync(p->d_jg[idx], 0, (size_t)p->n2 * 4, sJ));
+        for (int i = p->opt.njr - 1; i >= 0; --i) {
+            const float w = p->opt.wjreg_fun[i];
+            const bool prior = p->opt.jreg_fun[i] == SMASHX_PRIOR;
+            const float res_b = prior ? w * jreg_b : (w * w) * jreg_b;    // wjreg_fun(i)**2 for the smoothing terms
+            for (int idx = SMASHX_GNP + SMASHX_GNS - 1; idx >= 0; --idx) {
+                if (jreg_optim(p, idx) <= 0) continue;
+                if (prior) hipLaunchKernelGGL(sx_k_prior_b, gfull, b, 0, sJ, p->d_jg[idx], p->d_jx[idx], p->d_jb[idx], res_b, p->n2);
+                else hipLaunchKernelGGL(sx_k_smooth_b, gfull, b, 0, sJ, p->d_jg[idx], p->d_jx[idx], p->d_jb[idx],
+                                        p->opt.jreg_fun[i] == SMASHX_SMOOTHING ? 1 : 0, p->d_active, nrow, ncol, res_b);
+            }
+        }
+        if (p->opt.denormalize_forward)
+            for (int idx = 0; idx < SMASHX_GNP + SMASHX_GNS; ++idx)
+                if (jreg_optim(p, idx) > 0) hipLaunchKernelGGL(sx_k_plane_div, gfull, b, 0, sJ, p->d_jg[idx], jreg_span(p, idx), p->n2);
+    }
+    HIPCHK(hipEventRecord(p->ev_j, sJ));
+    return 0;
+}
+}  // namespace
+
 int smashx_upload(smashx_plan* p, const smashx_parameters* params, const smashx_parameters* params_bgd,
                   const smashx_states* states, const smashx_states* states_bgd) {
-    (void)params_bgd; (void)states_bgd;   // only read by jreg (not built yet)
     if (!p || !params || !states) return fail(SMASHX_E_ARG, "null argument");
     int rc = set_device(p); if (rc) return rc;
     const int st = p->st;
@@ -631,6 +720,33 @@ int smashx_upload(smashx_plan* p, const smashx_parameters* params, const smashx_
         hipLaunchKernelGGL(k_gather, gk, b, 0, p->stream, p->st0[i], p->d_fullS[f], p->d_cell_flat, p->n);
     }
     hipLaunchKernelGGL(sx_k_prep_routing, gk, b, 0, p->stream, p->A);
+    p->jr_ready = false;
+    if (p->opt.njr > 0) {
+        // compute_jreg reads the control vector as compute_cost holds it: normalised again after the forward run
+        // when denormalize_forward is set (mwd_cost.f90:284-291), plus the background fields
+        if (!params_bgd || !states_bgd) return fail(SMASHX_E_ARG, "jreg needs parameters_bgd and states_bgd");
+        for (int idx = 0; idx < SMASHX_GNP + SMASHX_GNS; ++idx) {
+            if (jreg_optim(p, idx) <= 0) continue;
+            const bool isp = idx < SMASHX_GNP;
+            const float* h = isp ? params->f[idx] : states->f[idx - SMASHX_GNP];
+            const float* hb = isp ? params_bgd->f[idx] : states_bgd->f[idx - SMASHX_GNP];
+            if (!h || !hb) return fail(SMASHX_E_ARG, "an optimised field (optim_parameters / optim_states) or its background is NULL");
+            if (!p->d_jx[idx]) {
+                if ((rc = p->dmalloc(&p->d_jx[idx], (size_t)p->n2))) return rc;
+                if ((rc = p->dmalloc(&p->d_jb[idx], (size_t)p->n2))) return rc;
+                if ((rc = p->dmalloc(&p->d_jg[idx], (size_t)p->n2))) return rc;
+            }
+            const float lb = isp ? p->opt.lb_parameters[idx] : p->opt.lb_states[idx - SMASHX_GNP];
+            const float ub = isp ? p->opt.ub_parameters[idx] : p->opt.ub_states[idx - SMASHX_GNP];
+            HIPCHK(hipMemcpyAsync(p->d_jx[idx], h, (size_t)p->n2 * 4, hipMemcpyHostToDevice, p->stream));
+            if (p->opt.denormalize_forward) {
+                hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_jx[idx], p->n2, lb, ub);
+                hipLaunchKernelGGL(k_normalize, gfull, b, 0, p->stream, p->d_jx[idx], p->n2, lb, ub);
+            }
+            HIPCHK(hipMemcpyAsync(p->d_jb[idx], hb, (size_t)p->n2 * 4, hipMemcpyHostToDevice, p->stream));
+        }
+        p->jr_ready = true;
+    }
     HIPCHK(hipStreamSynchronize(p->stream));
     HIPCHK(hipGetLastError());
     p->uploaded = true;
@@ -650,6 +766,10 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     HIPCHK(hipStreamWaitEvent(sR, p->ev0, 0));
     p->chain_used = false;
     HIPCHK(hipMemsetAsync(p->A.prog + p->sch.ngroups, 0, sizeof(int), sR));   // stall flag of the chained launches
+    if (p->opt.njr > 0) {
+        HIPCHK(hipStreamWaitEvent(p->stream_j, p->ev0, 0));
+        if ((rc = run_jreg(p, adjoint, cost_b))) return rc;
+    }
     if ((rc = restore_states(p, p->st0))) return rc;
     const int C = p->nchunks;
     auto nsub_of = [&](int T) { return (T + p->Tp - 1) / p->Tp; };
@@ -726,10 +846,23 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
             if ((rc = forward_chunk(c, C == 1))) return rc;
         }
         if ((rc = run_cost(p, 1, cost_b))) return rc;
-        float* gv[9] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b};
-        for (auto q : gv) HIPCHK(hipMemsetAsync(q, 0, (size_t)p->npad * 4, sV));
-        HIPCHK(hipMemsetAsync(p->A.lr_b, 0, (size_t)p->npad * 4, sR));
-        HIPCHK(hipMemsetAsync(p->A.hlr_b, 0, (size_t)p->npad * 4, sR));
+        {   // gradient accumulators start from what COMPUTE_COST_B left in parameters_b / states_b: zero, or the
+            // regulariser's gradient for the optimised fields (forward_db.f90:10869-10874)
+            float* gv[11] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b,
+                             p->A.lr_b, p->A.hlr_b};
+            const int gi[11] = {SMASHX_P_CI, SMASHX_P_CP, SMASHX_P_CFT, SMASHX_P_CST, SMASHX_P_EXC, SMASHX_GNP + SMASHX_S_HI,
+                                SMASHX_GNP + SMASHX_S_HP, SMASHX_GNP + SMASHX_S_HFT, SMASHX_GNP + SMASHX_S_HST, SMASHX_P_LR,
+                                SMASHX_GNP + SMASHX_S_HLR};
+            bool waited[2] = {false, false};
+            for (int q = 0; q < 11; ++q) {
+                hipStream_t sq = q < 9 ? sV : sR;
+                HIPCHK(hipMemsetAsync(gv[q], 0, (size_t)p->npad * 4, sq));
+                if (p->opt.njr > 0 && jreg_optim(p, gi[q]) > 0) {
+                    if (!waited[q < 9 ? 0 : 1]) { HIPCHK(hipStreamWaitEvent(sq, p->ev_j, 0)); waited[q < 9 ? 0 : 1] = true; }
+                    hipLaunchKernelGGL(k_gather, dim3((p->n + 255) / 256), dim3(256), 0, sq, gv[q], p->d_jg[gi[q]], p->d_cell_flat, p->n);
+                }
+            }
+        }
         if (p->ng == 0) HIPCHK(hipMemsetAsync(p->A.qgb, 0, (size_t)std::max(p->ngc, 1) * p->nt * 4, sR));
         for (int c = C - 1; c >= 0; --c) {
             const int t0c = c * p->Tc, Tcur = chunk_len(p, c);
@@ -767,6 +900,7 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     HIPCHK(hipEventRecord(p->ev1, sV));
     HIPCHK(hipStreamSynchronize(sV));
     HIPCHK(hipStreamSynchronize(sR));
+    if (p->opt.njr > 0) HIPCHK(hipStreamSynchronize(p->stream_j));
     HIPCHK(hipGetLastError());
     if (p->chain_used) {
         int stalled = 0;
@@ -893,7 +1027,19 @@ int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smas
     if (costs) {
         float jobs = 0.f;
         if (p->ng > 0) HIPCHK(hipMemcpy(&jobs, p->d_cost_out, 4, hipMemcpyDeviceToHost));
-        const float jreg = 0.f;                      // njr = 0 (set_options rejects anything else for now)
+        float jreg = 0.f;
+        if (p->opt.njr > 0) {                        // mwd_cost.f90:199-228: weighted sums of the chains, then parameters + states
+            float sums[SX_JREG_MAXCHAIN] = {0.f};
+            HIPCHK(hipMemcpy(sums, p->d_jsum, sizeof(float) * 2 * p->opt.njr, hipMemcpyDeviceToHost));
+            float pj = 0.f, sj = 0.f;
+            for (int i = 0; i < p->opt.njr; ++i) {
+                const float w = p->opt.wjreg_fun[i];
+                const float ww = p->opt.jreg_fun[i] == SMASHX_PRIOR ? w : w * w;
+                pj = pj + ww * sums[2 * i];
+                sj = sj + ww * sums[2 * i + 1];
+            }
+            jreg = pj + sj;
+        }
         costs->cost = jobs + p->opt.wjreg * jreg;    // mwd_cost.f90:300
         costs->cost_jobs = jobs; costs->cost_jreg = jreg;
     }
@@ -943,8 +1089,16 @@ int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smas
                 if (!params_b->f[f]) continue;
                 int i = -1;
                 for (int q = 0; q < 6; ++q) if (kParamFields[q] == f) i = q;
-                if (i < 0 || !uses_param(st, f)) { std::memset(params_b->f[f], 0, (size_t)p->n2 * 4); continue; }
-                HIPCHK(hipMemsetAsync(p->d_stage, 0, (size_t)p->n2 * 4, p->stream));
+                const bool jr = p->opt.njr > 0 && jreg_optim(p, f) > 0;      // inactive cells / unused fields: the regulariser's part
+                if (jr) hipLaunchKernelGGL(sx_k_plane_scale, gfull, b, 0, p->stream, p->d_stage, p->d_jg[f],
+                                           p->opt.ub_parameters[f] - p->opt.lb_parameters[f], p->opt.denormalize_forward, p->n2);
+                else HIPCHK(hipMemsetAsync(p->d_stage, 0, (size_t)p->n2 * 4, p->stream));
+                if (i < 0 || !uses_param(st, f)) {
+                    if (!jr) { std::memset(params_b->f[f], 0, (size_t)p->n2 * 4); continue; }
+                    HIPCHK(hipMemcpyAsync(params_b->f[f], p->d_stage, (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
+                    HIPCHK(hipStreamSynchronize(p->stream));
+                    continue;
+                }
                 hipLaunchKernelGGL(k_scatter, gk, b, 0, p->stream, p->d_stage, gp[i], p->d_cell_flat, p->n,
                                    p->opt.ub_parameters[f] - p->opt.lb_parameters[f], p->opt.denormalize_forward);
                 HIPCHK(hipMemcpyAsync(params_b->f[f], p->d_stage, (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
@@ -955,8 +1109,16 @@ int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smas
                 if (!states_b->f[f]) continue;
                 int i = -1;
                 for (int q = 0; q < 5; ++q) if (kStateFields[q] == f) i = q;
-                if (i < 0 || !uses_state(st, f)) { std::memset(states_b->f[f], 0, (size_t)p->n2 * 4); continue; }
-                HIPCHK(hipMemsetAsync(p->d_stage, 0, (size_t)p->n2 * 4, p->stream));
+                const bool jr = p->opt.njr > 0 && jreg_optim(p, SMASHX_GNP + f) > 0;
+                if (jr) hipLaunchKernelGGL(sx_k_plane_scale, gfull, b, 0, p->stream, p->d_stage, p->d_jg[SMASHX_GNP + f],
+                                           p->opt.ub_states[f] - p->opt.lb_states[f], p->opt.denormalize_forward, p->n2);
+                else HIPCHK(hipMemsetAsync(p->d_stage, 0, (size_t)p->n2 * 4, p->stream));
+                if (i < 0 || !uses_state(st, f)) {
+                    if (!jr) { std::memset(states_b->f[f], 0, (size_t)p->n2 * 4); continue; }
+                    HIPCHK(hipMemcpyAsync(states_b->f[f], p->d_stage, (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
+                    HIPCHK(hipStreamSynchronize(p->stream));
+                    continue;
+                }
                 hipLaunchKernelGGL(k_scatter, gk, b, 0, p->stream, p->d_stage, gs[i], p->d_cell_flat, p->n,
                                    p->opt.ub_states[f] - p->opt.lb_states[f], p->opt.denormalize_forward);
                 HIPCHK(hipMemcpyAsync(states_b->f[f], p->d_stage, (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));

@@ -184,7 +184,10 @@ class Solver:
     def upload(self, parameters, states, parameters_bgd=None, states_bgd=None):
         P, k1 = self._pack(parameters, PARAM_NAMES, _lib.Parameters)
         S, k2 = self._pack(states, STATE_NAMES, _lib.States)
-        _lib.check(_lib.lib().smashx_upload(self._h, C.byref(P), None, C.byref(S), None))
+        PB, k3 = self._pack(parameters_bgd, PARAM_NAMES, _lib.Parameters) if parameters_bgd is not None else (None, None)
+        SB, k4 = self._pack(states_bgd, STATE_NAMES, _lib.States) if states_bgd is not None else (None, None)
+        _lib.check(_lib.lib().smashx_upload(self._h, C.byref(P), C.byref(PB) if PB is not None else None, C.byref(S),
+                                            C.byref(SB) if SB is not None else None))
 
     def sweep(self, adjoint=False, cost_b=1.0):
         _lib.check(_lib.lib().smashx_sweep(self._h, int(bool(adjoint)), C.c_float(cost_b)))

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import golden_util as gu
+from smash_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -27,12 +28,19 @@ def _types(g, **solver_kw):
     o.denormalize_forward = bool(g.opts.get("denormalize_forward", False))
     if "wgauge" in g.opts:
         o.wgauge = np.asarray(g.opts["wgauge"], np.float32)
+    if "jreg_fun" in g.opts:
+        o.jreg_fun, o.wjreg_fun, o.wjreg = list(g.opts["jreg_fun"]), list(g.opts["wjreg_fun"]), float(g.opts["wjreg"])
+    if "optim_parameters" in g.opts:
+        o.optim_parameters = np.asarray(g.opts["optim_parameters"], np.int32)
+        o.optim_states = np.asarray(g.opts["optim_states"], np.int32)
     mesh = smash_amd.MeshDT.from_synth(setup, g.mesh)
     inp = smash_amd.Input_DataDT(setup, mesh)
     inp.prcp, inp.pet, inp.qobs = g.prcp, g.pet, g.qobs
     par = smash_amd.ParametersDT.from_dict(mesh, g.params)
     sta = smash_amd.StatesDT.from_dict(mesh, g.states)
     out = smash_amd.OutputDT(setup, mesh)
+    inp._bgd = (smash_amd.ParametersDT.from_dict(mesh, g.opts["params_bgd"]), smash_amd.StatesDT.from_dict(mesh, g.opts["states_bgd"])) \
+        if "params_bgd" in g.opts else (par.copy(), sta.copy())
     if solver_kw:
         from smash_amd.solver import Solver
         s = Solver(setup, mesh, **solver_kw)
@@ -44,7 +52,7 @@ def _types(g, **solver_kw):
 def _run_forward(g, **kw):
     import smash_amd
     setup, mesh, inp, par, sta, out = _types(g, **kw)
-    smash_amd.forward(setup, mesh, inp, par, par.copy(), sta, sta.copy(), out, np.float32(0))
+    smash_amd.forward(setup, mesh, inp, par, inp._bgd[0], sta, inp._bgd[1], out, np.float32(0))
     return par, sta, out
 
 
@@ -52,15 +60,15 @@ def _run_adjoint(g, **kw):
     import smash_amd
     setup, mesh, inp, par, sta, out = _types(g, **kw)
     par_b, sta_b = par.copy(), sta.copy()
-    smash_amd.forward_b(setup, mesh, inp, par, par_b, par.copy(), par.copy(), sta, sta_b, sta.copy(), sta.copy(), out,
+    smash_amd.forward_b(setup, mesh, inp, par, par_b, inp._bgd[0], par.copy(), sta, sta_b, inp._bgd[1], sta.copy(), out,
                         out.copy(), np.float32(0), np.float32(1))
     return par, sta, out, par_b, sta_b
 
 
-NOJREG = [n for n in gu.names() if "jreg" not in n and "prior" not in n]
+ALL = gu.names()
 
 
-@pytest.mark.parametrize("name", NOJREG)
+@pytest.mark.parametrize("name", ALL)
 def test_forward_vs_reference_golden(name):
     g = gu.load(name)
     par, sta, out = _run_forward(g)
@@ -68,13 +76,14 @@ def test_forward_vs_reference_golden(name):
         e = gu.rel_l2(out.qsim[i], g.fwd["qsim"][i])
         assert e <= gu.tol(g.noise["qsim"][i]), (i, e, g.noise["qsim"][i])
     assert abs(out.cost - g.fwd["cost"]) <= gu.tol_cost(g.noise["cost"], g.fwd["cost"]), (out.cost, g.fwd["cost"])
+    assert abs(out.cost_jreg - g.fwd["cost_jreg"]) <= 1e-6 * abs(g.fwd["cost_jreg"]), (out.cost_jreg, g.fwd["cost_jreg"])
     for k in gu.STRUCT_STATES[g.structure]:
         e = gu.rel_l2(getattr(out.fstates, k), g.fwd["fstates"][k])
         assert e <= gu.tol_fstate(k, g.noise["fstates"][k]), (k, e, g.noise["fstates"][k])
         assert np.array_equal(getattr(sta, k), g.fwd["states"][k]), k       # states are restored (forward.f90:72)
 
 
-@pytest.mark.parametrize("name", NOJREG)
+@pytest.mark.parametrize("name", ALL)
 def test_adjoint_vs_reference_golden(name):
     g = gu.load(name)
     par, sta, out, par_b, sta_b = _run_adjoint(g)
@@ -88,7 +97,11 @@ def test_adjoint_vs_reference_golden(name):
         report[k] = (gu.rel_l2(getattr(sta_b, k), g.adj["states_b"][k]), gu.tol(g.noise["states_b"][k]))
     bad = {k: v for k, v in report.items() if not v[0] <= v[1]}
     assert not bad, report
-    # fields the structure does not use come back zero, like parameters_b = 0 (forward_db.f90:10869)
+    # fields the structure does not use come back zero, like parameters_b = 0 (forward_db.f90:10869) -- or, when
+    # they are optimised under a regulariser, with the regulariser's gradient alone
+    for k in synth.PARAM_NAMES:
+        if k not in gu.STRUCT_PARAMS[g.structure]:
+            assert np.array_equal(getattr(par_b, k), g.adj["parameters_b"][k]), k
     assert not np.any(par_b.beta) and not np.any(sta_b.husl1)
 
 
@@ -152,7 +165,7 @@ def test_unsupported_options_fail_loudly():
     import smash_amd
     g = gu.load("gr_a_24x24x120_norm_prior")
     setup, mesh, inp, par, sta, out = _types(g)
-    setup.optimize.jreg_fun, setup.optimize.wjreg_fun, setup.optimize.wjreg = ["prior"], [1.0], 1e-2
+    setup.optimize.jreg_fun, setup.optimize.wjreg_fun, setup.optimize.wjreg = ["no_such_regulariser"], [1.0], 1e-2
     with pytest.raises(smash_amd.SmashxError):
         smash_amd.forward(setup, mesh, inp, par, par.copy(), sta, sta.copy(), out, np.float32(0))
 
