@@ -302,8 +302,62 @@ static void logarithmic_b(const float* x, const float* y, float* y_b, int n_, fl
         }
 }
 
+/* mwd_cost.f90:594-673 (heap_sort): sift-down heap sort; idx moves with the values so that the adjoint
+ * (HEAP_SORT_B, forward_db.f90: pure data movement) is the inverse permutation, ties included. */
+static void heap_sort_idx(int n, float* arr, int* idx) {
+    if (n < 2) return;
+    int l = n / 2 + 1, ir = n;
+    for (;;) {
+        float arr_l; int idx_l;
+        if (l > 1) { l = l - 1; arr_l = arr[l - 1]; idx_l = idx[l - 1]; }
+        else {
+            arr_l = arr[ir - 1]; idx_l = idx[ir - 1];
+            arr[ir - 1] = arr[0]; idx[ir - 1] = idx[0];
+            ir = ir - 1;
+            if (ir == 1) { arr[0] = arr_l; idx[0] = idx_l; return; }
+        }
+        int i = l, j = l + l;
+        while (j <= ir) {
+            if (j < ir && arr[j - 1] < arr[j]) j = j + 1;
+            if (arr_l < arr[j - 1]) { arr[i - 1] = arr[j - 1]; idx[i - 1] = idx[j - 1]; i = j; j = j + j; }
+            else j = ir + 1;
+        }
+        arr[i - 1] = arr_l; idx[i - 1] = idx_l;
+    }
+}
+/* mwd_cost.f90:675-723 (quantile, p = 0.5) and QUANTILE_B forward_db.f90:4327-4370: returns the median of
+ * dat[0..n) and, when dat_b != NULL, the weights d(res)/d(dat[k]) * res_b */
+static float median_b(int n, const float* dat, float* dat_b, float res_b) {
+    float res = dat[0];
+    if (dat_b) for (int k = 0; k < n; ++k) dat_b[k] = 0.f;
+    if (n > 1) {
+        float* sd = (float*)malloc(sizeof(float) * (size_t)n);
+        int* id = (int*)malloc(sizeof(int) * (size_t)n);
+        for (int k = 0; k < n; ++k) { sd[k] = dat[k]; id[k] = k; }
+        heap_sort_idx(n, sd, id);
+        const float frac = (float)(n - 1) * 0.5f + 1.f;
+        if (frac <= 1.f) { res = sd[0]; if (dat_b) dat_b[id[0]] = dat_b[id[0]] + res_b; }
+        else if (frac >= (float)n) { res = sd[n - 1]; if (dat_b) dat_b[id[n - 1]] = dat_b[id[n - 1]] + res_b; }
+        else {
+            const int k = (int)frac;
+            const float q1 = sd[k - 1], q2 = sd[k];
+            res = q1 + (q2 - q1) * (frac - (float)k);
+            if (dat_b) {
+                const float temp_b = (frac - (float)k) * res_b;
+                dat_b[id[k]] = dat_b[id[k]] + temp_b;
+                dat_b[id[k - 1]] = dat_b[id[k - 1]] + (res_b - temp_b);
+            }
+        }
+        free(sd); free(id);
+    } else if (dat_b) {
+        dat_b[0] = dat_b[0] + res_b;
+    }
+    return res;
+}
+
 /* mwd_cost.f90:37-156 (compute_jobs); with qsim_b != NULL also forward_db.f90:2553-2715 (compute_jobs_b).
- * The negative-weight / median-over-gauges branch (mwd_cost.f90:145-154) is not restated: returns -1. */
+ * Gauges with a negative weight enter a median instead of the weighted sum; as soon as there is one, the
+ * median REPLACES the weighted sum (mwd_cost.f90:139-154) and jobs_b no longer reaches the weighted gauges. */
 static int compute_jobs(const orc_config* cfg, const int* flwacc, const int* gauge_pos, const float* area,
                         const float* qobs, const float* wgauge, const float* qsim, float* jobs, float jobs_b,
                         float* qsim_b) {
@@ -311,11 +365,13 @@ static int compute_jobs(const orc_config* cfg, const int* flwacc, const int* gau
     float* qo = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     float* qs = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     float* qs_b = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    float* arr = (float*)malloc(sizeof(float) * (size_t)(ng > 0 ? ng : 1));
+    float* arr_b = (float*)malloc(sizeof(float) * (size_t)(ng > 0 ? ng : 1));
+    int arr_size = 0;
     *jobs = 0.f;
     if (qsim_b) memset(qsim_b, 0, sizeof(float) * (size_t)ng * nt);
     for (int g = 0; g < ng; ++g) {
         if (!(wgauge[g] > 0.f || wgauge[g] < 0.f)) continue;
-        if (wgauge[g] < 0.f) { free(qo); free(qs); free(qs_b); return -1; }
         int row = gauge_pos[g], col = gauge_pos[g + ng];
         int any = 0;
         for (int i = 0; i < n; ++i) {
@@ -339,12 +395,17 @@ static int compute_jobs(const orc_config* cfg, const int* flwacc, const int* gau
             }
             gauge_jobs = gauge_jobs + cfg->wjobs_fun[j] * j_imd;
         }
-        *jobs = *jobs + wgauge[g] * gauge_jobs;
+        if (wgauge[g] > 0.f) *jobs = *jobs + wgauge[g] * gauge_jobs;
+        else arr[arr_size++] = gauge_jobs;
+    }
+    if (arr_size > 0) {
+        *jobs = median_b(arr_size, arr, qsim_b ? arr_b : 0, jobs_b);
+        jobs_b = 0.f;
     }
     if (qsim_b) {
         float j_imd_b = 0.f;
         for (int g = ng - 1; g >= 0; --g) {
-            if (!(wgauge[g] > 0.f)) continue;
+            if (!(wgauge[g] > 0.f || wgauge[g] < 0.f)) continue;
             int row = gauge_pos[g], col = gauge_pos[g + ng];
             int any = 0;
             for (int i = 0; i < n; ++i) {
@@ -354,7 +415,9 @@ static int compute_jobs(const orc_config* cfg, const int* flwacc, const int* gau
                 if (qo[i] >= 0.f) any = 1;
                 qs_b[i] = 0.f;
             }
-            float gauge_jobs_b = wgauge[g] * jobs_b;
+            float gauge_jobs_b;
+            if (wgauge[g] > 0.f) gauge_jobs_b = wgauge[g] * jobs_b;
+            else gauge_jobs_b = arr_b[--arr_size];
             for (int j = cfg->njf - 1; j >= 0; --j) {
                 j_imd_b = j_imd_b + cfg->wjobs_fun[j] * gauge_jobs_b;
                 if (!any) continue; /* control 8: j_imd_b keeps accumulating (forward_db.f90:2672-2704) */
@@ -372,7 +435,7 @@ static int compute_jobs(const orc_config* cfg, const int* flwacc, const int* gau
                 qsim_b[g + (long)ng * (s0 + i)] = qsim_b[g + (long)ng * (s0 + i)] + cfg->dt * 1e3f * qs_b[i] / area[g];
         }
     }
-    free(qo); free(qs); free(qs_b);
+    free(qo); free(qs); free(qs_b); free(arr); free(arr_b);
     return 0;
 }
 

@@ -150,6 +150,7 @@ struct smashx_plan {
     int *d_gauge_gid = nullptr, *d_gauge_flwacc = nullptr;
     float *d_area = nullptr, *d_wgauge = nullptr, *d_qobs = nullptr, *d_qsim_b = nullptr, *d_cost_out = nullptr;
     SxGaugeSums* d_sums = nullptr; SxCostCoef* d_coef = nullptr;
+    float* d_med = nullptr; int* d_med_idx = nullptr;    // median over negative-weight gauges
     float jobs = 0.f;
     // regularisation (sx_jreg.h): planes 0..15 = parameters, 16..23 = states
     bool tiled = false;
@@ -355,6 +356,7 @@ SxCostArgs cost_args(smashx_plan* p, float jobs_b) {
     C.qg = p->A.qg; C.qgb = p->A.qgb; C.ngc = p->ngc;
     C.gauge_gid = p->d_gauge_gid; C.gauge_flwacc = p->d_gauge_flwacc; C.area = p->d_area; C.wgauge = p->d_wgauge;
     C.qobs = p->d_qobs; C.qsim_b = p->d_qsim_b; C.sums = p->d_sums; C.coef = p->d_coef; C.out = p->d_cost_out;
+    C.med = p->d_med; C.med_idx = p->d_med_idx;
     C.jobs_b = jobs_b;
     return C;
 }
@@ -512,6 +514,8 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     TRY(p->dmalloc(&p->d_qobs, (size_t)std::max(p->ng, 1) * p->nt));
     TRY(p->dmalloc(&p->d_sums, (size_t)std::max(p->ng, 1)));
     TRY(p->dmalloc(&p->d_coef, (size_t)std::max(p->ng, 1) * SX_MAXJF));
+    TRY(p->dmalloc(&p->d_med, (size_t)2 * std::max(p->ng, 1)));
+    TRY(p->dmalloc(&p->d_med_idx, (size_t)2 * std::max(p->ng, 1)));
     TRY(p->dmalloc(&p->d_cost_out, 4));
     if (hipMemset(p->d_qobs, 0, (size_t)std::max(p->ng, 1) * p->nt * 4) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipMemset"); }
     // default options: plain Model.run(): njf = 0 (mwd_setup.f90:236)
@@ -620,7 +624,7 @@ int smashx_set_options(smashx_plan* p, const smashx_options* o) {
     p->opt.wgauge = nullptr;
     for (int g = 0; g < p->ng; ++g) {
         const float w = o->wgauge ? o->wgauge[g] : 1.f / p->ng;
-        if (w < 0.f) return fail(SMASHX_E_UNSUPPORTED, "negative wgauge (median over gauges, mwd_cost.f90:145-154) not built yet");
+        if (w < 0.f && p->tiled) return fail(SMASHX_E_UNSUPPORTED, "negative wgauge (median over gauges) on a tiled plan: the median needs every gauge on one plan");
         p->wgauge[g] = w;
     }
     HIPCHK(hipMemcpy(p->d_wgauge, p->wgauge.data(), p->wgauge.size() * 4, hipMemcpyHostToDevice));

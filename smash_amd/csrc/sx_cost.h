@@ -45,6 +45,8 @@ struct SxCostArgs {
     SxCostCoef* coef;               // [ng][SX_MAXJF]
     float* out;                     // [0] = jobs
     float jobs_b;
+    float* med;                     // [2 ng] gauge_jobs of the negative-weight gauges, then their adjoint weights
+    int* med_idx;                   // [2 ng] sort permutation, then gauge of each entry
 };
 
 __device__ __forceinline__ float sx_qs(const SxCostArgs& C, int g, int t) {
@@ -122,9 +124,35 @@ __device__ __forceinline__ void sx_kge_coef(const SxGaugeSums& S, const SxKge& k
 }
 
 // single thread: per-gauge criteria, weighted sum over gauges in gauge order, adjoint coefficients
+// heap_sort (mwd_cost.f90:594-673) with the permutation carried along: its adjoint only moves data back
+__device__ inline void sx_heap_sort_idx(int n, float* arr, int* idx) {
+    if (n < 2) return;
+    int l = n / 2 + 1, ir = n;
+    for (;;) {
+        float arr_l; int idx_l;
+        if (l > 1) { l = l - 1; arr_l = arr[l - 1]; idx_l = idx[l - 1]; }
+        else {
+            arr_l = arr[ir - 1]; idx_l = idx[ir - 1];
+            arr[ir - 1] = arr[0]; idx[ir - 1] = idx[0];
+            ir = ir - 1;
+            if (ir == 1) { arr[0] = arr_l; idx[0] = idx_l; return; }
+        }
+        int i = l, j = l + l;
+        while (j <= ir) {
+            if (j < ir && arr[j - 1] < arr[j]) j = j + 1;
+            if (arr_l < arr[j - 1]) { arr[i - 1] = arr[j - 1]; idx[i - 1] = idx[j - 1]; i = j; j = j + j; }
+            else j = ir + 1;
+        }
+        arr[i - 1] = arr_l; idx[i - 1] = idx_l;
+    }
+}
+
 __global__ void sx_k_cost_final(SxCostArgs C, int adjoint) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float jobs = 0.f;
+    int arr_size = 0;
+    float* arr = C.med; float* arr_b = C.med + C.ng;
+    int* perm = C.med_idx; int* arr_gauge = C.med_idx + C.ng;
     for (int g = 0; g < C.ng; ++g) {
         const float w = C.wgauge[g];
         if (!(w > 0.f || w < 0.f)) continue;
@@ -149,7 +177,31 @@ __global__ void sx_k_cost_final(SxCostArgs C, int adjoint) {
             }
             gauge_jobs = gauge_jobs + C.wjobs_fun[j] * j_imd;
         }
-        jobs = jobs + w * gauge_jobs;   // wgauge < 0 (median over gauges) is rejected on the host
+        if (w > 0.f) jobs = jobs + w * gauge_jobs;
+        else { arr[arr_size] = gauge_jobs; arr_b[arr_size] = 0.f; perm[arr_size] = arr_size; arr_gauge[arr_size] = g; ++arr_size; }
+    }
+    float jobs_b = C.jobs_b;
+    if (arr_size > 0) {
+        // quantile(arr, 0.5) replaces the weighted sum (mwd_cost.f90:154, 675-723); QUANTILE_B forward_db.f90:4327-4370
+        float res = arr[0];
+        if (arr_size > 1) {
+            sx_heap_sort_idx(arr_size, arr, perm);
+            const float frac = (float)(arr_size - 1) * 0.5f + 1.f;
+            if (frac <= 1.f) { res = arr[0]; arr_b[perm[0]] = arr_b[perm[0]] + jobs_b; }
+            else if (frac >= (float)arr_size) { res = arr[arr_size - 1]; arr_b[perm[arr_size - 1]] = arr_b[perm[arr_size - 1]] + jobs_b; }
+            else {
+                const int k = (int)frac;
+                const float q1 = arr[k - 1], q2 = arr[k];
+                res = q1 + (q2 - q1) * (frac - (float)k);
+                const float temp_b = (frac - (float)k) * jobs_b;
+                arr_b[perm[k]] = arr_b[perm[k]] + temp_b;
+                arr_b[perm[k - 1]] = arr_b[perm[k - 1]] + (jobs_b - temp_b);
+            }
+        } else {
+            arr_b[0] = arr_b[0] + jobs_b;
+        }
+        jobs = res;
+        jobs_b = 0.f;
     }
     C.out[0] = jobs;
     if (!adjoint) return;
@@ -157,10 +209,10 @@ __global__ void sx_k_cost_final(SxCostArgs C, int adjoint) {
     for (int g = C.ng - 1; g >= 0; --g) {
         for (int j = 0; j < SX_MAXJF; ++j) { SxCostCoef z; z.kind = 0; z.c_xy = z.c_yy = z.c_y = z.c = 0.f; C.coef[g * SX_MAXJF + j] = z; }
         const float w = C.wgauge[g];
-        if (!(w > 0.f)) continue;
+        if (!(w > 0.f || w < 0.f)) continue;
         const SxGaugeSums S = C.sums[g];
         const bool any = S.n > 0;
-        const float gauge_jobs_b = w * C.jobs_b;
+        const float gauge_jobs_b = (w > 0.f) ? w * jobs_b : arr_b[--arr_size];
         const float n = (float)S.n;
         for (int j = C.njf - 1; j >= 0; --j) {
             j_imd_b = j_imd_b + C.wjobs_fun[j] * gauge_jobs_b;
@@ -191,7 +243,7 @@ __global__ void sx_k_cost_seeds(SxCostArgs C) {
     const int g = blockIdx.y;
     if (t >= C.nt) return;
     float out = 0.f;
-    if (t >= C.s0 && C.wgauge[g] > 0.f) {
+    if (t >= C.s0 && (C.wgauge[g] > 0.f || C.wgauge[g] < 0.f)) {
         const float x = sx_qo(C, g, t), y = sx_qs(C, g, t);
         float y_b = 0.f;
         for (int j = C.njf - 1; j >= 0; --j) {

@@ -41,6 +41,11 @@ CASES = [
                    wgauge=[0.5, 0.0, 0.5])),
     dict(name="gr_a_24x24x120_norm_prior", structure="gr-a", n=24, nt=120, ng=3, mask=False, gaps=1000, normalized=True,
          opts=dict(jreg_fun=("prior",), wjreg_fun=(1.0,), wjreg=1e-2, denormalize_forward=True)),
+    # negative gauge weights: the median over those gauges replaces the weighted sum (mwd_cost.f90:139-154)
+    dict(name="gr_a_16x16x96_median3", structure="gr-a", n=16, nt=96, ng=4, mask=False, gaps=1000,
+         opts=dict(wgauge=[-1.0, 0.3, -1.0, -1.0])),
+    dict(name="gr_b_16x16x96_median2", structure="gr-b", n=16, nt=96, ng=3, mask=True, gaps=1000,
+         opts=dict(jobs_fun=("nse", "kge"), wjobs_fun=(0.6, 0.4), wgauge=[-0.5, -0.5, 0.0])),
     dict(name="gr_a_12x12x48_nse_cold", structure="gr-a", n=12, nt=48, ng=2, mask=False, gaps=0, warm=False, opts={}),
     # larger cases: forcing is regenerated from smash_amd.synth (sha256 pinned in the fixture)
     dict(name="gr_b_64x64x720_nse", structure="gr-b", n=64, nt=720, ng=4, mask=False, gaps=1000, big=True, opts={}),
@@ -87,7 +92,10 @@ def build_case(c):
 def main():
     if not refbind.available():
         raise SystemExit("oracle/_ref/libsmash_ref.so missing: run oracle/ref/build_ref.sh first")
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]
     for c in CASES:
+        if only and c["name"] not in only:
+            continue
         mesh, prcp, pet, qobs, P, S, opts = build_case(c)
         f = refbind.run(c["structure"], mesh, DT, prcp, pet, qobs, P, S, **opts)
         b = refbind.run(c["structure"], mesh, DT, prcp, pet, qobs, P, S, adjoint=True, **opts)
@@ -164,6 +172,7 @@ def main_lbfgsb():
 
 
 if __name__ == "__main__":
-    main()
-    os.makedirs(os.path.join(OUT, "lbfgsb"), exist_ok=True)
-    main_lbfgsb()
+    main()                              # python make_golden.py [case names...]: only those cases
+    if not [a for a in sys.argv[1:] if not a.startswith("-")]:
+        os.makedirs(os.path.join(OUT, "lbfgsb"), exist_ok=True)
+        main_lbfgsb()
