@@ -62,8 +62,8 @@ def parse():
     ap.add_argument("--forward-only", action="store_true")
     ap.add_argument("--trace-groups", default="", help="diagnostics: write per-round start/end times of the routing groups (JSON) here")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-grid", type=int, default=192)
-    ap.add_argument("--cpu-nt", type=int, default=120)
+    ap.add_argument("--cpu-grid", type=int, default=256)
+    ap.add_argument("--cpu-nt", type=int, default=360)
     return ap.parse_args()
 
 
