@@ -94,6 +94,14 @@ module smashx_c
             type(smashx_options), intent(in) :: opt
             integer(c_int) :: rc
         end function
+        function smashx_set_domain_outputs(plan, qsim_domain, net_prcp_domain, sparse) &
+        & bind(C, name="smashx_set_domain_outputs") result(rc)
+            import
+            type(c_ptr), value :: plan, qsim_domain, net_prcp_domain
+            integer(c_int), value :: sparse
+            integer(c_int) :: rc
+        end function smashx_set_domain_outputs
+
         function smashx_forward(plan, params, params_bgd, states, states_bgd, qsim, costs, fstates) &
         & bind(C, name="smashx_forward") result(rc)
             import :: c_int, c_ptr, smashx_parameters, smashx_states, smashx_costs
@@ -322,7 +330,8 @@ subroutine base_forward(setup, mesh, input_data, parameters, parameters_bgd, sta
     type(smashx_parameters) :: cp, cpb
     type(smashx_states) :: cs, csb, cf
     type(smashx_costs) :: cc
-    type(c_ptr) :: qs
+    type(c_ptr) :: qs, qdom, pdom
+    integer(c_int) :: sp_flag
 
     call smashx_prepare(setup, mesh, input_data)
     call smashx_pack_parameters(parameters, cp)
@@ -332,7 +341,28 @@ subroutine base_forward(setup, mesh, input_data, parameters, parameters_bgd, sta
     call smashx_pack_states(output%fstates, cf)
     qs = c_null_ptr
     if (mesh%ng .gt. 0) qs = c_loc(output%qsim)
+    !  optional whole-domain stores (md_forward_structure.f90:158-194)
+    qdom = c_null_ptr
+    pdom = c_null_ptr
+    sp_flag = 0
+    if (setup%sparse_storage) sp_flag = 1
+    if (setup%save_qsim_domain) then
+        if (setup%sparse_storage) then
+            qdom = c_loc(output%sparse_qsim_domain)
+        else
+            qdom = c_loc(output%qsim_domain)
+        end if
+    end if
+    if (setup%save_net_prcp_domain) then
+        if (setup%sparse_storage) then
+            pdom = c_loc(output%sparse_net_prcp_domain)
+        else
+            pdom = c_loc(output%net_prcp_domain)
+        end if
+    end if
+    call sx_check(smashx_set_domain_outputs(sx_plan, qdom, pdom, sp_flag), "set_domain_outputs")
     call sx_check(smashx_forward(sx_plan, cp, cpb, cs, csb, qs, cc, cf), "forward")
+    call sx_check(smashx_set_domain_outputs(sx_plan, c_null_ptr, c_null_ptr, sp_flag), "set_domain_outputs")
     cost = cc%cost
     output%cost = cc%cost
     output%cost_jobs = cc%cost_jobs

@@ -150,6 +150,12 @@ int smashx_sweep(smashx_plan* plan, int adjoint, float cost_b);
 int smashx_download(smashx_plan* plan, int adjoint, smashx_parameters* params, smashx_states* states, float* qsim,
                     smashx_costs* costs, smashx_states* fstates, smashx_parameters* params_b, smashx_states* states_b);
 int smashx_get_timing(const smashx_plan* plan, smashx_timing* out);
+/* Optional whole-domain stores of the forward run, OutputDT%qsim_domain / net_prcp_domain (mwd_output.f90:43-47,
+ * written at md_forward_structure.f90:158-194 when setup%save_qsim_domain / save_net_prcp_domain): caller-owned host
+ * arrays (nrow, ncol, nt) column-major -- inactive cells are set to -99 like OutputDT_initialise does -- or, with
+ * sparse != 0, the (nac, nt) sparse_ forms.  They are filled by every following smashx_forward / forward sweep
+ * until reset with NULL; adjoint sweeps do not touch them. */
+int smashx_set_domain_outputs(smashx_plan* plan, float* qsim_domain, float* net_prcp_domain, int sparse);
 
 /* ---- multi-GPU tiles: discharge series that cross the tile boundary -------------------
  * A cell whose D8 receiver lies in another tile publishes its discharge series ("out" edge); a cell of another

@@ -52,8 +52,9 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         states_bgd=None, denormalize_forward=False, optimize_start_step=1, jobs_fun=("nse",),
         wjobs_fun=(1.0,), jreg_fun=(), wjreg_fun=(), wjreg=0.0, wgauge=None, optim_parameters=None,
         optim_states=None, lb_parameters=None, ub_parameters=None, lb_states=None, ub_states=None,
-        cost_b=1.0):
-    """Same calling convention and result dict as oracle.refbind.run (dense forcing only)."""
+        cost_b=1.0, save_domain=False):
+    """Same calling convention and result dict as oracle.refbind.run (dense forcing only).
+    save_domain: also return qsim_domain / net_prcp_domain (nrow, ncol, nt), -99 on inactive cells."""
     from smash_amd.synth import PARAM_NAMES, STATE_NAMES
     L = lib()
     nrow, ncol, ng = mesh.nrow, mesh.ncol, mesh.ng
@@ -93,13 +94,22 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
     s_b = np.zeros((nrow, ncol, GNS), np.float32, order="F")
     common = [C.byref(cfg), _p(flwdir), _p(flwacc), _p(path), _p(active), _p(gpos), _p(area), _p(prcp), _p(pet),
               _p(qobs), _p(wg), _p(P), _p(Pb), _p(S), _p(Sb)]
-    if adjoint:
-        rc = L.orc_forward_b(*common, C.c_float(cost_b), _p(qsim), _p(costs), _p(p_b), _p(s_b))
-    else:
-        rc = L.orc_forward(*common, _p(qsim), _p(costs), _p(fstates))
+    qdom = pdom = None
+    if save_domain and not adjoint:
+        qdom = np.full((nrow, ncol, nt), -99.0, np.float32, order="F")
+        pdom = np.full((nrow, ncol, nt), -99.0, np.float32, order="F")
+        L.orc_set_domain_outputs(_p(qdom), _p(pdom))
+    try:
+        if adjoint:
+            rc = L.orc_forward_b(*common, C.c_float(cost_b), _p(qsim), _p(costs), _p(p_b), _p(s_b))
+        else:
+            rc = L.orc_forward(*common, _p(qsim), _p(costs), _p(fstates))
+    finally:
+        L.orc_set_domain_outputs(None, None)
     if rc != 0:
         raise RuntimeError(f"oracle returned {rc}")
-    return dict(qsim=qsim[:ng], cost=float(costs[0]), cost_jobs=float(costs[1]), cost_jreg=float(costs[2]),
+    return dict(qsim_domain=qdom, net_prcp_domain=pdom,
+                qsim=qsim[:ng], cost=float(costs[0]), cost_jobs=float(costs[1]), cost_jreg=float(costs[2]),
                 fstates=unpack(fstates, STATE_NAMES), parameters=unpack(P, PARAM_NAMES),
                 states=unpack(S, STATE_NAMES), parameters_b=unpack(p_b, PARAM_NAMES),
                 states_b=unpack(s_b, STATE_NAMES))

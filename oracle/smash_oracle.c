@@ -88,6 +88,14 @@ enum { S_HI = 0, S_HP = 1, S_HFT = 2, S_HST = 3, S_HLR = 7 };
 
 /* one cell-step of gr_{a,b,c,d}_forward: md_forward_structure.f90:62-156 / 248-340 / 432-520 / 621-698.
  * tape (optional, 8 floats): pre-step hi,hp,hft,hst,hlr, qup, prcp, pet -- what the reverse sweep needs. */
+/* optional whole-domain stores (md_forward_structure.f90:158-194): set through orc_set_domain_outputs */
+static float* g_qsim_domain = 0;     /* (nrow, ncol, nt) column-major, inactive cells left untouched */
+static float* g_net_prcp_domain = 0;
+static float* g_qt_out = 0;
+void orc_set_domain_outputs(float* qsim_domain, float* net_prcp_domain) {
+    g_qsim_domain = qsim_domain; g_net_prcp_domain = net_prcp_domain;
+}
+
 static void cell_step(int st, float dt, float dx, int nrow, int ncol, const int* flwdir, const int* flwacc,
                       int row, int col, float prcp, float pet, const float* P, float* S, float* q,
                       float* tape) {
@@ -132,6 +140,7 @@ static void cell_step(int st, float dt, float dx, int nrow, int ncol, const int*
         gr_transfer(5.f, prcp, prr, P[P_CFT * n2 + c], hft, &qr);
         qt = qr;
     }
+    if (g_qt_out) *g_qt_out = qt;
     qup = upstream_discharge(dt, dx, nrow, ncol, flwdir, flwacc, row, col, q);
     if (tape) tape[5] = qup;
     linear_routing(dt, qup, P[P_LR * n2 + c], hlr, &qrout);
@@ -151,8 +160,13 @@ static void structure_forward(const orc_config* cfg, const int* flwdir, const in
             if (row < 0 || col < 0) continue;
             long c = row + (long)col * nrow;
             if (active[c] != 1) continue;
+            float qt_cell = 0.f;
+            g_qt_out = g_net_prcp_domain ? &qt_cell : 0;
             cell_step(cfg->structure, cfg->dt, cfg->dx, nrow, ncol, flwdir, flwacc, row, col,
                       prcp[c + n2 * t], pet[c + n2 * t], P, S, q, tape ? tape + 8 * (i + n2 * t) : 0);
+            g_qt_out = 0;
+            if (g_net_prcp_domain) g_net_prcp_domain[c + n2 * t] = qt_cell;
+            if (g_qsim_domain) g_qsim_domain[c + n2 * t] = q[c];
         }
         for (int g = 0; g < cfg->ng; ++g)
             qsim[g + (long)cfg->ng * t] = q[gauge_pos[g] + (long)gauge_pos[g + cfg->ng] * nrow];

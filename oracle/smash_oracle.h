@@ -46,6 +46,10 @@ typedef struct {
  * (mwd_parameters_manipulation.f90:59, mwd_states_manipulation.f90:58); they come back
  * denormalised when denormalize_forward is set, states restored to entry values (forward.f90:41,72).
  */
+/* optional whole-domain stores of the NEXT orc_forward calls (setup%save_qsim_domain / save_net_prcp_domain,
+ * md_forward_structure.f90:158-194): (nrow, ncol, nt) column-major, only active cells are written; NULL = off */
+void orc_set_domain_outputs(float* qsim_domain, float* net_prcp_domain);
+
 int orc_forward(const orc_config* cfg, const int* flwdir, const int* flwacc, const int* path,
                 const int* active_cell, const int* gauge_pos, const float* area, const float* prcp,
                 const float* pet, const float* qobs, const float* wgauge, float* params,

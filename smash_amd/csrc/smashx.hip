@@ -105,6 +105,19 @@ __global__ void k_selftest_div(unsigned long long n, unsigned seed, float blo, f
     if (bad2) atomicAdd(out + 1, bad2);
 }
 
+// whole-domain outputs: T4 chunk buffer -> planes of `plane` floats per time step, cell k at idx[k]
+__global__ void k_domain_export(float* stage, const float* src4, const int* idx, int n, int npad, long plane, int tl0, int nb) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tt = blockIdx.y;
+    if (k >= n || tt >= nb) return;
+    const int tl = tl0 + tt;
+    stage[(size_t)tt * plane + idx[k]] = src4[((size_t)(tl >> 2) * npad + k) * 4 + (tl & 3)];
+}
+__global__ void k_fill(float* dst, float v, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+
 struct Launch { hipEvent_t a, b; int kind; };
 
 }  // namespace
@@ -152,6 +165,9 @@ struct smashx_plan {
     SxGaugeSums* d_sums = nullptr; SxCostCoef* d_coef = nullptr;
     float* d_med = nullptr; int* d_med_idx = nullptr;    // median over negative-weight gauges
     float jobs = 0.f;
+    // optional whole-domain outputs of forward sweeps (host arrays owned by the caller)
+    float* h_qsim_domain = nullptr; float* h_net_prcp_domain = nullptr; int dom_sparse = 0;
+    bool dom_q_active = false;       // the running sweep stores every cell's discharge (forward sweeps only)
     // regularisation (sx_jreg.h): planes 0..15 = parameters, 16..23 = states
     bool tiled = false;
     int* d_active = nullptr;
@@ -240,6 +256,10 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
         HIPCHK(hipMemsetAsync(p->A.xT, 0, (size_t)std::max(p->sch.nxslots, 1) * Tc * 4, p->stream));
         p->chunk_ready = true;
     }
+    if (p->h_qsim_domain && !p->A.qdT) {
+        int rc;
+        if ((rc = p->dmalloc(&p->A.qdT, (size_t)p->npad * p->Tc))) return rc;
+    }
     if (adjoint && !p->adj_ready) {
         int rc;
         const size_t cs = (size_t)p->npad * p->Tc;
@@ -265,6 +285,7 @@ SxDeviceArrays view_at(const smashx_plan* p, int off) {
     const size_t q = (size_t)(off / 4);
     B.qtT = p->A.qtT + q * p->npad * 4;
     if (p->A.hrT) B.hrT = p->A.hrT + q * p->npad * 4;
+    if (p->A.qdT) B.qdT = p->A.qdT + q * p->npad * 4;
     B.xT = p->A.xT + q * p->A.nx * 4;
     if (p->A.tape_hp) B.tape_hp = p->A.tape_hp + (size_t)off * p->npad;
     if (p->A.tape_hft) B.tape_hft = p->A.tape_hft + (size_t)off * p->npad;
@@ -306,7 +327,8 @@ void vert_adj(smashx_plan* p, int off, int t0, int T) {
 // HBM-bound); the narrow, latency-bound rounds from chain_from on run chained inside a single launch
 // (sx_kernels.h "rounds chained inside one launch"), which turns their sum into roughly the longest of them.
 void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
-    const SxDeviceArrays B = view_at(p, off);
+    SxDeviceArrays B = view_at(p, off);
+    if (!p->dom_q_active) B.qdT = nullptr;
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
     const int nr = p->sch.nrounds;
     const int cf = (p->chain && nr - p->chain_from >= 2) ? p->chain_from : nr;
@@ -832,10 +854,36 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
         HIPCHK(hipStreamWaitEvent(sV, e, 0));
         return 0;
     };
+    p->dom_q_active = !adjoint && p->h_qsim_domain && p->A.qdT;
+    // optional whole-domain stores (md_forward_structure.f90:158-194) of one storage chunk -> the caller's arrays
+    auto export_domain = [&](int c) -> int {
+        const int t0c = c * p->Tc, Tcur = chunk_len(p, c);
+        HIPCHK(hipStreamSynchronize(sV));
+        HIPCHK(hipStreamSynchronize(sR));
+        const long plane = p->dom_sparse ? (long)p->n : p->n2;
+        const int* idx = p->dom_sparse ? p->d_sparse_idx : p->d_cell_flat;
+        const int nbmax = (int)std::max<long>(1, std::min<long>(p->stage_planes * p->n2 / plane, 1 << 15));
+        for (int which = 0; which < 2; ++which) {
+            float* host = which ? p->h_net_prcp_domain : p->h_qsim_domain;
+            const float* src = which ? p->A.qtT : p->A.qdT;
+            if (!host || !src) continue;
+            for (int tl0 = 0; tl0 < Tcur; tl0 += nbmax) {
+                const int nb = std::min(nbmax, Tcur - tl0);
+                if (!p->dom_sparse)
+                    hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)nb * plane + 255) / 256)), dim3(256), 0, sV, p->d_stage, -99.f, (size_t)nb * plane);
+                hipLaunchKernelGGL(k_domain_export, dim3((p->n + 255) / 256, nb), dim3(256), 0, sV, p->d_stage, src, idx, p->n, p->npad, plane, tl0, nb);
+                HIPCHK(hipMemcpyAsync(host + (size_t)(t0c + tl0) * plane, p->d_stage, (size_t)nb * plane * 4, hipMemcpyDeviceToHost, sV));
+                HIPCHK(hipStreamSynchronize(sV));
+            }
+        }
+        return 0;
+    };
     if (!adjoint) {
+        const bool dom = p->h_qsim_domain || p->h_net_prcp_domain;
         for (int c = 0; c < C; ++c) {
             if (c > 0 && (rc = v_waits_r())) return rc;
             if ((rc = forward_chunk(c, false))) return rc;
+            if (dom && (rc = export_domain(c))) return rc;
         }
         if ((rc = run_cost(p, 0, 0.f))) return rc;
     } else {
@@ -929,6 +977,17 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     tm.n_chunks = p->nchunks; tm.chunk_steps = p->Tc; tm.pipe_steps = p->Tp; tm.n_rounds = p->sch.nrounds; tm.n_groups = p->sch.ngroups;
     tm.device_bytes = p->bytes;
     p->last_adjoint = adjoint;
+    return 0;
+}
+
+// Output_DT%qsim_domain / net_prcp_domain (or their sparse_ forms): host arrays the next FORWARD sweeps fill
+int smashx_set_domain_outputs(smashx_plan* p, float* qsim_domain, float* net_prcp_domain, int sparse) {
+    if (!p) return fail(SMASHX_E_ARG, "null plan");
+    if (sparse && !p->d_sparse_idx && (qsim_domain || net_prcp_domain))
+        return fail(SMASHX_E_ARG, "sparse domain outputs need mesh.path (the sparse cell numbering)");
+    if (p->tiled && (qsim_domain || net_prcp_domain))
+        return fail(SMASHX_E_UNSUPPORTED, "whole-domain outputs on a tiled plan");
+    p->h_qsim_domain = qsim_domain; p->h_net_prcp_domain = net_prcp_domain; p->dom_sparse = sparse ? 1 : 0;
     return 0;
 }
 

@@ -110,6 +110,7 @@ struct SxDeviceArrays {
     float *ci_b, *cp_b, *cft_b, *cst_b, *exc_b, *lr_b, *hi_b, *hp_b, *hft_b, *hst_b, *hlr_b;
     // chunk buffers
     float *qtT, *hrT;
+    float* qdT;                   // optional: discharge of every cell (setup%save_qsim_domain), T4 like qtT; null = off
     float *tape_hi, *tape_hp, *tape_hft, *tape_hst;
     float* xT;                    // exchange series
     // gauges
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
                 if (tb >= 0 && tb < nb) {
                     if (xout >= 0) x4[(size_t)tb * A.nx + xout] = outq[u];
                     if (TAPE) hr4[(size_t)tb * A.npad + cell] = outh[u];
+                    if (A.qdT) reinterpret_cast<float4*>(A.qdT)[(size_t)tb * A.npad + cell] = outq[u];
                     if (gid >= 0) {
                         const float qv[4] = {outq[u].x, outq[u].y, outq[u].z, outq[u].w};
 #pragma unroll

@@ -117,6 +117,17 @@ class Solver:
         _lib.check(_lib.lib().smashx_plan_chunking(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_domain_outputs(self, qsim_domain=None, net_prcp_domain=None, sparse=False):
+        """Host arrays the following forward sweeps fill (OutputDT%qsim_domain / net_prcp_domain or sparse_ forms)."""
+        for a in (qsim_domain, net_prcp_domain):
+            if a is not None and not (a.dtype == np.float32 and a.flags.f_contiguous):
+                raise _lib.SmashxError(_lib.E_ARG, "domain outputs must be Fortran-ordered float32 arrays")
+        self._dom_keep = (qsim_domain, net_prcp_domain)
+        fn = _lib.lib().smashx_set_domain_outputs
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.check(fn(self._h, None if qsim_domain is None else qsim_domain.ctypes.data,
+                      None if net_prcp_domain is None else net_prcp_domain.ctypes.data, int(bool(sparse))))
+
     def group_times(self):
         """Diagnostics (SMASHX_TRACE_GROUPS=1): (ticks[2][groups][2] at 100 MHz, round_of_group[groups])."""
         ng = self.timing()["n_groups"]
@@ -240,7 +251,16 @@ def forward(setup, mesh, input_data, parameters, parameters_bgd, states, states_
     """Drop-in for mw_forward::forward (mw_forward.f90:18-39).  Returns output.cost."""
     s = _solver_for(setup, mesh, input_data)
     s.upload(parameters, states, parameters_bgd, states_bgd)
-    s.sweep(False)
+    key = "sparse_" if setup.sparse_storage else ""
+    dom = (getattr(output, key + "qsim_domain", None) if getattr(setup, "save_qsim_domain", False) else None,
+           getattr(output, key + "net_prcp_domain", None) if getattr(setup, "save_net_prcp_domain", False) else None)
+    if dom[0] is not None or dom[1] is not None:
+        s.set_domain_outputs(dom[0], dom[1], setup.sparse_storage)
+    try:
+        s.sweep(False)
+    finally:
+        if dom[0] is not None or dom[1] is not None:
+            s.set_domain_outputs(None, None)
     return s.download(False, parameters, states, output)
 
 

@@ -55,11 +55,13 @@ class Optimize_SetupDT:
 
 class SetupDT:
     def __init__(self, nd: int = 0, ng: int = 0, *, structure: str = "gr-a", dt: float = 3600.0, ntime_step: int = 0,
-                 sparse_storage: bool = False):
+                 sparse_storage: bool = False, save_qsim_domain: bool = False, save_net_prcp_domain: bool = False):
         self.structure = structure
         self.dt = float(dt)
         self.ntime_step = int(ntime_step)
         self.sparse_storage = bool(sparse_storage)
+        self.save_qsim_domain = bool(save_qsim_domain)          # mwd_setup.f90:144-145
+        self.save_net_prcp_domain = bool(save_net_prcp_domain)
         self.optimize = Optimize_SetupDT(ng)
 
     def copy(self):
@@ -142,6 +144,13 @@ class StatesDT(_Fields):
 class OutputDT:
     def __init__(self, setup: SetupDT, mesh: MeshDT):
         self.qsim = np.full((mesh.ng, setup.ntime_step), -99.0, np.float32, order="F")
+        # optional whole-domain stores (OutputDT_initialise, mwd_output.f90:80-112)
+        shp = (mesh.nac, setup.ntime_step) if setup.sparse_storage else (mesh.nrow, mesh.ncol, setup.ntime_step)
+        key = ("sparse_" if setup.sparse_storage else "")
+        if setup.save_qsim_domain:
+            setattr(self, key + "qsim_domain", np.full(shp, -99.0, np.float32, order="F"))
+        if setup.save_net_prcp_domain:
+            setattr(self, key + "net_prcp_domain", np.full(shp, -99.0, np.float32, order="F"))
         self.cost = 0.0
         self.cost_jobs = 0.0
         self.cost_jreg = 0.0

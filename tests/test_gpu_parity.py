@@ -190,3 +190,44 @@ def test_device_division_matches_ieee(blo, bhi):
     _lib.check(fn(0, n, 12345, blo, bhi, out))
     assert out[1] == 0
     assert out[0] <= n * 1e-6, (out[0], n)
+
+
+@pytest.mark.parametrize("name,sparse", [("gr_c_16x16x96_kge_se_log_mask", False), ("gr_b_16x16x96_nse_gaps", True)])
+def test_domain_outputs(name, sparse):
+    """setup%save_qsim_domain / save_net_prcp_domain (md_forward_structure.f90:158-194): discharge and net rainfall of
+    every active cell and step, dense (-99 on inactive cells) or in the sparse (nac, nt) form; also across chunks."""
+    import smash_amd
+    from oracle import pyoracle
+    from smash_amd.solver import Solver
+    g = gu.load(name)
+    ref = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, save_domain=True,
+                       **{k: v for k, v in g.opts.items() if k in ("jobs_fun", "wjobs_fun", "optimize_start_step")})
+    setup, mesh, inp, par, sta, out = _types(g)
+    setup.save_qsim_domain = setup.save_net_prcp_domain = True
+    act = g.mesh.active_cell
+    if sparse:
+        setup.sparse_storage = True
+        idx = [(r, c) for r, c in zip(g.mesh.path[0], g.mesh.path[1]) if r >= 0 and c >= 0 and act[r, c] == 1]
+        rr = np.array([i[0] for i in idx]); cc = np.array([i[1] for i in idx])
+        inp = smash_amd.Input_DataDT(setup, mesh)
+        inp.sparse_prcp = np.asfortranarray(g.prcp[rr, cc, :]); inp.sparse_pet = np.asfortranarray(g.pet[rr, cc, :])
+        inp.qobs = g.qobs
+    out = smash_amd.OutputDT(setup, mesh)
+    s = Solver(setup, mesh, chunk_steps=32)
+    if sparse:
+        s.set_forcing(inp.sparse_prcp, inp.sparse_pet, sparse=True)
+    else:
+        s.set_forcing(inp.prcp, inp.pet)
+    inp._smashx_solver = s
+    smash_amd.forward(setup, mesh, inp, par, par.copy(), sta, sta.copy(), out, np.float32(0))
+    qd = out.sparse_qsim_domain if sparse else out.qsim_domain
+    pd = out.sparse_net_prcp_domain if sparse else out.net_prcp_domain
+    if sparse:
+        rq, rp = ref["qsim_domain"][rr, cc, :], ref["net_prcp_domain"][rr, cc, :]
+    else:
+        rq, rp = ref["qsim_domain"], ref["net_prcp_domain"]
+        assert np.all(qd[act != 1] == -99.0) and np.all(pd[act != 1] == -99.0)
+        for i in range(g.mesh.ng):      # the gauge cell of the domain array IS output%qsim
+            assert np.array_equal(qd[g.mesh.gauge_pos[i, 0], g.mesh.gauge_pos[i, 1], :], out.qsim[i])
+    # net rainfall of the data-gap steps is a difference of nearly equal powers (md_gr_operator.f90:94-96): 2e-6 there
+    assert gu.rel_l2(qd, rq) <= 1e-6 and gu.rel_l2(pd, rp) <= 5e-6, (gu.rel_l2(qd, rq), gu.rel_l2(pd, rp))
