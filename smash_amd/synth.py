@@ -169,6 +169,42 @@ def make_mesh(nrow: int, ncol: int, ng: int = 8, dx: float = 1000.0, seed: int =
     return Mesh(nrow, ncol, dx, flwdir, flwacc, path, active, gauge_pos, area)
 
 
+def make_mesh_d8(nrow: int, ncol: int, ng: int = 3, dx: float = 1000.0, seed: int = SEED, radius: float = 0.0) -> Mesh:
+    """A catchment that uses all eight D8 codes: every cell drains towards an interior outlet along the steepest
+    descent of  distance-to-outlet + 0.45 * noise  (a king move always shortens the distance by > 0.9, so the
+    field is acyclic and has one basin).  The outlet flows south into a masked cell; radius > 0 also masks
+    everything farther than radius * min(nrow, ncol) from the outlet (ragged, upstream-closed mask)."""
+    r = np.arange(nrow, dtype=np.int64)[:, None]
+    c = np.arange(ncol, dtype=np.int64)[None, :]
+    r0, c0 = (3 * nrow) // 5, (11 * ncol) // 20
+    u = (_hash3(seed, r, c, np.int64(11)) & 0xFFFF).astype(np.float64) / 65536.0
+    phi = np.hypot(r - r0, c - c0) + 0.45 * u
+    active = np.ones((nrow, ncol), dtype=np.int32)
+    active[r0 + 1, c0] = 0
+    if radius > 0:
+        active[np.hypot(r - r0, c - c0) > radius * min(nrow, ncol)] = 0
+        active[r0 + 1, c0] = 0
+    big = np.float64(1e30)
+    pad = np.full((nrow + 2, ncol + 2), big)
+    pad[1:-1, 1:-1] = np.where(active == 1, phi, big)
+    best = np.full((nrow, ncol), big)
+    fd = np.zeros((nrow, ncol), dtype=np.int32)
+    for k in range(8):
+        nb = pad[1 + DROW[k]: 1 + DROW[k] + nrow, 1 + DCOL[k]: 1 + DCOL[k] + ncol]
+        take = nb < best
+        best = np.where(take, nb, best)
+        fd = np.where(take, k + 1, fd)
+    assert np.all((best < phi) | (active != 1) | ((r == r0) & (c == c0))), "local minimum in the synthetic relief"
+    fd[r0, c0] = 5
+    flwdir = np.asfortranarray(np.where(active == 1, fd, -99).astype(np.int32))
+    active = np.asfortranarray(active)
+    flwacc = flow_accumulation(flwdir, active)
+    path = make_path(np.where(active == 1, flwacc, -99))
+    gauge_pos = pick_gauges(np.where(active == 1, flwacc, -1), ng)
+    area = np.array([float(flwacc[a, b]) * dx * dx for a, b in gauge_pos], dtype=np.float32)
+    return Mesh(nrow, ncol, dx, flwdir, flwacc, path, active, gauge_pos, area)
+
+
 # ----------------------------------------------------------------------------------------------
 # forcing (integer construction; identical under numpy and torch)
 # ----------------------------------------------------------------------------------------------

@@ -46,6 +46,10 @@ CASES = [
          opts=dict(wgauge=[-1.0, 0.3, -1.0, -1.0])),
     dict(name="gr_b_16x16x96_median2", structure="gr-b", n=16, nt=96, ng=3, mask=True, gaps=1000,
          opts=dict(jobs_fun=("nse", "kge"), wjobs_fun=(0.6, 0.4), wgauge=[-0.5, -0.5, 0.0])),
+    # all eight D8 codes, interior outlet, ragged mask (synth.make_mesh_d8): what real catchments look like
+    dict(name="gr_b_20x20x96_d8", structure="gr-b", n=20, nt=96, ng=3, mask=False, gaps=1000, d8=True, opts={}),
+    dict(name="gr_c_32x32x240_d8_ragged", structure="gr-c", n=32, nt=240, ng=4, mask=True, gaps=1000, d8=True, radius=0.42,
+         opts=dict(jobs_fun=("kge", "nse"), wjobs_fun=(0.5, 0.5))),
     dict(name="gr_a_12x12x48_nse_cold", structure="gr-a", n=12, nt=48, ng=2, mask=False, gaps=0, warm=False, opts={}),
     # larger cases: forcing is regenerated from smash_amd.synth (sha256 pinned in the fixture)
     dict(name="gr_b_64x64x720_nse", structure="gr-b", n=64, nt=720, ng=4, mask=False, gaps=1000, big=True, opts={}),
@@ -67,7 +71,10 @@ def sha(a):
 
 def build_case(c):
     n, nt = c["n"], c["nt"]
-    mesh = synth.make_mesh(n, n, ng=c["ng"], mask_corner=c["mask"])
+    if c.get("d8"):
+        mesh = synth.make_mesh_d8(n, n, ng=c["ng"], radius=c.get("radius", 0.0))
+    else:
+        mesh = synth.make_mesh(n, n, ng=c["ng"], mask_corner=c["mask"])
     prcp, pet = synth.dense_forcing(mesh, nt, gap_per_million=c["gaps"])
     P = synth.make_parameters(n, n)
     S = synth.make_states(n, n, warm=c.get("warm", True))

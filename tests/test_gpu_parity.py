@@ -105,7 +105,7 @@ def test_adjoint_vs_reference_golden(name):
     assert not np.any(par_b.beta) and not np.any(sta_b.husl1)
 
 
-@pytest.mark.parametrize("name", ["gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask"])
+@pytest.mark.parametrize("name", ["gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask", "gr_c_32x32x240_d8_ragged"])
 @pytest.mark.parametrize("chunk,pipe,group", [(16, 0, 64), (32, 16, 128), (48, 32, 512), (0, 16, 256)])
 def test_chunking_and_grouping_do_not_change_results(name, chunk, pipe, group):
     """Time-chunk checkpointing, the two-stream chunk pipeline and the routing partition only reorder
