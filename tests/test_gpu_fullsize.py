@@ -1,0 +1,125 @@
+"""GPU, BASELINE.json's full single-GPU size (configs[2]: 1024 x 1024 cells x 8760 hourly steps, gr-b, forward +
+adjoint): the oracle cannot run this, so the sweep is checked through size-independent properties of the path:
+
+  * determinism        two sweeps give bit-identical cost and gradient fields
+  * linearity          the adjoint is linear in its seed: cost_b = 2 doubles every gradient field exactly
+                       (a power-of-two factor commutes with every rounding)
+  * directional        (J(theta + e d) - J(theta - e d)) / 2e  against  <grad J, d>  for d = sign(grad) * theta over
+    derivative         cp, cft and lr (two extra forward sweeps; fp32 finite differences: 5 % bar)
+  * storage invariance the chunked checkpoint/recompute adjoint (4 storage chunks) is bit-identical to store-all
+
+SMASHX_FULLSIZE_GRID / SMASHX_FULLSIZE_NT shrink the case for a quick run.
+"""
+import gc
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N = int(os.environ.get("SMASHX_FULLSIZE_GRID", "1024"))
+NT = int(os.environ.get("SMASHX_FULLSIZE_NT", "8760"))
+FIELDS_P = ("ci", "cp", "cft", "exc", "lr")
+FIELDS_S = ("hi", "hp", "hft", "hlr")
+
+
+def _problem(chunk):
+    import torch
+    import smash_amd
+    from smash_amd import synth
+    from smash_amd.solver import Solver
+    dev = torch.device("cuda", 0)
+    m = synth.make_mesh(N, N, ng=8)
+    setup = smash_amd.SetupDT(0, m.ng, structure="gr-b", dt=3600.0, ntime_step=NT)
+    setup.optimize.jobs_fun, setup.optimize.wjobs_fun = ["nse"], [1.0]
+    mesh = smash_amd.MeshDT.from_synth(setup, m)
+    sol = Solver(setup, mesh, chunk_steps=chunk)
+    rows, cols = sol.cell_order()
+    d_rows = torch.from_numpy(rows.astype(np.int64)).to(dev)
+    d_cols = torch.from_numpy(cols.astype(np.int64)).to(dev)
+    tb = max(1, min(NT, (1 << 26) // max(sol.ncells, 1)))
+    for t0 in range(0, NT, tb):
+        t1 = min(NT, t0 + tb)
+        prcp, pet = synth.forcing_block(d_rows, d_cols, t0, t1, xp=torch, device=dev)
+        torch.cuda.synchronize()
+        sol.set_forcing_device_block(t0, t1, prcp.data_ptr(), pet.data_ptr())
+        del prcp, pet
+    del d_rows, d_cols
+    torch.cuda.empty_cache()
+    par = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(N, N))
+    sta = smash_amd.StatesDT.from_dict(mesh, synth.make_states(N, N, warm=True))
+    parq = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(N, N, perturb=0.1))
+    out = smash_amd.OutputDT(setup, mesh)
+    sol.set_options(setup.optimize)
+    sol.upload(parq, sta)
+    sol.sweep(False)
+    sol.download(False, parq, sta, out)
+    sol.set_qobs(out.qsim)                       # observations = run with parameters + 10 %
+    return sol, setup, mesh, par, sta
+
+
+def _adjoint(sol, setup, mesh, par, sta, cost_b=1.0):
+    import smash_amd
+    out = smash_amd.OutputDT(setup, mesh)
+    par_b, sta_b = par.copy(), sta.copy()
+    sol.upload(par, sta)
+    sol.sweep(True, cost_b)
+    cost = sol.download(True, par, sta, out, par_b, sta_b)
+    return cost, {k: getattr(par_b, k).copy() for k in FIELDS_P}, {k: getattr(sta_b, k).copy() for k in FIELDS_S}, out.qsim.copy()
+
+
+def _cost(sol, setup, mesh, par, sta):
+    import smash_amd
+    out = smash_amd.OutputDT(setup, mesh)
+    sol.upload(par, sta)
+    sol.sweep(False)
+    return sol.download(False, par, sta, out)
+
+
+def test_fullsize_properties():
+    sol, setup, mesh, par, sta = _problem(0)
+    assert sol.chunking()[0] >= NT, "store-all expected at this size (288 GB HBM)"
+    c1, p1, s1, q1 = _adjoint(sol, setup, mesh, par, sta)
+    assert np.isfinite(c1) and 0.0 < c1 < 10.0
+    for k in FIELDS_P:
+        assert np.all(np.isfinite(p1[k])) and np.any(p1[k] != 0.0), k
+    # determinism
+    c1b, p1b, s1b, q1b = _adjoint(sol, setup, mesh, par, sta)
+    assert c1b == c1 and np.array_equal(q1, q1b)
+    assert all(np.array_equal(p1[k], p1b[k]) for k in FIELDS_P) and all(np.array_equal(s1[k], s1b[k]) for k in FIELDS_S)
+    # linearity in the seed
+    c2, p2, s2, _ = _adjoint(sol, setup, mesh, par, sta, cost_b=2.0)
+    assert c2 == c1
+    for k in FIELDS_P:
+        assert np.array_equal(p2[k], np.float32(2.0) * p1[k]), k
+    for k in FIELDS_S:
+        assert np.array_equal(s2[k], np.float32(2.0) * s1[k]), k
+    # directional derivative along d = sign(grad) * theta over cp, cft and lr: <grad, d> = sum |grad * theta|
+    eps = 1e-2
+    keep = {k: getattr(par, k).copy() for k in ("cp", "cft", "lr")}
+    sgn = {k: np.sign(p1[k]).astype(np.float32) for k in keep}
+    for k in keep:
+        setattr(par, k, np.asfortranarray(keep[k] * (np.float32(1.0) + np.float32(eps) * sgn[k])))
+    jp = _cost(sol, setup, mesh, par, sta)
+    for k in keep:
+        setattr(par, k, np.asfortranarray(keep[k] * (np.float32(1.0) - np.float32(eps) * sgn[k])))
+    jm = _cost(sol, setup, mesh, par, sta)
+    for k in keep:
+        setattr(par, k, keep[k])
+    fd = (jp - jm) / (2.0 * eps)
+    ad = float(sum(np.sum(np.abs(p1[k].astype(np.float64) * keep[k].astype(np.float64))) for k in keep))
+    assert abs(fd - ad) <= 5e-2 * abs(ad) + 1e-6, (fd, ad)
+    # storage invariance: 4 storage chunks, checkpoints + recomputation
+    del sol
+    gc.collect()
+    sol, setup, mesh, par, sta = _problem(((NT + 3) // 4 + 15) // 16 * 16)
+    assert sol.chunking()[0] < NT
+    c3, p3, s3, q3 = _adjoint(sol, setup, mesh, par, sta)
+    assert c3 == c1 and np.array_equal(q3, q1)
+    for k in FIELDS_P:
+        assert np.array_equal(p3[k], p1[k]), k
+    for k in FIELDS_S:
+        assert np.array_equal(s3[k], s1[k]), k
+    del sol
+    gc.collect()
