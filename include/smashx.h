@@ -157,6 +157,17 @@ int smashx_get_timing(const smashx_plan* plan, smashx_timing* out);
  * until reset with NULL; adjoint sweeps do not touch them. */
 int smashx_set_domain_outputs(smashx_plan* plan, float* qsim_domain, float* net_prcp_domain, int sparse);
 
+/* base_forward_d (forward_db.f90:10517-10601), the tangent-linear model behind mw_forward::forward_d
+ * (mw_forward.f90:70-97): directional derivative of the discharge and of the cost along (params_d, states_d), which
+ * are given in the same space as params / states (normalised when denormalize_forward).  qsim_d (ng, nt) may be NULL.
+ * params / states / qsim / costs come back as from smashx_forward.  parameters_bgd_d / states_bgd_d of the reference
+ * are passive and have no counterpart.  Deviation: the reference's forward_d ends with an unconditional
+ * denormalisation (forward_db.f90:3246-3247) that corrupts parameters and states when denormalize_forward is off;
+ * here they are left as smashx_forward leaves them, and params_d / states_d are not modified. */
+int smashx_forward_d(smashx_plan* plan, smashx_parameters* params, const smashx_parameters* params_d,
+                     const smashx_parameters* params_bgd, smashx_states* states, const smashx_states* states_d,
+                     const smashx_states* states_bgd, float* qsim, float* qsim_d, smashx_costs* costs, float* cost_d);
+
 /* ---- multi-GPU tiles: discharge series that cross the tile boundary -------------------
  * A cell whose D8 receiver lies in another tile publishes its discharge series ("out" edge); a cell of another
  * tile draining into this one is an "in" edge.  Both lists are sorted by the flat (row + col*nrow) index of

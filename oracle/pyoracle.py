@@ -52,9 +52,10 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         states_bgd=None, denormalize_forward=False, optimize_start_step=1, jobs_fun=("nse",),
         wjobs_fun=(1.0,), jreg_fun=(), wjreg_fun=(), wjreg=0.0, wgauge=None, optim_parameters=None,
         optim_states=None, lb_parameters=None, ub_parameters=None, lb_states=None, ub_states=None,
-        cost_b=1.0, save_domain=False):
+        cost_b=1.0, save_domain=False, params_d=None, states_d=None):
     """Same calling convention and result dict as oracle.refbind.run (dense forcing only).
-    save_domain: also return qsim_domain / net_prcp_domain (nrow, ncol, nt), -99 on inactive cells."""
+    save_domain: also return qsim_domain / net_prcp_domain (nrow, ncol, nt), -99 on inactive cells.
+    params_d / states_d (dicts): run the tangent model (orc_forward_d) along that direction -> cost_d, qsim_d."""
     from smash_amd.synth import PARAM_NAMES, STATE_NAMES
     L = lib()
     nrow, ncol, ng = mesh.nrow, mesh.ncol, mesh.ng
@@ -94,6 +95,21 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
     s_b = np.zeros((nrow, ncol, GNS), np.float32, order="F")
     common = [C.byref(cfg), _p(flwdir), _p(flwacc), _p(path), _p(active), _p(gpos), _p(area), _p(prcp), _p(pet),
               _p(qobs), _p(wg), _p(P), _p(Pb), _p(S), _p(Sb)]
+    if params_d is not None or states_d is not None:
+        zp, zs = np.zeros((nrow, ncol, GNP), np.float32, order="F"), np.zeros((nrow, ncol, GNS), np.float32, order="F")
+        P_d = pack(params_d, PARAM_NAMES, nrow, ncol) if params_d is not None else zp
+        S_d = pack(states_d, STATE_NAMES, nrow, ncol) if states_d is not None else zs
+        qsim_d = np.zeros((max(ng, 1), nt), np.float32, order="F")
+        cost_d = C.c_float(0.0)
+        L.orc_forward_d.restype = C.c_int
+        rc = L.orc_forward_d(C.byref(cfg), _p(flwdir), _p(flwacc), _p(path), _p(active), _p(gpos), _p(area), _p(prcp), _p(pet),
+                             _p(qobs), _p(wg), _p(P), _p(P_d), _p(Pb), _p(S), _p(S_d), _p(Sb), _p(qsim), _p(qsim_d), _p(costs),
+                             C.byref(cost_d))
+        if rc != 0:
+            raise RuntimeError(f"oracle returned {rc}")
+        return dict(qsim=qsim[:ng], qsim_d=qsim_d[:ng], cost_d=float(cost_d.value), cost_jobs=float(costs[1]),
+                    parameters=unpack(P, PARAM_NAMES), states=unpack(S, STATE_NAMES),
+                    parameters_d=unpack(P_d, PARAM_NAMES), states_d=unpack(S_d, STATE_NAMES))
     qdom = pdom = None
     if save_domain and not adjoint:
         qdom = np.full((nrow, ncol, nt), -99.0, np.float32, order="F")

@@ -22,7 +22,7 @@ module ref_capi
     use mwd_parameters_manipulation
     use mwd_states_manipulation
     use mw_sparse_storage
-    use mw_forward, only: forward, forward_b
+    use mw_forward, only: forward, forward_b, forward_d
     use mw_optimize, only: optimize_lbfgsb
 
     implicit none
@@ -58,16 +58,18 @@ contains
     !  icfg(2:5) nrow, ncol, nt, ng
     !  icfg(6)  sparse_storage (0/1)         icfg(7)  denormalize_forward (0/1)
     !  icfg(8)  optimize_start_step (1-based) icfg(9)  njf      icfg(10) njr
-    !  icfg(11) mode: 0 = forward, 1 = forward_b, 2 = optimize_lbfgsb (mw_optimize.f90:484-676)
+    !  icfg(11) mode: 0 = forward, 1 = forward_b, 2 = optimize_lbfgsb (mw_optimize.f90:484-676),
+    !           3 = forward_d (tangent model, mw_forward.f90:70-97; entry point ref_run_d only)
     !  icfg(12) nrep (timing repetitions, >=1)     icfg(13) maxiter (mode 2)
     !  rcfg(1) dt  rcfg(2) dx  rcfg(3) wjreg  rcfg(4) cost_b
     !  Arrays are column-major exactly as the reference holds them; path and gauge_pos are 1-based.
     !  params/states are the (nrow,ncol,GNP)/(nrow,ncol,GNS) packings of get_parameters/get_states
     !  (mwd_parameters_manipulation.f90:59, mwd_states_manipulation.f90:58).
-    subroutine ref_run(icfg, rcfg, flwdir, flwacc, path, active_cell, gauge_pos, area, &
+    subroutine ref_core(icfg, rcfg, flwdir, flwacc, path, active_cell, gauge_pos, area, &
     & prcp, pet, qobs, params, params_bgd, states, states_bgd, &
     & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
-    & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed) bind(C, name="ref_run")
+    & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed, &
+    & params_d, states_d, params_bgd_d, states_bgd_d, qsim_d, cost_d_out)
 
         integer(c_int), intent(in) :: icfg(16)
         real(c_float), intent(in) :: rcfg(4)
@@ -92,7 +94,15 @@ contains
         real(c_float), intent(inout) :: params_out(icfg(2), icfg(3), GNP), states_out(icfg(2), icfg(3), GNS)
         real(c_float), intent(inout) :: params_b(icfg(2), icfg(3), GNP), states_b(icfg(2), icfg(3), GNS)
         real(c_double), intent(inout) :: elapsed
+        real(c_float), intent(in), optional :: params_d(icfg(2), icfg(3), GNP), states_d(icfg(2), icfg(3), GNS)
+        real(c_float), intent(in), optional :: params_bgd_d(icfg(2), icfg(3), GNP), states_bgd_d(icfg(2), icfg(3), GNS)
+        real(c_float), intent(inout), optional :: qsim_d(icfg(5), icfg(4))
+        real(c_float), intent(inout), optional :: cost_d_out
 
+        type(ParametersDT) :: p_d
+        type(StatesDT) :: s_d
+        type(OutputDT) :: output_d
+        real(sp) :: cost_d
         type(SetupDT) :: setup
         type(MeshDT) :: mesh
         type(Input_DataDT) :: input_data
@@ -191,6 +201,20 @@ contains
             call system_clock(c0, crate)
             if (icfg(11) .eq. 0) then
                 call forward(setup, mesh, input_data, p, p_bgd, s, s_bgd, output, cost)
+            else if (icfg(11) .eq. 3) then
+                !  tangent model: p_b / s_b objects double as the (scratch) background tangents
+                call ParametersDT_initialise(p_d, mesh)
+                call StatesDT_initialise(s_d, mesh)
+                call OutputDT_initialise(output_d, setup, mesh)
+                call set_parameters(mesh, p_d, params_d)
+                call set_states(mesh, s_d, states_d)
+                call set_parameters(mesh, p_bgd_b, params_bgd_d)
+                call set_states(mesh, s_bgd_b, states_bgd_d)
+                cost_d = 0._sp
+                call forward_d(setup, mesh, input_data, p, p_d, p_bgd, p_bgd_b, &
+                & s, s_d, s_bgd, s_bgd_b, output, output_d, cost, cost_d)
+                cost_d_out = cost_d
+                if (ng .gt. 0) qsim_d = output_d%qsim
             else if (icfg(11) .eq. 2) then
                 setup%optimize%denormalize_forward = .false.
                 setup%optimize%maxiter = icfg(13)
@@ -218,6 +242,80 @@ contains
             call get_states(mesh, s_b, states_b)
         end if
 
+    end subroutine ref_core
+
+    subroutine ref_run(icfg, rcfg, flwdir, flwacc, path, active_cell, gauge_pos, area, &
+    & prcp, pet, qobs, params, params_bgd, states, states_bgd, &
+    & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
+    & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed) bind(C, name="ref_run")
+        integer(c_int), intent(in) :: icfg(16)
+        real(c_float), intent(in) :: rcfg(4)
+        integer(c_int), intent(in) :: flwdir(icfg(2), icfg(3)), flwacc(icfg(2), icfg(3))
+        integer(c_int), intent(in) :: path(2, icfg(2)*icfg(3)), active_cell(icfg(2), icfg(3))
+        integer(c_int), intent(in) :: gauge_pos(icfg(5), 2)
+        real(c_float), intent(in) :: area(icfg(5))
+        real(c_float), intent(in) :: prcp(icfg(2), icfg(3), icfg(4)), pet(icfg(2), icfg(3), icfg(4))
+        real(c_float), intent(in) :: qobs(icfg(5), icfg(4))
+        real(c_float), intent(in) :: params(icfg(2), icfg(3), GNP), params_bgd(icfg(2), icfg(3), GNP)
+        real(c_float), intent(in) :: states(icfg(2), icfg(3), GNS), states_bgd(icfg(2), icfg(3), GNS)
+        real(c_float), intent(in) :: wgauge(icfg(5))
+        integer(c_int), intent(in) :: jobs_codes(*)
+        real(c_float), intent(in) :: wjobs(*)
+        integer(c_int), intent(in) :: jreg_codes(*)
+        real(c_float), intent(in) :: wjreg_fun(*)
+        integer(c_int), intent(in) :: optim_p(GNP), optim_s(GNS)
+        real(c_float), intent(in) :: lbp(GNP), ubp(GNP), lbs(GNS), ubs(GNS)
+        real(c_float), intent(inout) :: qsim(icfg(5), icfg(4))
+        real(c_float), intent(inout) :: costs(3)
+        real(c_float), intent(inout) :: fstates(icfg(2), icfg(3), GNS)
+        real(c_float), intent(inout) :: params_out(icfg(2), icfg(3), GNP), states_out(icfg(2), icfg(3), GNS)
+        real(c_float), intent(inout) :: params_b(icfg(2), icfg(3), GNP), states_b(icfg(2), icfg(3), GNS)
+        real(c_double), intent(inout) :: elapsed
+        call ref_core(icfg, rcfg, flwdir, flwacc, path, active_cell, gauge_pos, area, &
+        & prcp, pet, qobs, params, params_bgd, states, states_bgd, &
+        & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
+        & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed)
     end subroutine ref_run
+
+    !  icfg(11) must be 3: mw_forward::forward_d with the tangent direction (params_d, states_d) and the tangents
+    !  of the background fields; returns output_d%qsim and cost_d beside the primal outputs
+    subroutine ref_run_d(icfg, rcfg, flwdir, flwacc, path, active_cell, gauge_pos, area, &
+    & prcp, pet, qobs, params, params_bgd, states, states_bgd, &
+    & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
+    & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed, &
+    & params_d, states_d, params_bgd_d, states_bgd_d, qsim_d, cost_d) bind(C, name="ref_run_d")
+        integer(c_int), intent(in) :: icfg(16)
+        real(c_float), intent(in) :: rcfg(4)
+        integer(c_int), intent(in) :: flwdir(icfg(2), icfg(3)), flwacc(icfg(2), icfg(3))
+        integer(c_int), intent(in) :: path(2, icfg(2)*icfg(3)), active_cell(icfg(2), icfg(3))
+        integer(c_int), intent(in) :: gauge_pos(icfg(5), 2)
+        real(c_float), intent(in) :: area(icfg(5))
+        real(c_float), intent(in) :: prcp(icfg(2), icfg(3), icfg(4)), pet(icfg(2), icfg(3), icfg(4))
+        real(c_float), intent(in) :: qobs(icfg(5), icfg(4))
+        real(c_float), intent(in) :: params(icfg(2), icfg(3), GNP), params_bgd(icfg(2), icfg(3), GNP)
+        real(c_float), intent(in) :: states(icfg(2), icfg(3), GNS), states_bgd(icfg(2), icfg(3), GNS)
+        real(c_float), intent(in) :: wgauge(icfg(5))
+        integer(c_int), intent(in) :: jobs_codes(*)
+        real(c_float), intent(in) :: wjobs(*)
+        integer(c_int), intent(in) :: jreg_codes(*)
+        real(c_float), intent(in) :: wjreg_fun(*)
+        integer(c_int), intent(in) :: optim_p(GNP), optim_s(GNS)
+        real(c_float), intent(in) :: lbp(GNP), ubp(GNP), lbs(GNS), ubs(GNS)
+        real(c_float), intent(inout) :: qsim(icfg(5), icfg(4))
+        real(c_float), intent(inout) :: costs(3)
+        real(c_float), intent(inout) :: fstates(icfg(2), icfg(3), GNS)
+        real(c_float), intent(inout) :: params_out(icfg(2), icfg(3), GNP), states_out(icfg(2), icfg(3), GNS)
+        real(c_float), intent(inout) :: params_b(icfg(2), icfg(3), GNP), states_b(icfg(2), icfg(3), GNS)
+        real(c_double), intent(inout) :: elapsed
+        real(c_float), intent(in) :: params_d(icfg(2), icfg(3), GNP), states_d(icfg(2), icfg(3), GNS)
+        real(c_float), intent(in) :: params_bgd_d(icfg(2), icfg(3), GNP), states_bgd_d(icfg(2), icfg(3), GNS)
+        real(c_float), intent(inout) :: qsim_d(icfg(5), icfg(4))
+        real(c_float), intent(inout) :: cost_d
+        call ref_core(icfg, rcfg, flwdir, flwacc, path, active_cell, gauge_pos, area, &
+        & prcp, pet, qobs, params, params_bgd, states, states_bgd, &
+        & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
+        & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed, &
+        & params_d, states_d, params_bgd_d, states_bgd_d, qsim_d, cost_d)
+    end subroutine ref_run_d
 
 end module ref_capi

@@ -67,17 +67,21 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         states_bgd=None, sparse_storage=False, denormalize_forward=False, optimize_start_step=1,
         jobs_fun=("nse",), wjobs_fun=(1.0,), jreg_fun=(), wjreg_fun=(), wjreg=0.0, wgauge=None,
         optim_parameters=None, optim_states=None, lb_parameters=None, ub_parameters=None,
-        lb_states=None, ub_states=None, cost_b=1.0, nrep=1, fast=False, optimize_maxiter=None):
+        lb_states=None, ub_states=None, cost_b=1.0, nrep=1, fast=False, optimize_maxiter=None,
+        params_d=None, states_d=None, params_bgd_d=None, states_bgd_d=None):
     """Call the reference forward / forward_b (mw_forward.f90:18-68) on flat arrays.
 
     mesh: object with nrow, ncol, dx, flwdir, flwacc, path (0-based), active_cell, gauge_pos (0-based),
-    area.  params/states: dict name -> (nrow, ncol) float32.  Returns a dict of outputs."""
+    area.  params/states: dict name -> (nrow, ncol) float32.  Returns a dict of outputs.
+    params_d / states_d (dicts): run the tangent model forward_d (mw_forward.f90:70-97) along that direction
+    instead; the result also holds cost_d and qsim_d."""
     from smash_amd.synth import PARAM_NAMES, STATE_NAMES
     lib = _lib(fast)
     nrow, ncol, ng = mesh.nrow, mesh.ncol, mesh.ng
     nt = prcp.shape[2]
     jobs_fun, jreg_fun = list(jobs_fun), list(jreg_fun)
-    mode = 2 if optimize_maxiter is not None else int(adjoint)
+    tangent = params_d is not None or states_d is not None
+    mode = 3 if tangent else (2 if optimize_maxiter is not None else int(adjoint))
     icfg = np.array([STRUCTURES[structure], nrow, ncol, nt, ng, int(sparse_storage),
                      int(denormalize_forward), optimize_start_step, len(jobs_fun), len(jreg_fun),
                      mode, nrep, optimize_maxiter or 0, 0, 0, 0], dtype=np.int32)
@@ -111,11 +115,20 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
             _f(prcp, np.float32), _f(pet, np.float32), _f(qobs, np.float32), P, Pb, S, Sb, wg, jc, wj,
             rc, wr, op, os_, lbp, ubp, lbs, ubs, qsim, costs, fstates, pout, sout, p_b, s_b]
     cargs = [_ptr(a) for a in args] + [C.byref(elapsed)]
+    if tangent:
+        zp, zs = np.zeros((nrow, ncol, GNP), np.float32, order="F"), np.zeros((nrow, ncol, GNS), np.float32, order="F")
+        P_d = pack(params_d, PARAM_NAMES, nrow, ncol) if params_d is not None else zp
+        S_d = pack(states_d, STATE_NAMES, nrow, ncol) if states_d is not None else zs
+        Pb_d = pack(params_bgd_d, PARAM_NAMES, nrow, ncol) if params_bgd_d is not None else zp
+        Sb_d = pack(states_bgd_d, STATE_NAMES, nrow, ncol) if states_bgd_d is not None else zs
+        qsim_d = np.zeros((max(ng, 1), nt), np.float32, order="F")
+        cost_d = C.c_float(0.0)
+        cargs += [_ptr(P_d), _ptr(S_d), _ptr(Pb_d), _ptr(Sb_d), _ptr(qsim_d), C.byref(cost_d)]
     err = []
 
     def call():
         try:
-            lib.ref_run(*cargs)
+            (lib.ref_run_d if tangent else lib.ref_run)(*cargs)
         except Exception as e:  # pragma: no cover
             err.append(e)
 
@@ -130,4 +143,5 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
     return dict(qsim=qsim[:ng], cost=float(costs[0]), cost_jobs=float(costs[1]), cost_jreg=float(costs[2]),
                 fstates=unpack(fstates, STATE_NAMES), parameters=unpack(pout, PARAM_NAMES),
                 states=unpack(sout, STATE_NAMES), parameters_b=unpack(p_b, PARAM_NAMES),
-                states_b=unpack(s_b, STATE_NAMES), elapsed=elapsed.value)
+                states_b=unpack(s_b, STATE_NAMES), elapsed=elapsed.value,
+                cost_d=float(cost_d.value) if tangent else None, qsim_d=qsim_d[:ng] if tangent else None)

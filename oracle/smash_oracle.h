@@ -62,6 +62,15 @@ int orc_forward_b(const orc_config* cfg, const int* flwdir, const int* flwacc, c
                   const float* params_bgd, float* states, const float* states_bgd, float cost_b,
                   float* qsim, float* costs, float* params_b, float* states_b);
 
+/* Tangent model, base_forward_d (forward_db.f90:10517-10601), smash_oracle_d.c.  params_d / states_d: the direction
+ * (in normalised space when denormalize_forward; they come back denormalised like the reference leaves them);
+ * qsim_d (ng, nt) and cost_d out; costs[1] = jobs.  The background tangents are passive in the reference. */
+int orc_forward_d(const orc_config* cfg, const int* flwdir, const int* flwacc, const int* path,
+                  const int* active_cell, const int* gauge_pos, const float* area, const float* prcp,
+                  const float* pet, const float* qobs, const float* wgauge, float* params, float* params_d,
+                  const float* params_bgd, float* states, float* states_d, const float* states_bgd,
+                  float* qsim, float* qsim_d, float* costs, float* cost_d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,22 @@ __global__ void k_fill(float* dst, float v, size_t n) {
     if (i < n) dst[i] = v;
 }
 
+// fp64 dot product of two float arrays (one block): cost_d = <d cost / d y, y_d>
+__global__ void k_dot(const float* a, const float* b, size_t n, double* out, int accumulate) {
+    __shared__ double sh[256];
+    double acc = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) acc += (double)a[i] * (double)b[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + sh[0];
+}
+// qsim_d(g, t) from the per-gauge-cell tangent series
+__global__ void k_gauge_rows(float* dst, const float* src, const int* gid, int ng, int nt) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+    if (t < nt && g < ng) dst[(size_t)g * nt + t] = src[(size_t)gid[g] * nt + t];
+}
+
 struct Launch { hipEvent_t a, b; int kind; };
 
 }  // namespace
@@ -168,6 +184,11 @@ struct smashx_plan {
     // optional whole-domain outputs of forward sweeps (host arrays owned by the caller)
     float* h_qsim_domain = nullptr; float* h_net_prcp_domain = nullptr; int dom_sparse = 0;
     bool dom_q_active = false;       // the running sweep stores every cell's discharge (forward sweeps only)
+    // tangent sweep (smashx_forward_d)
+    bool tan_ready = false;
+    float* d_qsim_d = nullptr;       // [ng][nt]
+    double* d_dot = nullptr;
+    float* d_tanplane[SMASHX_GNP + SMASHX_GNS] = {nullptr};   // full planes of the (denormalised) direction, jreg only
     // regularisation (sx_jreg.h): planes 0..15 = parameters, 16..23 = states
     bool tiled = false;
     int* d_active = nullptr;
@@ -1199,6 +1220,171 @@ int smashx_forward(smashx_plan* p, smashx_parameters* params, const smashx_param
     if ((rc = smashx_upload(p, params, params_bgd, states, states_bgd))) return rc;
     if ((rc = smashx_sweep(p, 0, 0.f))) return rc;
     return smashx_download(p, 0, params, states, qsim, costs, fstates, nullptr, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tangent model: base_forward_d (forward_db.f90:10517-10601).  One forward sweep that carries the directional
+// derivative along (params_d, states_d): vertical kernel on dual numbers, routing twice (values with the hr_imd
+// tape, then tangents), cost_d = <d cost / d qsim, qsim_d> + <d(wjreg jreg) / d theta, theta_d> with the adjoint
+// seeds of the cost kernels and of the regulariser (fp64 dot products).
+// ---------------------------------------------------------------------------------------------------------
+int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_parameters* params_d, const smashx_parameters* params_bgd,
+                     smashx_states* states, const smashx_states* states_d, const smashx_states* states_bgd, float* qsim,
+                     float* qsim_d, smashx_costs* costs, float* cost_d) {
+    if (!p || !params || !states || !params_d || !states_d || !cost_d) return fail(SMASHX_E_ARG, "null argument");
+    if (p->tiled) return fail(SMASHX_E_UNSUPPORTED, "tangent model on a tiled plan");
+    int rc = smashx_upload(p, params, params_bgd, states, states_bgd); if (rc) return rc;
+    if (!p->have_forcing) return fail(SMASHX_E_STATE, "forcing not set");
+    if ((rc = set_device(p))) return rc;
+    if ((rc = ensure_chunk_buffers(p, true))) return rc;
+    const int st = p->st;
+    hipStream_t sV = p->stream, sR = p->stream_r;
+    const dim3 b(256), gfull((unsigned)((p->n2 + 255) / 256)), gk((p->n + 255) / 256);
+    if (!p->tan_ready) {
+        if ((rc = p->dmalloc(&p->A.qtdT, (size_t)p->npad * p->Tc))) return rc;
+        if ((rc = p->dmalloc(&p->A.xdT, (size_t)std::max(p->sch.nxslots, 1) * p->Tc))) return rc;
+        if ((rc = p->dmalloc(&p->A.qgd, (size_t)std::max(p->ngc, 1) * p->nt))) return rc;
+        if ((rc = p->dmalloc(&p->d_qsim_d, (size_t)std::max(p->ng, 1) * p->nt))) return rc;
+        if ((rc = p->dmalloc(&p->d_dot, 2))) return rc;
+        HIPCHK(hipMemset(p->A.xdT, 0, (size_t)std::max(p->sch.nxslots, 1) * p->Tc * 4));
+        p->tan_ready = true;
+    }
+    // direction -> per-cell arrays (the gradient arrays double as tangent storage); DENORMALIZE_*_D scales by (ub - lb)
+    float* tp[6] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.lr_b};
+    float* ts[5] = {p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b, p->A.hlr_b};
+    for (int i = 0; i < 6; ++i) {
+        const int f = kParamFields[i];
+        HIPCHK(hipMemsetAsync(tp[i], 0, (size_t)p->npad * 4, sV));
+        if (!uses_param(st, f)) continue;
+        if (!params_d->f[f]) return fail(SMASHX_E_ARG, "a tangent field the structure uses is NULL");
+        HIPCHK(hipMemcpyAsync(p->d_stage, params_d->f[f], (size_t)p->n2 * 4, hipMemcpyHostToDevice, sV));
+        if (p->opt.denormalize_forward)
+            hipLaunchKernelGGL(sx_k_plane_scale, gfull, b, 0, sV, p->d_stage, p->d_stage, p->opt.ub_parameters[f] - p->opt.lb_parameters[f], 1, p->n2);
+        hipLaunchKernelGGL(k_gather, gk, b, 0, sV, tp[i], p->d_stage, p->d_cell_flat, p->n);
+        HIPCHK(hipStreamSynchronize(sV));
+    }
+    for (int i = 0; i < 5; ++i) {
+        const int f = kStateFields[i];
+        HIPCHK(hipMemsetAsync(ts[i], 0, (size_t)p->npad * 4, sV));
+        if (!uses_state(st, f)) continue;
+        if (!states_d->f[f]) return fail(SMASHX_E_ARG, "a tangent field the structure uses is NULL");
+        HIPCHK(hipMemcpyAsync(p->d_stage, states_d->f[f], (size_t)p->n2 * 4, hipMemcpyHostToDevice, sV));
+        if (p->opt.denormalize_forward)
+            hipLaunchKernelGGL(sx_k_plane_scale, gfull, b, 0, sV, p->d_stage, p->d_stage, p->opt.ub_states[f] - p->opt.lb_states[f], 1, p->n2);
+        hipLaunchKernelGGL(k_gather, gk, b, 0, sV, ts[i], p->d_stage, p->d_cell_flat, p->n);
+        HIPCHK(hipStreamSynchronize(sV));
+    }
+    // regulariser tangent (COMPUTE_JREG_D, forward_db.f90:2810-2925): the reference's running sums in its order
+    float jreg_d = 0.f;
+    if (p->opt.njr > 0) {
+        HIPCHK(hipEventRecord(p->ev0, sV));
+        HIPCHK(hipStreamWaitEvent(p->stream_j, p->ev0, 0));
+        if ((rc = run_jreg(p, 0, 0.f))) return rc;                        // jreg itself (cost), fills p->jchains
+        HIPCHK(hipStreamSynchronize(p->stream_j));
+        float sums_keep[SX_JREG_MAXCHAIN] = {0.f};
+        HIPCHK(hipMemcpy(sums_keep, p->d_jsum, sizeof(float) * 2 * p->opt.njr, hipMemcpyDeviceToHost));
+        const int nrow = p->cfg.nrow, ncol = p->cfg.ncol;
+        // tangent of the control vector as compute_cost sees it: NORMALIZE_D(DENORMALIZE_D(direction))
+        for (int idx = 0; idx < SMASHX_GNP + SMASHX_GNS; ++idx) {
+            if (jreg_optim(p, idx) <= 0) continue;
+            const float* h = idx < SMASHX_GNP ? params_d->f[idx] : states_d->f[idx - SMASHX_GNP];
+            if (!h) return fail(SMASHX_E_ARG, "the tangent of an optimised field is NULL");
+            if (!p->d_tanplane[idx]) { if ((rc = p->dmalloc(&p->d_tanplane[idx], (size_t)p->n2))) return rc; }
+            HIPCHK(hipMemcpyAsync(p->d_tanplane[idx], h, (size_t)p->n2 * 4, hipMemcpyHostToDevice, sV));
+            if (p->opt.denormalize_forward) {
+                hipLaunchKernelGGL(sx_k_plane_scale, gfull, b, 0, sV, p->d_tanplane[idx], p->d_tanplane[idx], jreg_span(p, idx), 1, p->n2);
+                hipLaunchKernelGGL(sx_k_plane_div, gfull, b, 0, sV, p->d_tanplane[idx], jreg_span(p, idx), p->n2);
+            }
+        }
+        const SxJregChains& ch = p->jchains;
+        for (int i = 0; i < p->opt.njr; ++i)
+            for (int grp = 0; grp < 2; ++grp) {
+                const int c = 2 * i + grp, lo = grp ? SMASHX_GNP : 0, hi = grp ? SMASHX_GNP + SMASHX_GNS : SMASHX_GNP;
+                long slot = ch.first[c];
+                for (int idx = lo; idx < hi; ++idx) {
+                    if (jreg_optim(p, idx) <= 0) continue;
+                    float* t = p->d_jterm + (size_t)slot++ * p->n2;
+                    if (p->opt.jreg_fun[i] == SMASHX_PRIOR)
+                        hipLaunchKernelGGL(sx_k_prior_terms_d, gfull, b, 0, sV, t, p->d_jx[idx], p->d_jb[idx], p->d_tanplane[idx], p->n2);
+                    else
+                        hipLaunchKernelGGL(sx_k_smooth_terms_d, gfull, b, 0, sV, t, p->d_jx[idx], p->d_jb[idx], p->d_tanplane[idx],
+                                           p->opt.jreg_fun[i] == SMASHX_SMOOTHING ? 1 : 0, p->d_active, nrow, ncol);
+                }
+            }
+        hipLaunchKernelGGL(sx_k_seq_sum, dim3(ch.nchain), dim3(64), 0, sV, p->d_jterm, ch, p->n2, p->d_jsum);
+        float sd[SX_JREG_MAXCHAIN] = {0.f};
+        HIPCHK(hipMemcpyAsync(sd, p->d_jsum, sizeof(float) * 2 * p->opt.njr, hipMemcpyDeviceToHost, sV));
+        HIPCHK(hipStreamSynchronize(sV));
+        HIPCHK(hipMemcpy(p->d_jsum, sums_keep, sizeof(float) * 2 * p->opt.njr, hipMemcpyHostToDevice));   // the download reads jreg from here
+        float pj = 0.f, sj = 0.f;
+        for (int i = 0; i < p->opt.njr; ++i) {
+            const float w = p->opt.wjreg_fun[i];
+            const float ww = p->opt.jreg_fun[i] == SMASHX_PRIOR ? w : w * w;
+            pj = pj + ww * sd[2 * i];
+            sj = sj + ww * sd[2 * i + 1];
+        }
+        jreg_d = pj + sj;
+    }
+    // sweep
+    p->launches.clear(); p->pool_used = 0;
+    HIPCHK(hipEventRecord(p->ev0, sV));
+    HIPCHK(hipStreamWaitEvent(sR, p->ev0, 0));
+    p->chain_used = false;
+    p->dom_q_active = false;
+    HIPCHK(hipMemsetAsync(p->A.prog + p->sch.ngroups, 0, sizeof(int), sR));
+    if ((rc = restore_states(p, p->st0))) return rc;
+    const dim3 vgrid(p->npad / SX_VBLOCK), vblock(SX_VBLOCK);
+    const size_t lds = (size_t)2 * p->M * sizeof(float4);
+    for (int c = 0; c < p->nchunks; ++c) {
+        const int t0c = c * p->Tc, Tcur = chunk_len(p, c);
+        if (c > 0) { hipEvent_t e = p->event(); HIPCHK(hipEventRecord(e, sR)); HIPCHK(hipStreamWaitEvent(sV, e, 0)); }
+        const SxDeviceArrays B = view_at(p, 0);
+        p->mark_begin(0, sV);
+        switch (st) {
+            case 1: hipLaunchKernelGGL((sx_k_vert_fwd_d<1>), vgrid, vblock, 0, sV, B, t0c, Tcur); break;
+            case 2: hipLaunchKernelGGL((sx_k_vert_fwd_d<2>), vgrid, vblock, 0, sV, B, t0c, Tcur); break;
+            case 3: hipLaunchKernelGGL((sx_k_vert_fwd_d<3>), vgrid, vblock, 0, sV, B, t0c, Tcur); break;
+            default: hipLaunchKernelGGL((sx_k_vert_fwd_d<4>), vgrid, vblock, 0, sV, B, t0c, Tcur); break;
+        }
+        p->mark_end();
+        hipEvent_t e = p->event(); HIPCHK(hipEventRecord(e, sV)); HIPCHK(hipStreamWaitEvent(sR, e, 0));
+        SxDeviceArrays Bt = B; Bt.qdT = nullptr;
+        for (int pass = 1; pass <= 2; ++pass)                           // values (forward_d's primal forms, hr_imd tape on), then tangents
+            for (int r = 0; r < p->sch.nrounds; ++r) {                  // one launch per round
+                const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
+                p->mark_begin(1, sR);
+                if (pass == 1) hipLaunchKernelGGL((sx_k_route_fwd<true, false, 1>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c, Tcur);
+                else           hipLaunchKernelGGL((sx_k_route_fwd<false, false, 2>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c, Tcur);
+                p->mark_end();
+            }
+    }
+    // cost (values) and its tangent in the reference's summation order
+    if ((rc = run_cost(p, 0, 0.f))) return rc;
+    float jobs_d = 0.f;
+    if (p->ng > 0) {
+        SxCostArgs C = cost_args(p, 0.f);
+        hipLaunchKernelGGL(k_gauge_rows, dim3((p->nt + 255) / 256, p->ng), dim3(256), 0, sR, p->d_qsim_d, p->A.qgd, p->d_gauge_gid, p->ng, p->nt);
+        hipLaunchKernelGGL(sx_k_cost_tangent, dim3(1), dim3(64), 0, sR, C, p->A.qgd, p->d_cost_out + 1);
+        HIPCHK(hipMemcpyAsync(&jobs_d, p->d_cost_out + 1, sizeof(float), hipMemcpyDeviceToHost, sR));
+    }
+    HIPCHK(hipStreamSynchronize(sV));
+    HIPCHK(hipStreamSynchronize(sR));
+    HIPCHK(hipGetLastError());
+    if (p->chain_used) {
+        int stalled = 0;
+        HIPCHK(hipMemcpy(&stalled, p->A.prog + p->sch.ngroups, sizeof(int), hipMemcpyDeviceToHost));
+        if (stalled) return fail(SMASHX_E_HIP, "chained routing launch stalled");
+    }
+    *cost_d = jobs_d + p->opt.wjreg * jreg_d;                        // COMPUTE_COST_D (forward_db.f90:3248)
+    if (qsim_d && p->ng > 0) {
+        std::vector<float> qd((size_t)p->ng * p->nt);
+        HIPCHK(hipMemcpy(qd.data(), p->d_qsim_d, qd.size() * 4, hipMemcpyDeviceToHost));
+        for (int g = 0; g < p->ng; ++g)
+            for (int t = 0; t < p->nt; ++t) qsim_d[g + (size_t)p->ng * t] = qd[(size_t)g * p->nt + t];
+    }
+    p->last_adjoint = 0;
+    // primal outputs exactly like base_forward (parameters / states denormalised + round trip, states restored)
+    return smashx_download(p, 0, params, states, qsim, costs, nullptr, nullptr, nullptr);
 }
 
 int smashx_forward_b(smashx_plan* p, smashx_parameters* params, const smashx_parameters* params_bgd, smashx_states* states,

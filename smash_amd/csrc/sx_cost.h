@@ -275,3 +275,121 @@ __global__ void sx_k_cost_cellseeds(SxCostArgs C) {
         if (C.gauge_gid[g] == gc) acc = acc + C.qsim_b[(size_t)g * C.nt + t];
     C.qgb[(size_t)gc * C.nt + t] = acc;
 }
+
+// ------------------------------------------------------------------------------------------------
+// tangent of the cost: COMPUTE_JOBS_D (forward_db.f90:2445-2551) with NSE_D / KGE_D / SE_D / RMSE_D / LOGARITHMIC_D
+// and QUANTILE_D.  The criteria derivatives are differences of nearly equal fp32 sums, so they are evaluated with the
+// reference's formulas and summation order (one thread per gauge, sequential in time); a mathematically equal
+// evaluation through the adjoint seeds lands 5e-6 away.  qgd = q_d at the gauge cells; out[0] = jobs_d.
+// ------------------------------------------------------------------------------------------------
+__device__ inline void sx_heap_sort_pair(int n, float* arr, float* arr_d) {
+    if (n < 2) return;
+    int l = n / 2 + 1, ir = n;
+    for (;;) {
+        float a, ad;
+        if (l > 1) { l = l - 1; a = arr[l - 1]; ad = arr_d[l - 1]; }
+        else {
+            a = arr[ir - 1]; ad = arr_d[ir - 1];
+            arr[ir - 1] = arr[0]; arr_d[ir - 1] = arr_d[0];
+            ir = ir - 1;
+            if (ir == 1) { arr[0] = a; arr_d[0] = ad; return; }
+        }
+        int i = l, j = l + l;
+        while (j <= ir) {
+            if (j < ir && arr[j - 1] < arr[j]) j = j + 1;
+            if (a < arr[j - 1]) { arr[i - 1] = arr[j - 1]; arr_d[i - 1] = arr_d[j - 1]; i = j; j = j + j; }
+            else j = ir + 1;
+        }
+        arr[i - 1] = a; arr_d[i - 1] = ad;
+    }
+}
+
+__global__ void sx_k_cost_tangent(SxCostArgs C, const float* qgd, float* out) {
+    float* gj = C.med; float* gjd = C.med + C.ng;     // gauge_jobs, gauge_jobs_d
+    for (int g = threadIdx.x; g < C.ng; g += blockDim.x) {
+        gj[g] = 0.f; gjd[g] = 0.f;
+        const float w = C.wgauge[g];
+        if (!(w > 0.f || w < 0.f)) continue;
+        int n = 0;
+        float sum_x = 0.f, sum_y = 0.f, sum_xx = 0.f, sum_yy = 0.f, sum_xy = 0.f, sum_y_d = 0.f, sum_yy_d = 0.f, sum_xy_d = 0.f;
+        float se = 0.f, se_d = 0.f, lg = 0.f, lg_d = 0.f;
+        bool any = false;
+        const float* yd = qgd + (size_t)C.gauge_gid[g] * C.nt;
+        for (int t = C.s0; t < C.nt; ++t) {
+            const float x = sx_qo(C, g, t), y = sx_qs(C, g, t);
+            const float y_d = C.dt * 1e3f * yd[t] / C.area[g];
+            if (x >= 0.f) {
+                any = true;
+                n++;
+                sum_x = sum_x + x; sum_y_d = sum_y_d + y_d; sum_y = sum_y + y;
+                sum_xx = sum_xx + x * x;
+                sum_yy_d = sum_yy_d + 2.f * y * y_d; sum_yy = sum_yy + y * y;
+                sum_xy_d = sum_xy_d + x * y_d; sum_xy = sum_xy + x * y;
+                se_d = se_d - 2.f * (x - y) * y_d; se = se + (x - y) * (x - y);
+            }
+            if (x > 0.f && y > 0.f) {
+                const float a_d = y_d / x, a = y / x;
+                const float lt = sx_logf(a);
+                lg_d = lg_d + x * (lt * a_d / a + lt * a_d / a);
+                lg = lg + x * (lt * lt);
+            }
+        }
+        const float fn = (float)n;
+        float gauge_jobs = 0.f, gauge_jobs_d = 0.f, j_imd = 0.f, j_imd_d = 0.f;
+        for (int j = 0; j < C.njf; ++j) {
+            if (any) {
+                const int fun = C.jobs_fun[j];
+                if (fun == 1) {
+                    const float mean_x = sum_x / fn;
+                    const float num_d = sum_yy_d - 2.f * sum_xy_d, num = sum_xx - 2.f * sum_xy + sum_yy;
+                    const float den = sum_xx - fn * mean_x * mean_x;
+                    j_imd_d = num_d / den; j_imd = num / den;
+                } else if (fun == 2 || fun == 3) {
+                    const float mean_x = sum_x / fn, mean_y_d = sum_y_d / fn, mean_y = sum_y / fn;
+                    const float var_x = sum_xx / fn - mean_x * mean_x;
+                    const float var_y_d = sum_yy_d / fn - 2.f * mean_y * mean_y_d, var_y = sum_yy / fn - mean_y * mean_y;
+                    const float cov_d = sum_xy_d / fn - mean_x * mean_y_d, cov = sum_xy / fn - mean_x * mean_y;
+                    const float sx = sqrtf(var_x), sy = sqrtf(var_y);
+                    const float sy_d = (var_y == 0.f) ? 0.f : var_y_d / (2.0f * sy);
+                    const float r = cov / (sx * sy);
+                    const float r_d = (cov_d - r * sx * sy_d) / (sx * sy);
+                    const float a_d = sy_d / sx, a = sy / sx;
+                    const float b_d = mean_y_d / mean_x, b = mean_y / mean_x;
+                    const float arg1_d = 2.f * (r - 1.f) * r_d + 2.f * (b - 1.f) * b_d + 2.f * (a - 1.f) * a_d;
+                    const float arg1 = (r - 1.f) * (r - 1.f) + (b - 1.f) * (b - 1.f) + (a - 1.f) * (a - 1.f);
+                    const float kv = sqrtf(arg1);
+                    const float kd = (arg1 == 0.f) ? 0.f : arg1_d / (2.0f * kv);
+                    if (fun == 2) { j_imd_d = kd; j_imd = kv; } else { j_imd_d = 2.f * kv * kd; j_imd = kv * kv; }
+                } else if (fun == 4) { j_imd_d = se_d; j_imd = se; }
+                else if (fun == 5) {
+                    const float tv = sqrtf(se / fn);
+                    j_imd_d = (se / fn == 0.f) ? 0.f : se_d / (2.0f * tv * fn);
+                    j_imd = tv;
+                } else if (fun == 6) { j_imd_d = lg_d; j_imd = lg; }
+            }
+            gauge_jobs_d = gauge_jobs_d + C.wjobs_fun[j] * j_imd_d;
+            gauge_jobs = gauge_jobs + C.wjobs_fun[j] * j_imd;
+        }
+        gj[g] = gauge_jobs; gjd[g] = gauge_jobs_d;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float jobs_d = 0.f;
+    int arr_size = 0;
+    for (int g = 0; g < C.ng; ++g) {
+        const float w = C.wgauge[g];
+        if (w > 0.f) jobs_d = jobs_d + w * gjd[g];
+        else if (w < 0.f) { gj[arr_size] = gj[g]; gjd[arr_size] = gjd[g]; ++arr_size; }   // in place: arr_size <= g
+    }
+    if (arr_size > 0) {   // QUANTILE_D, p = 0.5
+        jobs_d = gjd[0];
+        if (arr_size > 1) {
+            sx_heap_sort_pair(arr_size, gj, gjd);
+            const float frac = (float)(arr_size - 1) * 0.5f + 1.f;
+            if (frac <= 1.f) jobs_d = gjd[0];
+            else if (frac >= (float)arr_size) jobs_d = gjd[arr_size - 1];
+            else { const int k = (int)frac; jobs_d = gjd[k - 1] + (frac - (float)k) * (gjd[k] - gjd[k - 1]); }
+        }
+    }
+    out[0] = jobs_d;
+}

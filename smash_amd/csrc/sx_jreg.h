@@ -138,3 +138,28 @@ __global__ void sx_k_plane_scale(float* dst, const float* src, float scale, int 
     const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (c < n2) dst[c] = scaled ? scale * src[c] : src[c];
 }
+
+// ---------------------------------------------------------------- tangent (REG_PRIOR_D, REG_SMOOTHING_D)
+// terms of the running sums res_d of forward_db.f90:5720-5750 / 5382-5500; xd = tangent of the (normalised) field
+__global__ void sx_k_prior_terms_d(float* t, const float* x, const float* xb, const float* xd, long n2) {
+    const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (c >= n2) return;
+    t[c] = 2.f * (x[c] - xb[c]) * xd[c];
+}
+__global__ void sx_k_smooth_terms_d(float* t, const float* x, const float* xb, const float* xd, int rel, const int* active, int nrow, int ncol) {
+    const long c = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (c >= (long)nrow * ncol) return;
+    float v = 0.f;
+    if (active[c] == 1) {
+        const int row = (int)(c % nrow), col = (int)(c / nrow);
+        int mnc, mxc, mnr, mxr;
+        sx_smooth_bounds(active, nrow, ncol, row, col, mnc, mxc, mnr, mxr);
+        const float m0 = sx_smooth_mat(x, xb, rel, c);
+        const float dr = sx_smooth_mat(x, xb, rel, mxr + (long)col * nrow) - 2.f * m0 + sx_smooth_mat(x, xb, rel, mnr + (long)col * nrow);
+        const float dc = sx_smooth_mat(x, xb, rel, row + (long)mxc * nrow) - 2.f * m0 + sx_smooth_mat(x, xb, rel, row + (long)mnc * nrow);
+        const float dr_d = xd[mxr + (long)col * nrow] - 2.f * xd[c] + xd[mnr + (long)col * nrow];
+        const float dc_d = xd[row + (long)mxc * nrow] - 2.f * xd[c] + xd[row + (long)mnc * nrow];
+        v = 2.f * dr * dr_d + 2.f * dc * dc_d;
+    }
+    t[c] = v;
+}

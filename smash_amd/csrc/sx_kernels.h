@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "sx_ops.h"
+#include "sx_tangent.h"
 
 #define SX_BT 4           // time steps per routing super-step (one float4 per cell per super-step)
 #define SX_VBLOCK 256     // threads (cells) per vertical workgroup
@@ -110,6 +111,9 @@ struct SxDeviceArrays {
     float *ci_b, *cp_b, *cft_b, *cst_b, *exc_b, *lr_b, *hi_b, *hp_b, *hft_b, *hst_b, *hlr_b;
     // chunk buffers
     float *qtT, *hrT;
+    // tangent sweep (base_forward_d): qt_d per cell (T4 like qtT), exchange series of q_d, q_d at the gauge cells.
+    // The tangents of parameters and states live in the gradient arrays (ci_b .. hlr_b) during a tangent sweep.
+    float *qtdT, *xdT, *qgd;
     float* qdT;                   // optional: discharge of every cell (setup%save_qsim_domain), T4 like qtT; null = off
     float *tape_hi, *tape_hp, *tape_hft, *tape_hst;
     float* xT;                    // exchange series
@@ -197,6 +201,64 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// vertical forward with tangents (inner body of GR_x_FORWARD_D, forward_db.f90:7748-9602): thread per cell; writes
+// qt to qtT and qt_d to qtdT; the tangents of the states march along in the *_b arrays
+// ------------------------------------------------------------------------------------------------
+template <int ST>
+__global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, int t0, int T) {
+    const int k = blockIdx.x * SX_VBLOCK + threadIdx.x;
+    if (k >= A.n) return;
+    const size_t npad = (size_t)A.npad;
+    SxCellParams P;
+    P.ci = (ST == 2 || ST == 3) ? A.ci[k] : 1.f;
+    P.cp = A.cp[k];
+    P.cft = A.cft[k];
+    P.cst = (ST == 3) ? A.cst[k] : 1.f;
+    P.exc = (ST != 4) ? A.exc[k] : 0.f;
+    sx_cell_params_init(P);
+    SxAdjParams Q;
+    Q.cst_m5 = 1.f;
+    sx_pow_m4_m5(P.cft, &P.cft_m4, &Q.cft_m5);
+    P.cst_m4 = 1.f;
+    if (ST == 3) sx_pow_m4_m5(P.cst, &P.cst_m4, &Q.cst_m5);
+    Q.dcft2 = sx_mkdiv(P.cft * P.cft);
+    Q.dcst2 = sx_mkdiv(P.cst * P.cst);
+    Q.dcp2 = sx_mkdiv(P.cp * P.cp);
+    SxTanParams D;
+    D.ci_d = (ST == 2 || ST == 3) ? A.ci_b[k] : 0.f;
+    D.cp_d = A.cp_b[k];
+    D.cft_d = A.cft_b[k];
+    D.cst_d = (ST == 3) ? A.cst_b[k] : 0.f;
+    D.exc_d = (ST != 4) ? A.exc_b[k] : 0.f;
+    SxDual hi = sx_mk(0.f, 0.f), hp, hft, hst = sx_mk(0.f, 0.f);
+    if (ST == 2 || ST == 3) hi = sx_mk(A.hi[k], A.hi_b[k]);
+    hp = sx_mk(A.hp[k], A.hp_b[k]);
+    hft = sx_mk(A.hft[k], A.hft_b[k]);
+    if (ST == 3) hst = sx_mk(A.hst[k], A.hst_b[k]);
+    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
+    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    float4* qt4 = reinterpret_cast<float4*>(A.qtT) + k;
+    float4* qd4 = reinterpret_cast<float4*>(A.qtdT) + k;
+    for (int tq = 0; tq * 4 < T; ++tq) {
+        float q[4] = {0.f, 0.f, 0.f, 0.f}, qd[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tt = tq * 4 + i;
+            if (tt < T) {
+                const SxDual r = sx_vertical_step_d<ST>(P, Q, D, prcp_p[(size_t)tt * npad], pet_p[(size_t)tt * npad], hi, hp, hft, hst);
+                q[i] = r.v; qd[i] = r.d;
+            }
+        }
+        qt4[(size_t)tq * npad] = make_float4(q[0], q[1], q[2], q[3]);
+        qd4[(size_t)tq * npad] = make_float4(qd[0], qd[1], qd[2], qd[3]);
+    }
+    if (ST == 2 || ST == 3) { A.hi[k] = hi.v; A.hi_b[k] = hi.d; }
+    A.hp[k] = hp.v; A.hp_b[k] = hp.d;
+    A.hft[k] = hft.v; A.hft_b[k] = hft.d;
+    if (ST == 3) { A.hst[k] = hst.v; A.hst_b[k] = hst.d; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // routing forward: one workgroup per routing group, time-skewed wavefront through LDS.
 // Slot j at stage s handles time block (w - s) in super-step w; its children (stage s-1) published that
 // block in super-step w-1.  upstream_discharge + linear_routing + the q update of
@@ -212,8 +274,17 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
 #endif
 #define SX_MAXGROUP 512   // largest routing workgroup (group_size); 8 waves, registers are not the limit
 
-template <bool TAPE, bool CHAIN>
+// TMODE 2: the same wavefront on the tangents (UPSTREAM_DISCHARGE_D, LINEAR_ROUTING_D and the q update of
+// GR_x_FORWARD_D): reads qt_d (qtdT) and the hr_imd tape of the value pass, carries hlr_d (hlr_b), publishes q_d series
+// in xdT, q_d at the gauge cells in qgd; TAPE must be false.
+// TMODE 1: the value pass of a tangent sweep.  The Tapenade tangent code re-associates two primal expressions
+// (qup = dt*(qup/temp), forward_db.f90:6464; q = temp*((qt + f*qrout)/dt), :8445-8448): forward_d's discharge differs
+// from forward's in the last bit, and the criteria derivatives amplify that to ~5e-6 of cost_d, so the tangent sweep
+// evaluates the primal the way forward_d does.
+template <bool TAPE, bool CHAIN, int TMODE = 0>
 __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, int g0, int gend, int t0, int T) {
+    constexpr bool TAN = (TMODE == 2);
+    constexpr bool DFORM = (TMODE == 1);
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];   // [2][blockDim.x]
     const int g = g0 + blockIdx.x;
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
@@ -223,7 +294,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
     if (A.gtime && j == 0) A.gtime[2 * g] = wall_clock64();
 
     int cell = -1, stage = 0, cstart = 0, ccount = 0, xout = -1, xin = -1, gid = -1;
-    float a = 0.f, f = 0.f, den = 1.f, hlr = 0.f;
+    float a = 0.f, f = 0.f, den = 1.f, hlr = 0.f, ad = 0.f;
     bool hasup = false;
     if (valid) {
         const int c = A.s_cell[sb + j];
@@ -231,7 +302,8 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
         if (c >= 0) {
             cell = c;
             cstart = A.s_cstart[sb + j]; ccount = A.s_ccount[sb + j]; xout = A.s_xout[sb + j];
-            a = A.rt_a[c]; f = A.rt_f[c]; den = A.rt_denf[c]; hlr = A.hlr[c];
+            a = A.rt_a[c]; f = A.rt_f[c]; den = (TAN || DFORM) ? A.rt_denb[c] : A.rt_denf[c]; hlr = TAN ? A.hlr_b[c] : A.hlr[c];
+            if (TAN) { const float lrv = A.lr[c]; ad = a * ((A.dt / (60.f * lrv)) * A.lr_b[c] / lrv); }
             hasup = A.flwacc[c] > 1;
             gid = A.cell_gauge[c];
         } else {
@@ -241,11 +313,12 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
     const float dt = A.dt, dx = A.dx;
     const SxDiv dden = sx_mkdiv(den), ddt = sx_mkdiv(dt);
     // T4 addressing: element (tb, id) of an array with `stride` float4 per time block
-    const float4* src = (cell >= 0) ? reinterpret_cast<const float4*>(A.qtT) + cell
-                                    : reinterpret_cast<const float4*>(A.xT) + (xin >= 0 ? xin : 0);
+    const float4* src = (cell >= 0) ? reinterpret_cast<const float4*>(TAN ? A.qtdT : A.qtT) + cell
+                                    : reinterpret_cast<const float4*>(TAN ? A.xdT : A.xT) + (xin >= 0 ? xin : 0);
     const size_t sstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
-    float4* x4 = reinterpret_cast<float4*>(A.xT);
+    float4* x4 = reinterpret_cast<float4*>(TAN ? A.xdT : A.xT);
     float4* hr4 = reinterpret_cast<float4*>(A.hrT);
+    float* gauge_out = TAN ? A.qgd : A.qg;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // chained rounds: an inlet whose series is published inside this launch follows its producer's counter
     const int* wprog = nullptr;
@@ -253,20 +326,21 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
     if (CHAIN && xin >= 0) { const int pg = A.x_prod[xin]; if (pg >= g0 && pg < gend) wprog = A.prog + pg; }
     auto fetch = [&](int tb) -> float4 { return sx_gload4(src + (size_t)tb * sstride); };
 
-    float4 nxt[SX_MU], outq[SX_MU], outh[SX_MU];
+    float4 nxt[SX_MU], outq[SX_MU], outh[SX_MU], nhr[SX_MU];
     if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - stage, nb), seen, A.prog + A.ngroups);
 #pragma unroll
     for (int u = 0; u < SX_MU; ++u) {
         const int tb = u - stage;
         nxt[u] = (valid && tb >= 0 && tb < nb) ? fetch(tb) : zero4;
+        nhr[u] = (TAN && valid && cell >= 0 && tb >= 0 && tb < nb) ? sx_gload4(hr4 + (size_t)tb * A.npad + cell) : zero4;
         outq[u] = zero4; outh[u] = zero4;
     }
     const int nsuper = nb + dmax;
     const int nmacro = (nsuper + SX_MU - 1) / SX_MU;
     for (int mw = 0; mw <= nmacro; ++mw) {
-        float4 cur[SX_MU];
+        float4 cur[SX_MU], chr[SX_MU];
 #pragma unroll
-        for (int u = 0; u < SX_MU; ++u) { cur[u] = nxt[u]; sx_pin(cur[u]); }
+        for (int u = 0; u < SX_MU; ++u) { cur[u] = nxt[u]; sx_pin(cur[u]); if (TAN) { chr[u] = nhr[u]; sx_pin(chr[u]); } }
         // chained: the stores of the previous macro-step (four super-steps old) have completed past this point
         if (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // results of the previous macro-step leave now
@@ -282,7 +356,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
                         const float qv[4] = {outq[u].x, outq[u].y, outq[u].z, outq[u].w};
 #pragma unroll
                         for (int i = 0; i < SX_BT; ++i)
-                            if (tb * SX_BT + i < T) A.qg[(size_t)gid * A.nt + t0 + tb * SX_BT + i] = qv[i];
+                            if (tb * SX_BT + i < T) gauge_out[(size_t)gid * A.nt + t0 + tb * SX_BT + i] = qv[i];
                     }
                 }
             }
@@ -294,6 +368,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
         for (int u = 0; u < SX_MU; ++u) {
             const int tb = SX_MU * (mw + 1) + u - stage;
             nxt[u] = (valid && tb >= 0 && tb < nb) ? fetch(tb) : zero4;
+            if (TAN) nhr[u] = (valid && cell >= 0 && tb >= 0 && tb < nb) ? sx_gload4(hr4 + (size_t)tb * A.npad + cell) : zero4;
         }
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
@@ -324,23 +399,43 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
                     // four steps are independent and overlap (a lone wave pays the full latency of every dependent op)
 #pragma unroll
                     for (int i = 0; i < SX_BT; ++i) {
-                        const float d = sx_div(s[i] * dt, dden);
+                        const float d = DFORM ? dt * sx_div(s[i], dden) : sx_div(s[i] * dt, dden);
                         qup[i] = hasup ? d : 0.f;
                     }
+                    if (!TAN) {
 #pragma unroll
-                    for (int i = 0; i < SX_BT; ++i) {
-                        // steps beyond T (only in the last block of a chunk) are computed and discarded
-                        const bool live = tl + i < T;
-                        const float hr_imd = hlr + qup[i];
-                        const float hnew = hr_imd * a;
-                        qro[i] = hr_imd - hnew;
-                        hr[i] = live ? hr_imd : 0.f;
-                        hlr = live ? hnew : hlr;
-                    }
+                        for (int i = 0; i < SX_BT; ++i) {
+                            // steps beyond T (only in the last block of a chunk) are computed and discarded
+                            const bool live = tl + i < T;
+                            const float hr_imd = hlr + qup[i];
+                            const float hnew = hr_imd * a;
+                            qro[i] = hr_imd - hnew;
+                            hr[i] = live ? hr_imd : 0.f;
+                            hlr = live ? hnew : hlr;
+                        }
 #pragma unroll
-                    for (int i = 0; i < SX_BT; ++i) {
-                        const float v = sx_div((qt[i] + qro[i] * f) * dx * dx * 0.001f, ddt);
-                        q[i] = (tl + i < T) ? v : 0.f;
+                        for (int i = 0; i < SX_BT; ++i) {
+                            const float v = DFORM ? (0.001f * (dx * dx)) * sx_div(qt[i] + f * qro[i], ddt)
+                                                  : sx_div((qt[i] + qro[i] * f) * dx * dx * 0.001f, ddt);
+                            q[i] = (tl + i < T) ? v : 0.f;
+                        }
+                    } else {
+                        // hlr carries hr_d; hrv = hr_imd of the value pass:  hr_d = a hr_imd_d + hr_imd (a arg1_d)
+                        const float hrv[SX_BT] = {chr[u].x, chr[u].y, chr[u].z, chr[u].w};
+#pragma unroll
+                        for (int i = 0; i < SX_BT; ++i) {
+                            const bool live = tl + i < T;
+                            const float hr_imd_d = hlr + qup[i];
+                            const float hnew_d = a * hr_imd_d + hrv[i] * ad;
+                            qro[i] = hr_imd_d - hnew_d;
+                            hr[i] = 0.f;
+                            hlr = live ? hnew_d : hlr;
+                        }
+#pragma unroll
+                        for (int i = 0; i < SX_BT; ++i) {
+                            const float v = sx_div((0.001f * (dx * dx)) * (qt[i] + f * qro[i]), ddt);
+                            q[i] = (tl + i < T) ? v : 0.f;
+                        }
                     }
                     const float4 q4 = make_float4(q[0], q[1], q[2], q[3]);
                     pub[j] = q4;
@@ -356,7 +451,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
             if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0) sx_publish(A.prog + g, done); }
         }
     }
-    if (valid && cell >= 0) A.hlr[cell] = hlr;
+    if (valid && cell >= 0) { if (TAN) A.hlr_b[cell] = hlr; else A.hlr[cell] = hlr; }
     if (A.gtime && j == 0) A.gtime[2 * g + 1] = wall_clock64();
     if (CHAIN) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

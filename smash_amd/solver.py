@@ -232,6 +232,28 @@ class Solver:
         return float(costs.cost)
 
 
+def _tangent_call(s, parameters, parameters_d, parameters_bgd, states, states_d, states_bgd, output, output_d):
+    P, k1 = s._pack(parameters, PARAM_NAMES, _lib.Parameters)
+    PD, k2 = s._pack(parameters_d, PARAM_NAMES, _lib.Parameters)
+    PB, k3 = s._pack(parameters_bgd, PARAM_NAMES, _lib.Parameters)
+    S, k4 = s._pack(states, STATE_NAMES, _lib.States)
+    SD, k5 = s._pack(states_d, STATE_NAMES, _lib.States)
+    SB, k6 = s._pack(states_bgd, STATE_NAMES, _lib.States)
+    qs = np.zeros((s.ng, s.nt), np.float32, order="F") if s.ng else None
+    qd = np.zeros((s.ng, s.nt), np.float32, order="F") if s.ng else None
+    costs = _lib.Costs()
+    cost_d = C.c_float(0.0)
+    _lib.check(_lib.lib().smashx_forward_d(s._h, C.byref(P), C.byref(PD), C.byref(PB), C.byref(S), C.byref(SD), C.byref(SB),
+                                           _ptr(qs), _ptr(qd), C.byref(costs), C.byref(cost_d)))
+    if output is not None:
+        if qs is not None:
+            output.qsim = qs
+        output.cost, output.cost_jobs, output.cost_jreg = float(costs.cost), float(costs.cost_jobs), float(costs.cost_jreg)
+    if output_d is not None and qd is not None:
+        output_d.qsim = qd
+    return float(costs.cost), float(cost_d.value)
+
+
 def _solver_for(setup, mesh, input_data, **kw):
     s = getattr(input_data, "_smashx_solver", None)
     if s is None or s._sig != Solver.signature(setup, mesh):
@@ -273,3 +295,31 @@ def forward_b(setup, mesh, input_data, parameters, parameters_b, parameters_bgd,
     s.upload(parameters, states, parameters_bgd, states_bgd)
     s.sweep(True, float(cost_b))
     return s.download(True, parameters, states, output, parameters_b, states_b)
+
+
+def forward_d(setup, mesh, input_data, parameters, parameters_d, parameters_bgd, parameters_bgd_d, states, states_d,
+              states_bgd, states_bgd_d, output, output_d, cost=None, cost_d=None):
+    """Drop-in for mw_forward::forward_d (mw_forward.f90:70-97), the tangent-linear model: returns (cost, cost_d) and
+    fills output.qsim / output_d.qsim.  *_bgd_d are passive in the reference and are ignored."""
+    s = _solver_for(setup, mesh, input_data)
+    return _tangent_call(s, parameters, parameters_d, parameters_bgd, states, states_d, states_bgd, output, output_d)
+
+
+def scalar_product_test(setup, mesh, input_data, parameters, states, output):
+    """mw_adjoint_test::scalar_product_test (mw_adjoint_test.f90:26-105): <dY*, dY> = cost_b * cost_d against
+    <dk*, dk> = sum(parameters_b * parameters_d) for dk = 1 on every parameter field and 0 on the states.
+    Returns (sp1, sp2)."""
+    from .types import OutputDT
+    par_d, sta_d = parameters.copy(), states.copy()
+    for k in PARAM_NAMES:
+        getattr(par_d, k)[...] = 1.0
+    for k in STATE_NAMES:
+        getattr(sta_d, k)[...] = 0.0
+    par_b, sta_b = parameters.copy(), states.copy()
+    out_d, out_b = OutputDT(setup, mesh), OutputDT(setup, mesh)
+    _, cost_d = forward_d(setup, mesh, input_data, parameters.copy(), par_d, parameters.copy(), parameters.copy(), states.copy(),
+                          sta_d, states.copy(), states.copy(), output, out_d)
+    forward_b(setup, mesh, input_data, parameters.copy(), par_b, parameters.copy(), parameters.copy(), states.copy(), sta_b,
+              states.copy(), states.copy(), output, out_b, 0.0, 1.0)
+    sp2 = float(sum(np.sum(getattr(par_b, k).astype(np.float64) * getattr(par_d, k)) for k in PARAM_NAMES))
+    return 1.0 * cost_d, sp2

@@ -152,6 +152,37 @@ def main():
               f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def tangent_direction(g):
+    """The direction the tangent fixtures use: 1 % of every field, signed like the reference gradient, so that
+    cost_d = sum |grad . d| is well conditioned (a random direction makes cost_d a cancelling sum)."""
+    pd = {k: np.asfortranarray((0.01 * np.maximum(np.abs(v), 1e-3) * np.sign(g.adj["parameters_b"][k])).astype(np.float32))
+          for k, v in g.params.items()}
+    sd = {k: np.asfortranarray((0.01 * np.maximum(np.abs(v), 1e-3) * np.sign(g.adj["states_b"][k])).astype(np.float32))
+          for k, v in g.states.items()}
+    return pd, sd
+
+
+TANGENT_CASES = ["gr_a_12x12x48_nse", "gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask", "gr_d_12x12x48_rmse_kge2_start",
+                 "gr_b_24x24x120_norm_jreg", "gr_b_16x16x96_median2", "gr_c_32x32x240_d8_ragged"]
+
+
+def main_tangent():
+    """forward_d of the reference (mw_forward.f90:70-97) along tangent_direction(): cost_d, qsim_d and their
+    flag-to-flag noise (-O3 + FMA build against the parity build)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import golden_util as gu
+    os.makedirs(os.path.join(OUT, "tangent"), exist_ok=True)
+    for name in TANGENT_CASES:
+        g = gu.load(name)
+        pd, sd = tangent_direction(g)
+        r = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, params_d=pd, states_d=sd, **g.opts)
+        r3 = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, params_d=pd, states_d=sd, fast=True, **g.opts)
+        np.savez_compressed(os.path.join(OUT, "tangent", name + ".npz"), cost_d=np.float32(r["cost_d"]), qsim_d=r["qsim_d"],
+                            noise_cost_d=np.float64(abs(r3["cost_d"] - r["cost_d"]) / abs(r["cost_d"])),
+                            noise_qsim_d=np.array([rel_l2(r3["qsim_d"][i], r["qsim_d"][i]) for i in range(g.mesh.ng)]))
+        print(f"tangent {name}: cost_d={r['cost_d']:.8g} noise={abs(r3['cost_d'] - r['cost_d']) / abs(r['cost_d']):.2g}")
+
+
 def main_lbfgsb():
     """Row f1: the reference's own optimize_lbfgsb (mw_optimize.f90:484-676) on the gr-b 24x24x120 case,
     distributed mapping over cp, cft, exc, lr: cost after 0..4 iterations and the final parameter fields."""
@@ -183,3 +214,4 @@ if __name__ == "__main__":
     if not [a for a in sys.argv[1:] if not a.startswith("-")]:
         os.makedirs(os.path.join(OUT, "lbfgsb"), exist_ok=True)
         main_lbfgsb()
+        main_tangent()

@@ -50,3 +50,20 @@ def test_oracle_gradient_taylor():
         fd = (cp_ - cm_) / (2 * eps)
         ad = float(np.sum(o["parameters_b"][k].astype(np.float64) * d))
         assert abs(fd - ad) <= 2e-2 * max(abs(fd), abs(ad)) + 1e-7, (k, fd, ad)
+
+
+def test_tangent_oracle_is_bit_identical_to_reference_forward_d():
+    """orc_forward_d (oracle/smash_oracle_d.c) against the reference's own forward_d (tests/golden/tangent/*.npz,
+    make_golden.py::main_tangent): cost_d and qsim_d bit for bit on every case."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+    from oracle import pyoracle
+    for name in mg.TANGENT_CASES:
+        g = gu.load(name)
+        z = np.load(os.path.join(gu.GOLDEN_DIR, "tangent", name + ".npz"))
+        pd, sd = mg.tangent_direction(g)
+        r = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, params_d=pd, states_d=sd, **g.opts)
+        assert np.float32(r["cost_d"]) == z["cost_d"], name
+        assert np.array_equal(r["qsim_d"], z["qsim_d"]), name
