@@ -102,6 +102,17 @@ module smashx_c
             integer(c_int) :: rc
         end function smashx_set_domain_outputs
 
+        function smashx_forward_d(plan, params, params_d, params_bgd, states, states_d, states_bgd, qsim, qsim_d, costs, &
+        & cost_d) bind(C, name="smashx_forward_d") result(rc)
+            import
+            type(c_ptr), value :: plan, qsim, qsim_d
+            type(smashx_parameters) :: params, params_d, params_bgd
+            type(smashx_states) :: states, states_d, states_bgd
+            type(smashx_costs) :: costs
+            real(c_float) :: cost_d
+            integer(c_int) :: rc
+        end function smashx_forward_d
+
         function smashx_forward(plan, params, params_bgd, states, states_bgd, qsim, costs, fstates) &
         & bind(C, name="smashx_forward") result(rc)
             import :: c_int, c_ptr, smashx_parameters, smashx_states, smashx_costs
@@ -420,3 +431,64 @@ subroutine base_forward_b(setup, mesh, input_data, parameters, parameters_b, par
     output%cost_jreg = cc%cost_jreg
 
 end subroutine base_forward_b
+
+!  Tangent-linear model: replaces BASE_FORWARD_D (forward_db.f90:10517-10601) behind mw_forward::forward_d
+!  (mw_forward.f90:70-97).  parameters_bgd_d / states_bgd_d are passive in the reference; output_d is the one-field
+!  OUTPUTDT_DIFF (qsim), which callers hand over as an OutputDT.
+subroutine base_forward_d(setup, mesh, input_data, parameters, parameters_d, parameters_bgd, parameters_bgd_d, &
+& states, states_d, states_bgd, states_bgd_d, output, output_d, cost, cost_d)
+
+    use iso_c_binding
+    use md_constant
+    use mwd_setup
+    use mwd_mesh
+    use mwd_input_data
+    use mwd_parameters
+    use mwd_states
+    use mwd_output
+    use smashx_c
+    use smashx_glue
+
+    implicit none
+
+    type(SetupDT), intent(in), target :: setup
+    type(MeshDT), intent(in), target :: mesh
+    type(Input_DataDT), intent(in), target :: input_data
+    type(ParametersDT), intent(inout), target :: parameters, parameters_d
+    type(ParametersDT), intent(in), target :: parameters_bgd
+    type(ParametersDT), intent(in) :: parameters_bgd_d
+    type(StatesDT), intent(inout), target :: states, states_d
+    type(StatesDT), intent(in), target :: states_bgd
+    type(StatesDT), intent(in) :: states_bgd_d
+    type(OutputDT), intent(inout), target :: output, output_d
+    real(sp), intent(inout) :: cost, cost_d
+
+    type(smashx_parameters) :: cp, cpd, cpb
+    type(smashx_states) :: cs, csd, csb
+    type(smashx_costs) :: cc
+    type(c_ptr) :: qs, qd
+    real(c_float) :: cd
+
+    call smashx_prepare(setup, mesh, input_data)
+    call smashx_pack_parameters(parameters, cp)
+    call smashx_pack_parameters(parameters_d, cpd)
+    call smashx_pack_parameters(parameters_bgd, cpb)
+    call smashx_pack_states(states, cs)
+    call smashx_pack_states(states_d, csd)
+    call smashx_pack_states(states_bgd, csb)
+    qs = c_null_ptr
+    qd = c_null_ptr
+    if (mesh%ng .gt. 0) then
+        qs = c_loc(output%qsim)
+        qd = c_loc(output_d%qsim)
+    end if
+    cd = 0._c_float
+    call sx_check(smashx_forward_d(sx_plan, cp, cpd, cpb, cs, csd, csb, qs, qd, cc, cd), "forward_d")
+    cost_d = cd
+    !  the reference's COMPUTE_COST_D does not assign cost; the drop-in returns the value it has anyway
+    cost = cc%cost
+    output%cost = cc%cost
+    output%cost_jobs = cc%cost_jobs
+    output%cost_jreg = cc%cost_jreg
+
+end subroutine base_forward_d

@@ -1,7 +1,7 @@
 """GPU: the reference's OWN Fortran boundary running on the HIP path.
 
-oracle/_ref/libsmash_dropin.so is the unmodified reference solver with only base_forward / base_forward_b
-replaced by the ISO_C_BINDING shim fortran/smashx_dropin.f90 (built by oracle/ref/build_ref.sh in the build
+oracle/_ref/libsmash_dropin.so is the unmodified reference solver with only base_forward / base_forward_b /
+base_forward_d replaced by the ISO_C_BINDING shim fortran/smashx_dropin.f90 (built by oracle/ref/build_ref.sh in the build
 container; the prebuilt library travels to the GPU box).  The same bind(C) driver that produced the golden
 vectors (oracle/ref/ref_capi.f90 -> mw_forward::forward / forward_b, mw_optimize::optimize_lbfgsb) is called
 on it, so these tests exercise exactly what a maintainer gets by relinking the reference against libsmashx.
@@ -62,3 +62,21 @@ def test_reference_lbfgsb_loop_through_dropin():
     assert abs(costs[0] - ref[0]) <= 3e-7 + 1e-5 * abs(ref[0]), (costs, ref)
     assert costs[-1] < 0.8 * costs[0]
     assert abs(costs[-1] - ref[-1]) <= 0.02 * abs(ref[0]), (costs, ref)
+
+
+@pytest.mark.parametrize("name", ["gr_b_16x16x96_nse_gaps", "gr_b_24x24x120_norm_jreg"])
+def test_reference_forward_d_through_dropin(name):
+    """mw_forward::forward_d of the reference (mw_forward.f90:70-97) on the GPU tangent sweep: base_forward_d replaced by
+    the shim; against the golden vectors of the all-CPU reference (tests/golden/tangent)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+    g = gu.load(name)
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "tangent", name + ".npz"))
+    pd, sd = mg.tangent_direction(g)
+    r = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, params_d=pd, states_d=sd, fast="dropin", **g.opts)
+    for i in range(g.mesh.ng):
+        assert gu.rel_l2(r["qsim_d"][i], z["qsim_d"][i]) <= gu.tol(z["noise_qsim_d"][i]), i
+    ref = float(z["cost_d"])
+    assert abs(r["cost_d"] - ref) <= 1e-5 * abs(ref), (r["cost_d"], ref)
