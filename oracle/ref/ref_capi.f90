@@ -54,7 +54,7 @@ contains
         end select
     end function jreg_name
 
-    !  icfg(1)  structure id: 1 gr-a, 2 gr-b, 3 gr-c, 4 gr-d
+    !  icfg(1)  structure id: 1 gr-a, 2 gr-b, 3 gr-c, 4 gr-d, 5 vic-a
     !  icfg(2:5) nrow, ncol, nt, ng
     !  icfg(6)  sparse_storage (0/1)         icfg(7)  denormalize_forward (0/1)
     !  icfg(8)  optimize_start_step (1-based) icfg(9)  njf      icfg(10) njr
@@ -121,6 +121,7 @@ contains
         case (2); setup%structure = "gr-b"
         case (3); setup%structure = "gr-c"
         case (4); setup%structure = "gr-d"
+        case (5); setup%structure = "vic-a"
         end select
         setup%dt = rcfg(1)
         setup%sparse_storage = (icfg(6) .ne. 0)

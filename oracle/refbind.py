@@ -14,7 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 GNP, GNS = 16, 8
-STRUCTURES = {"gr-a": 1, "gr-b": 2, "gr-c": 3, "gr-d": 4}
+STRUCTURES = {"gr-a": 1, "gr-b": 2, "gr-c": 3, "gr-d": 4, "vic-a": 5}
 JOBS = {"nse": 1, "kge": 2, "kge2": 3, "se": 4, "rmse": 5, "logarithmic": 6}
 JREG = {"prior": 1, "smoothing": 2, "hard_smoothing": 3}
 GLB_P = np.array([1e-6] * 6 + [-50.0] + [1e-6] * 9, dtype=np.float32)

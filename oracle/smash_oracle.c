@@ -83,8 +83,11 @@ static void linear_routing(float dt, float qup, float lr, float* hr, float* qrou
 /* ------------------------------------------------------------------------------------------- */
 /* field views into the (nrow,ncol,16)/(nrow,ncol,8) packings                                   */
 /* ------------------------------------------------------------------------------------------- */
-enum { P_CI = 0, P_CP = 1, P_BETA = 2, P_CFT = 3, P_CST = 4, P_ALPHA = 5, P_EXC = 6, P_LR = 15 };
-enum { S_HI = 0, S_HP = 1, S_HFT = 2, S_HST = 3, S_HLR = 7 };
+enum { P_CI = 0, P_CP = 1, P_BETA = 2, P_CFT = 3, P_CST = 4, P_ALPHA = 5, P_EXC = 6, P_B = 7, P_CUSL1 = 8, P_CUSL2 = 9,
+       P_CLSL = 10, P_KS = 11, P_DS = 12, P_DSM = 13, P_WS = 14, P_LR = 15 };
+enum { S_HI = 0, S_HP = 1, S_HFT = 2, S_HST = 3, S_HUSL1 = 4, S_HUSL2 = 5, S_HLSL = 6, S_HLR = 7 };
+
+#include "smash_oracle_vic.h"
 
 /* one cell-step of gr_{a,b,c,d}_forward: md_forward_structure.f90:62-156 / 248-340 / 432-520 / 621-698.
  * tape (optional, 8 floats): pre-step hi,hp,hft,hst,hlr, qup, prcp, pet -- what the reverse sweep needs. */
@@ -108,6 +111,26 @@ static void cell_step(int st, float dt, float dx, int nrow, int ncol, const int*
     float* hft = S + S_HFT * n2 + c;
     float* hst = S + S_HST * n2 + c;
     float* hlr = S + S_HLR * n2 + c;
+    if (st == ORC_VIC_A) {   /* vic_a_forward, md_forward_structure.f90:762-931 */
+        float* husl1 = S + S_HUSL1 * n2 + c;
+        float* husl2 = S + S_HUSL2 * n2 + c;
+        float* hlsl = S + S_HLSL * n2 + c;
+        if (tape) { tape[0] = *husl1; tape[1] = *husl2; tape[2] = *hlsl; tape[3] = 0.f; tape[4] = *hlr; tape[6] = prcp; tape[7] = pet; }
+        float runoff = 0.f, qi = 0.f, qb = 0.f;
+        if (prcp >= 0.f && pet >= 0.f) {
+            vic_infiltration(prcp, P[P_CUSL1 * n2 + c], P[P_CUSL2 * n2 + c], P[P_B * n2 + c], husl1, husl2, &runoff);
+            vic_vertical_transfer(pet, P[P_CUSL1 * n2 + c], P[P_CUSL2 * n2 + c], P[P_CLSL * n2 + c], P[P_KS * n2 + c], husl1, husl2, hlsl);
+        }
+        vic_interflow(5.f, P[P_CUSL2 * n2 + c], husl2, &qi);
+        vic_baseflow(P[P_CLSL * n2 + c], P[P_DS * n2 + c], P[P_DSM * n2 + c], P[P_WS * n2 + c], hlsl, &qb);
+        qt = (runoff + qi + qb);
+        if (g_qt_out) *g_qt_out = qt;
+        qup = upstream_discharge(dt, dx, nrow, ncol, flwdir, flwacc, row, col, q);
+        if (tape) tape[5] = qup;
+        linear_routing(dt, qup, P[P_LR * n2 + c], hlr, &qrout);
+        q[c] = (qt + qrout * (float)(flwacc[c] - 1)) * dx * dx * 0.001f / dt;
+        return;
+    }
     if (tape) { tape[0] = *hi; tape[1] = *hp; tape[2] = *hft; tape[3] = *hst; tape[4] = *hlr; tape[6] = prcp; tape[7] = pet; }
 
     if (prcp >= 0.f && pet >= 0.f) {
@@ -601,7 +624,7 @@ int orc_forward(const orc_config* cfg, const int* flwdir, const int* flwacc, con
                 const float* pet, const float* qobs, const float* wgauge, float* P, const float* Pb,
                 float* S, const float* Sb, float* qsim, float* costs, float* fstates) {
     const long n2 = (long)cfg->nrow * cfg->ncol;
-    if (cfg->structure < ORC_GR_A || cfg->structure > ORC_GR_D) return -2;
+    if (cfg->structure < ORC_GR_A || cfg->structure > ORC_VIC_A) return -2;
     if (cfg->denormalize_forward) {
         denormalize(P, n2, ORC_GNP, cfg->lb_parameters, cfg->ub_parameters);
         denormalize(S, n2, ORC_GNS, cfg->lb_states, cfg->ub_states);
@@ -808,6 +831,36 @@ static void structure_reverse(const orc_config* cfg, const int* flwdir, const in
             const float* tp = tape + 8 * (i + n2 * t);
             float hi = tp[0], hp = tp[1], hft = tp[2], hst = tp[3], hlr = tp[4], qup = tp[5], prcp = tp[6], pet = tp[7];
             const int wet = (prcp >= 0.f && pet >= 0.f);
+            if (st == ORC_VIC_A) {   /* VIC_A_FORWARD_B, forward_db.f90:10246-10329 */
+                const float husl1_0 = tp[0], husl2_0 = tp[1], hlsl_0 = tp[2];
+                float h1 = husl1_0, h2 = husl2_0, hl = hlsl_0, runoff = 0.f;
+                const float cusl1 = P[P_CUSL1 * n2 + c], cusl2 = P[P_CUSL2 * n2 + c], clsl = P[P_CLSL * n2 + c];
+                float h1_1 = h1, h2_1 = h2;                       /* after infiltration */
+                if (wet) {
+                    vic_infiltration(prcp, cusl1, cusl2, P[P_B * n2 + c], &h1, &h2, &runoff);
+                    h1_1 = h1; h2_1 = h2;
+                    vic_vertical_transfer(pet, cusl1, cusl2, clsl, P[P_KS * n2 + c], &h1, &h2, &hl);
+                }
+                const float h2_2 = h2, hl_2 = hl;                 /* on entry of interflow / baseflow */
+                float temp_b = (dx * dx) * 0.001f * q_b[c] / dt;
+                q_b[c] = 0.f;
+                float qt_b = temp_b;
+                float qrout_b = (float)(flwacc[c] - 1) * temp_b;
+                float qup_b = 0.f;
+                linear_routing_b(dt, qup, &qup_b, P[P_LR * n2 + c], &P_b[P_LR * n2 + c], hlr, &S_b[S_HLR * n2 + c], qrout_b);
+                upstream_discharge_b(dt, dx, nrow, ncol, flwdir, flwacc, row, col, q_b, qup_b);
+                vic_baseflow_b(clsl, &P_b[P_CLSL * n2 + c], P[P_DS * n2 + c], &P_b[P_DS * n2 + c], P[P_DSM * n2 + c], &P_b[P_DSM * n2 + c],
+                               P[P_WS * n2 + c], &P_b[P_WS * n2 + c], hl_2, &S_b[S_HLSL * n2 + c], qt_b);
+                vic_interflow_b(5.f, cusl2, &P_b[P_CUSL2 * n2 + c], h2_2, &S_b[S_HUSL2 * n2 + c], qt_b);
+                if (wet) {
+                    vic_vertical_transfer_b(pet, cusl1, &P_b[P_CUSL1 * n2 + c], cusl2, &P_b[P_CUSL2 * n2 + c], clsl, &P_b[P_CLSL * n2 + c],
+                                            P[P_KS * n2 + c], &P_b[P_KS * n2 + c], h1_1, &S_b[S_HUSL1 * n2 + c], h2_1, &S_b[S_HUSL2 * n2 + c],
+                                            hlsl_0, &S_b[S_HLSL * n2 + c]);
+                    vic_infiltration_b(prcp, cusl1, &P_b[P_CUSL1 * n2 + c], cusl2, &P_b[P_CUSL2 * n2 + c], P[P_B * n2 + c],
+                                       &P_b[P_B * n2 + c], husl1_0, &S_b[S_HUSL1 * n2 + c], husl2_0, &S_b[S_HUSL2 * n2 + c], qt_b);
+                }
+                continue;
+            }
             /* recompute the primal intermediates the reference pops from its tape */
             float ei = 0.f, pn = 0.f, en = 0.f, pr = 0.f, perc = 0.f, l = 0.f, prr, prl = 0.f, prd = 0.f;
             if (wet) {
@@ -871,7 +924,7 @@ int orc_forward_b(const orc_config* cfg, const int* flwdir, const int* flwacc, c
                   const float* pet, const float* qobs, const float* wgauge, float* P, const float* Pb,
                   float* S, const float* Sb, float cost_b, float* qsim, float* costs, float* P_b, float* S_b) {
     const long n2 = (long)cfg->nrow * cfg->ncol;
-    if (cfg->structure < ORC_GR_A || cfg->structure > ORC_GR_D) return -2;
+    if (cfg->structure < ORC_GR_A || cfg->structure > ORC_VIC_A) return -2;
     if (cfg->denormalize_forward) {
         denormalize(P, n2, ORC_GNP, cfg->lb_parameters, cfg->ub_parameters);
         denormalize(S, n2, ORC_GNS, cfg->lb_states, cfg->ub_states);

@@ -17,7 +17,7 @@ extern "C" {
 #define ORC_GNP 16
 #define ORC_GNS 8
 
-enum { ORC_GR_A = 1, ORC_GR_B = 2, ORC_GR_C = 3, ORC_GR_D = 4 };
+enum { ORC_GR_A = 1, ORC_GR_B = 2, ORC_GR_C = 3, ORC_GR_D = 4, ORC_VIC_A = 5 };
 enum { ORC_NSE = 1, ORC_KGE = 2, ORC_KGE2 = 3, ORC_SE = 4, ORC_RMSE = 5, ORC_LOGARITHMIC = 6 };
 enum { ORC_PRIOR = 1, ORC_SMOOTHING = 2, ORC_HARD_SMOOTHING = 3 };
 

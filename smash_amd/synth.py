@@ -321,8 +321,17 @@ def make_parameters(nrow: int, ncol: int, perturb: float = 0.0) -> dict:
     p["exc"] = _smooth(nrow, ncol, -5.0, 1.0, 0.7)
     p["lr"] = _smooth(nrow, ncol, 2.0, 30.0, 1.9)
     p["ci"][:] = 1.0
+    # vic-a (md_vic_operator.f90): soil-layer capacities, infiltration shape, conductivity, baseflow curve
+    p["b"] = _smooth(nrow, ncol, 0.1, 0.6, 2.9)
+    p["cusl1"] = _smooth(nrow, ncol, 50.0, 200.0, 3.7)
+    p["cusl2"] = _smooth(nrow, ncol, 200.0, 800.0, 4.3)
+    p["clsl"] = _smooth(nrow, ncol, 1000.0, 3000.0, 5.1)
+    p["ks"] = _smooth(nrow, ncol, 5.0, 40.0, 5.9)
+    p["ds"] = _smooth(nrow, ncol, 0.01, 0.1, 6.7)
+    p["dsm"] = _smooth(nrow, ncol, 0.1, 1.0, 7.3)
+    p["ws"] = _smooth(nrow, ncol, 0.5, 0.9, 8.1)
     if perturb:
-        for k in ("cp", "cft", "cst", "exc", "lr"):
+        for k in ("cp", "cft", "cst", "exc", "lr", "b", "cusl1", "cusl2", "clsl", "ks", "dsm"):
             p[k] = np.asfortranarray((p[k] * np.float32(1.0 + perturb)).astype(np.float32))
     return p
 

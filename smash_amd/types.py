@@ -15,7 +15,7 @@ import numpy as np
 
 from .synth import PARAM_DEFAULTS, PARAM_NAMES, STATE_DEFAULTS, STATE_NAMES
 
-STRUCTURES = {"gr-a": 1, "gr-b": 2, "gr-c": 3, "gr-d": 4}
+STRUCTURES = {"gr-a": 1, "gr-b": 2, "gr-c": 3, "gr-d": 4, "vic-a": 5}
 JOBS_FUN = {"nse": 1, "kge": 2, "kge2": 3, "se": 4, "rmse": 5, "logarithmic": 6}
 JREG_FUN = {"prior": 1, "smoothing": 2, "hard_smoothing": 3}
 

@@ -50,6 +50,10 @@ CASES = [
     dict(name="gr_b_20x20x96_d8", structure="gr-b", n=20, nt=96, ng=3, mask=False, gaps=1000, d8=True, opts={}),
     dict(name="gr_c_32x32x240_d8_ragged", structure="gr-c", n=32, nt=240, ng=4, mask=True, gaps=1000, d8=True, radius=0.42,
          opts=dict(jobs_fun=("kge", "nse"), wjobs_fun=(0.5, 0.5))),
+    # vic-a structure (md_vic_operator.f90, vic_a_forward md_forward_structure.f90:762-931)
+    dict(name="vic_a_16x16x96_nse_gaps", structure="vic-a", n=16, nt=96, ng=3, mask=False, gaps=20000, opts={}),
+    dict(name="vic_a_24x24x240_d8_kge", structure="vic-a", n=24, nt=240, ng=3, mask=True, gaps=1000, d8=True, radius=0.45,
+         opts=dict(jobs_fun=("kge", "nse"), wjobs_fun=(0.5, 0.5))),
     dict(name="gr_a_12x12x48_nse_cold", structure="gr-a", n=12, nt=48, ng=2, mask=False, gaps=0, warm=False, opts={}),
     # larger cases: forcing is regenerated from smash_amd.synth (sha256 pinned in the fixture)
     dict(name="gr_b_64x64x720_nse", structure="gr-b", n=64, nt=720, ng=4, mask=False, gaps=1000, big=True, opts={}),

@@ -90,9 +90,11 @@ def tol_fstate(name, noise):
 
 
 STRUCT_PARAMS = {"gr-a": ("cp", "cft", "exc", "lr"), "gr-b": ("ci", "cp", "cft", "exc", "lr"),
-                 "gr-c": ("ci", "cp", "cft", "cst", "exc", "lr"), "gr-d": ("cp", "cft", "lr")}
+                 "gr-c": ("ci", "cp", "cft", "cst", "exc", "lr"), "gr-d": ("cp", "cft", "lr"),
+                 "vic-a": ("b", "cusl1", "cusl2", "clsl", "ks", "ds", "dsm", "ws", "lr")}
 STRUCT_STATES = {"gr-a": ("hp", "hft", "hlr"), "gr-b": ("hi", "hp", "hft", "hlr"),
-                 "gr-c": ("hi", "hp", "hft", "hst", "hlr"), "gr-d": ("hp", "hft", "hlr")}
+                 "gr-c": ("hi", "hp", "hft", "hst", "hlr"), "gr-d": ("hp", "hft", "hlr"),
+                 "vic-a": ("husl1", "husl2", "hlsl", "hlr")}
 
 
 def rel_l2(a, b):
