@@ -165,6 +165,7 @@ contains
         case ("gr-b"); id = 2
         case ("gr-c"); id = 3
         case ("gr-d"); id = 4
+        case ("vic-a"); id = 5
         case default; id = 0
         end select
     end function sx_structure_id

@@ -27,12 +27,14 @@ extern "C" {
 #define SMASHX_GNP 16 /* md_constant.f90:32  ci cp beta cft cst alpha exc b cusl1 cusl2 clsl ks ds dsm ws lr */
 #define SMASHX_GNS 8  /* md_constant.f90:33  hi hp hft hst husl1 husl2 hlsl hlr */
 
-enum { SMASHX_GR_A = 1, SMASHX_GR_B = 2, SMASHX_GR_C = 3, SMASHX_GR_D = 4 };   /* setup%structure, forward.f90:43-65 */
+enum { SMASHX_GR_A = 1, SMASHX_GR_B = 2, SMASHX_GR_C = 3, SMASHX_GR_D = 4, SMASHX_VIC_A = 5 };   /* setup%structure, forward.f90:43-65 */
 enum { SMASHX_NSE = 1, SMASHX_KGE = 2, SMASHX_KGE2 = 3, SMASHX_SE = 4, SMASHX_RMSE = 5, SMASHX_LOGARITHMIC = 6 }; /* mwd_cost.f90:98-126 */
 enum { SMASHX_PRIOR = 1, SMASHX_SMOOTHING = 2, SMASHX_HARD_SMOOTHING = 3 };   /* mwd_cost.f90:199-224 */
 enum { SMASHX_P_CI = 0, SMASHX_P_CP = 1, SMASHX_P_BETA = 2, SMASHX_P_CFT = 3, SMASHX_P_CST = 4, SMASHX_P_ALPHA = 5,
-       SMASHX_P_EXC = 6, SMASHX_P_LR = 15 };
-enum { SMASHX_S_HI = 0, SMASHX_S_HP = 1, SMASHX_S_HFT = 2, SMASHX_S_HST = 3, SMASHX_S_HLR = 7 };
+       SMASHX_P_EXC = 6, SMASHX_P_B = 7, SMASHX_P_CUSL1 = 8, SMASHX_P_CUSL2 = 9, SMASHX_P_CLSL = 10, SMASHX_P_KS = 11,
+       SMASHX_P_DS = 12, SMASHX_P_DSM = 13, SMASHX_P_WS = 14, SMASHX_P_LR = 15 };
+enum { SMASHX_S_HI = 0, SMASHX_S_HP = 1, SMASHX_S_HFT = 2, SMASHX_S_HST = 3, SMASHX_S_HUSL1 = 4, SMASHX_S_HUSL2 = 5,
+       SMASHX_S_HLSL = 6, SMASHX_S_HLR = 7 };
 
 enum {
     SMASHX_OK = 0,
@@ -46,7 +48,7 @@ enum {
 
 /* SetupDT + MeshDT scalars the path reads (mwd_setup.f90:108-157, mwd_mesh.f90:45-72) */
 typedef struct {
-    int structure;     /* SMASHX_GR_* */
+    int structure;     /* SMASHX_GR_* / SMASHX_VIC_A */
     int nrow, ncol;
     int nt;            /* setup%ntime_step */
     int ng;

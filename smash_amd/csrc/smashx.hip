@@ -29,26 +29,38 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
             return fail(SMASHX_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
     } while (0)
 
-// which of the 16 / 8 fields each structure reads (smash/core/_constant.py:15-29; ci via gr_interception)
-const int kParamFields[6] = {SMASHX_P_CI, SMASHX_P_CP, SMASHX_P_CFT, SMASHX_P_CST, SMASHX_P_EXC, SMASHX_P_LR};
-const int kStateFields[5] = {SMASHX_S_HI, SMASHX_S_HP, SMASHX_S_HFT, SMASHX_S_HST, SMASHX_S_HLR};
-bool uses_param(int st, int f) {
-    switch (f) {
-        case SMASHX_P_CI: return st == 2 || st == 3;
-        case SMASHX_P_CP: case SMASHX_P_CFT: case SMASHX_P_LR: return true;
-        case SMASHX_P_CST: return st == 3;
-        case SMASHX_P_EXC: return st != 4;
-        default: return false;
+// Which of the 16 / 8 fields each structure reads (smash/core/_constant.py:15-29; ci via gr_interception), by device
+// slot.  Parameter slots: 0 ci, 1 cp, 2 cft, 3 cst, 4 exc, 5 lr, 6..8 px[0..2]; vic-a puts b, cusl1, cusl2, clsl, ks in
+// slots 0..4 and ds, dsm, ws in 6..8.  State slots: 0 hi, 1 hp, 2 hft, 3 hst, 4 hlr; vic-a: husl1, husl2, hlsl in 0..2.
+const int NPS = 9, NSS = 5;
+int param_field(int st, int slot) {
+    if (st == 5) {
+        const int f[NPS] = {SMASHX_P_B, SMASHX_P_CUSL1, SMASHX_P_CUSL2, SMASHX_P_CLSL, SMASHX_P_KS, SMASHX_P_LR,
+                            SMASHX_P_DS, SMASHX_P_DSM, SMASHX_P_WS};
+        return f[slot];
+    }
+    switch (slot) {
+        case 0: return (st == 2 || st == 3) ? SMASHX_P_CI : -1;
+        case 1: return SMASHX_P_CP;
+        case 2: return SMASHX_P_CFT;
+        case 3: return st == 3 ? SMASHX_P_CST : -1;
+        case 4: return st != 4 ? SMASHX_P_EXC : -1;
+        case 5: return SMASHX_P_LR;
+        default: return -1;
     }
 }
-bool uses_state(int st, int f) {
-    switch (f) {
-        case SMASHX_S_HI: return st == 2 || st == 3;
-        case SMASHX_S_HP: case SMASHX_S_HFT: case SMASHX_S_HLR: return true;
-        case SMASHX_S_HST: return st == 3;
-        default: return false;
+int state_field(int st, int slot) {
+    if (st == 5) { const int f[NSS] = {SMASHX_S_HUSL1, SMASHX_S_HUSL2, SMASHX_S_HLSL, -1, SMASHX_S_HLR}; return f[slot]; }
+    switch (slot) {
+        case 0: return (st == 2 || st == 3) ? SMASHX_S_HI : -1;
+        case 1: return SMASHX_S_HP;
+        case 2: return SMASHX_S_HFT;
+        case 3: return st == 3 ? SMASHX_S_HST : -1;
+        default: return SMASHX_S_HLR;
     }
 }
+int param_slot_of(int st, int f) { for (int i = 0; i < NPS; ++i) if (param_field(st, i) == f) return i; return -1; }
+int state_slot_of(int st, int f) { for (int i = 0; i < NSS; ++i) if (state_field(st, i) == f) return i; return -1; }
 
 // ---- small elementwise kernels on full (nrow*ncol) fields and on the cell vectors -------------------
 __global__ void k_denormalize(float* a, long n, float lb, float ub) {   // mwd_parameters_manipulation.f90:199
@@ -242,7 +254,7 @@ int chunk_len(const smashx_plan* p, int c) { return std::min(p->Tc, p->nt - c * 
 // allocate the time-chunk buffers; Tc from cfg or from free HBM
 int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
     const int st = p->st;
-    const int ntape = (st == 2 ? 3 : st == 3 ? 4 : 2);
+    const int ntape = ((st == 2 || st == 5) ? 3 : st == 3 ? 4 : 2);
     if (!p->chunk_ready) {
         const int nt16 = (p->nt + 15) / 16 * 16;
         int Tc = p->cfg.chunk_steps > 0 ? (p->cfg.chunk_steps + 15) / 16 * 16 : 0;
@@ -287,11 +299,11 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
         if ((rc = p->dmalloc(&p->A.hrT, cs))) return rc;
         if ((rc = p->dmalloc(&p->A.tape_hp, cs))) return rc;
         if ((rc = p->dmalloc(&p->A.tape_hft, cs))) return rc;
-        if (st == 2 || st == 3) { if ((rc = p->dmalloc(&p->A.tape_hi, cs))) return rc; }
+        if (st == 2 || st == 3 || st == 5) { if ((rc = p->dmalloc(&p->A.tape_hi, cs))) return rc; }
         if (st == 3) { if ((rc = p->dmalloc(&p->A.tape_hst, cs))) return rc; }
         if (p->nchunks > 1) { if ((rc = p->dmalloc(&p->ckpt, (size_t)p->nchunks * 5 * p->npad))) return rc; }
-        float** g[11] = {&p->A.ci_b, &p->A.cp_b, &p->A.cft_b, &p->A.cst_b, &p->A.exc_b, &p->A.lr_b,
-                         &p->A.hi_b, &p->A.hp_b, &p->A.hft_b, &p->A.hst_b, &p->A.hlr_b};
+        float** g[14] = {&p->A.ci_b, &p->A.cp_b, &p->A.cft_b, &p->A.cst_b, &p->A.exc_b, &p->A.lr_b,
+                         &p->A.hi_b, &p->A.hp_b, &p->A.hft_b, &p->A.hst_b, &p->A.hlr_b, &p->A.px_b[0], &p->A.px_b[1], &p->A.px_b[2]};
         for (auto q : g) if ((rc = p->dmalloc(q, (size_t)p->npad))) return rc;
         if ((rc = p->dmalloc(&p->A.qgb, (size_t)std::max(p->ngc, 1) * p->nt))) return rc;
         if ((rc = p->dmalloc(&p->d_qsim_b, (size_t)std::max(p->ng, 1) * p->nt))) return rc;
@@ -329,6 +341,13 @@ void vert_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
         case 1: launch_vert_fwd<1>(p, B, tape, t0, T); break;
         case 2: launch_vert_fwd<2>(p, B, tape, t0, T); break;
         case 3: launch_vert_fwd<3>(p, B, tape, t0, T); break;
+        case 5: {
+            const dim3 grid(p->npad / SX_VBLOCK), block(SX_VBLOCK);
+            p->mark_begin(0, p->stream);
+            if (tape) hipLaunchKernelGGL((sx_k_vert_fwd_vic<true>), grid, block, 0, p->stream, B, t0, T);
+            else      hipLaunchKernelGGL((sx_k_vert_fwd_vic<false>), grid, block, 0, p->stream, B, t0, T);
+            p->mark_end();
+        } break;
         default: launch_vert_fwd<4>(p, B, tape, t0, T); break;
     }
 }
@@ -340,6 +359,7 @@ void vert_adj(smashx_plan* p, int off, int t0, int T) {
         case 1: hipLaunchKernelGGL((sx_k_vert_adj<1>), grid, block, 0, p->stream, B, t0, T); break;
         case 2: hipLaunchKernelGGL((sx_k_vert_adj<2>), grid, block, 0, p->stream, B, t0, T); break;
         case 3: hipLaunchKernelGGL((sx_k_vert_adj<3>), grid, block, 0, p->stream, B, t0, T); break;
+        case 5: hipLaunchKernelGGL(sx_k_vert_adj_vic, grid, block, 0, p->stream, B, t0, T); break;
         default: hipLaunchKernelGGL((sx_k_vert_adj<4>), grid, block, 0, p->stream, B, t0, T); break;
     }
     p->mark_end();
@@ -422,7 +442,7 @@ int run_cost(smashx_plan* p, int adjoint, float cost_b) {
 // the reservoir levels live on the V stream, the routing store hlr (index 4) on the R stream
 int copy_states(smashx_plan* p, float* const dst[5], float* const src[5]) {
     for (int i = 0; i < 5; ++i)
-        if (uses_state(p->st, kStateFields[i]))
+        if (state_field(p->st, i) >= 0)
             HIPCHK(hipMemcpyAsync(dst[i], src[i], (size_t)p->npad * 4, hipMemcpyDeviceToDevice, i == 4 ? p->stream_r : p->stream));
     return 0;
 }
@@ -446,7 +466,7 @@ int smashx_device_count(void) {
 int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx_plan** out) {
     if (!cfg || !mesh || !out) return fail(SMASHX_E_ARG, "null argument");
     *out = nullptr;
-    if (cfg->structure < 1 || cfg->structure > 4) return fail(SMASHX_E_UNSUPPORTED, "structure must be gr-a/b/c/d (vic-a is a later row)");
+    if (cfg->structure < 1 || cfg->structure > 5) return fail(SMASHX_E_UNSUPPORTED, "structure must be gr-a/b/c/d or vic-a");
     if (cfg->nrow <= 0 || cfg->ncol <= 0 || cfg->nt <= 0 || cfg->ng < 0 || !(cfg->dt > 0.f) || !(cfg->dx > 0.f))
         return fail(SMASHX_E_ARG, "bad sizes in smashx_config");
     if (!mesh->flwdir || !mesh->flwacc || !mesh->active_cell || (cfg->ng > 0 && (!mesh->gauge_pos || !mesh->area)))
@@ -535,15 +555,15 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         if (ok) TRY(p->upload_vec(&p->d_sparse_idx, sp));
     }
     // parameters, states, routing invariants
-    float** pf[6] = {&A.ci, &A.cp, &A.cft, &A.cst, &A.exc, &A.lr};
+    float** pf[NPS] = {&A.ci, &A.cp, &A.cft, &A.cst, &A.exc, &A.lr, &A.px[0], &A.px[1], &A.px[2]};
     for (auto q : pf) TRY(p->dmalloc(q, (size_t)p->npad));
     float** sf[5] = {&A.hi, &A.hp, &A.hft, &A.hst, &A.hlr};
     for (auto q : sf) TRY(p->dmalloc(q, (size_t)p->npad));
     for (int i = 0; i < 5; ++i) TRY(p->dmalloc(&p->st0[i], (size_t)p->npad));
     float** rf[4] = {&A.rt_a, &A.rt_f, &A.rt_denf, &A.rt_denb};
     for (auto q : rf) TRY(p->dmalloc(q, (size_t)p->npad));
-    for (int i = 0; i < 6; ++i) TRY(p->dmalloc(&p->d_fullP[kParamFields[i]], (size_t)p->n2));
-    for (int i = 0; i < 5; ++i) TRY(p->dmalloc(&p->d_fullS[kStateFields[i]], (size_t)p->n2));
+    for (int i = 0; i < NPS; ++i) if (param_field(p->st, i) >= 0) TRY(p->dmalloc(&p->d_fullP[param_field(p->st, i)], (size_t)p->n2));
+    for (int i = 0; i < NSS; ++i) if (state_field(p->st, i) >= 0) TRY(p->dmalloc(&p->d_fullS[state_field(p->st, i)], (size_t)p->n2));
     p->stage_planes = std::max<long>(1, std::min<long>(64, (256L << 20) / (p->n2 * 4)));
     TRY(p->dmalloc(&p->d_stage, (size_t)p->n2 * p->stage_planes));
     // gauges / cost
@@ -747,19 +767,19 @@ int smashx_upload(smashx_plan* p, const smashx_parameters* params, const smashx_
     int rc = set_device(p); if (rc) return rc;
     const int st = p->st;
     const dim3 b(256), gfull((unsigned)((p->n2 + 255) / 256)), gk((p->n + 255) / 256);
-    float* pdst[6] = {p->A.ci, p->A.cp, p->A.cft, p->A.cst, p->A.exc, p->A.lr};
-    for (int i = 0; i < 6; ++i) {
-        const int f = kParamFields[i];
-        if (!uses_param(st, f)) continue;
+    float* pdst[NPS] = {p->A.ci, p->A.cp, p->A.cft, p->A.cst, p->A.exc, p->A.lr, p->A.px[0], p->A.px[1], p->A.px[2]};
+    for (int i = 0; i < NPS; ++i) {
+        const int f = param_field(st, i);
+        if (f < 0) continue;
         if (!params->f[f]) return fail(SMASHX_E_ARG, "a parameter field the structure uses is NULL");
         HIPCHK(hipMemcpyAsync(p->d_fullP[f], params->f[f], (size_t)p->n2 * 4, hipMemcpyHostToDevice, p->stream));
         if (p->opt.denormalize_forward)
             hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullP[f], p->n2, p->opt.lb_parameters[f], p->opt.ub_parameters[f]);
         hipLaunchKernelGGL(k_gather, gk, b, 0, p->stream, pdst[i], p->d_fullP[f], p->d_cell_flat, p->n);
     }
-    for (int i = 0; i < 5; ++i) {
-        const int f = kStateFields[i];
-        if (!uses_state(st, f)) continue;
+    for (int i = 0; i < NSS; ++i) {
+        const int f = state_field(st, i);
+        if (f < 0) continue;
         if (!states->f[f]) return fail(SMASHX_E_ARG, "a state field the structure uses is NULL");
         HIPCHK(hipMemcpyAsync(p->d_fullS[f], states->f[f], (size_t)p->n2 * 4, hipMemcpyHostToDevice, p->stream));
         if (p->opt.denormalize_forward)
@@ -921,17 +941,19 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
         if ((rc = run_cost(p, 1, cost_b))) return rc;
         {   // gradient accumulators start from what COMPUTE_COST_B left in parameters_b / states_b: zero, or the
             // regulariser's gradient for the optimised fields (forward_db.f90:10869-10874)
-            float* gv[11] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b,
-                             p->A.lr_b, p->A.hlr_b};
-            const int gi[11] = {SMASHX_P_CI, SMASHX_P_CP, SMASHX_P_CFT, SMASHX_P_CST, SMASHX_P_EXC, SMASHX_GNP + SMASHX_S_HI,
-                                SMASHX_GNP + SMASHX_S_HP, SMASHX_GNP + SMASHX_S_HFT, SMASHX_GNP + SMASHX_S_HST, SMASHX_P_LR,
-                                SMASHX_GNP + SMASHX_S_HLR};
+            float* gv[14] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b,
+                             p->A.lr_b, p->A.hlr_b, p->A.px_b[0], p->A.px_b[1], p->A.px_b[2]};
+            const int ps = p->st;
+            auto pfi = [&](int slot) { const int f = param_field(ps, slot); return f; };
+            auto sfi = [&](int slot) { const int f = state_field(ps, slot); return f < 0 ? -1 : SMASHX_GNP + f; };
+            const int gi[14] = {pfi(0), pfi(1), pfi(2), pfi(3), pfi(4), sfi(0), sfi(1), sfi(2), sfi(3), pfi(5), sfi(4), pfi(6), pfi(7), pfi(8)};
             bool waited[2] = {false, false};
-            for (int q = 0; q < 11; ++q) {
-                hipStream_t sq = q < 9 ? sV : sR;
+            for (int q = 0; q < 14; ++q) {
+                const bool on_r = (q == 9 || q == 10);
+                hipStream_t sq = on_r ? sR : sV;
                 HIPCHK(hipMemsetAsync(gv[q], 0, (size_t)p->npad * 4, sq));
-                if (p->opt.njr > 0 && jreg_optim(p, gi[q]) > 0) {
-                    if (!waited[q < 9 ? 0 : 1]) { HIPCHK(hipStreamWaitEvent(sq, p->ev_j, 0)); waited[q < 9 ? 0 : 1] = true; }
+                if (p->opt.njr > 0 && gi[q] >= 0 && jreg_optim(p, gi[q]) > 0) {
+                    if (!waited[on_r ? 1 : 0]) { HIPCHK(hipStreamWaitEvent(sq, p->ev_j, 0)); waited[on_r ? 1 : 0] = true; }
                     hipLaunchKernelGGL(k_gather, dim3((p->n + 255) / 256), dim3(256), 0, sq, gv[q], p->d_jg[gi[q]], p->d_cell_flat, p->n);
                 }
             }
@@ -1130,9 +1152,9 @@ int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smas
     // final states: output%fstates = states (forward.f90:71); inactive cells keep their entry values
     if (fstates && !adjoint) {
         float* cur[5] = {p->A.hi, p->A.hp, p->A.hft, p->A.hst, p->A.hlr};
-        for (int i = 0; i < 5; ++i) {
-            const int f = kStateFields[i];
-            if (!uses_state(st, f) || !fstates->f[f]) continue;
+        for (int i = 0; i < NSS; ++i) {
+            const int f = state_field(st, i);
+            if (f < 0 || !fstates->f[f]) continue;
             HIPCHK(hipMemcpyAsync(p->d_stage, p->d_fullS[f], (size_t)p->n2 * 4, hipMemcpyDeviceToDevice, p->stream));
             hipLaunchKernelGGL(k_scatter, gk, b, 0, p->stream, p->d_stage, cur[i], p->d_cell_flat, p->n, 1.f, 0);
             HIPCHK(hipMemcpyAsync(fstates->f[f], p->d_stage, (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
@@ -1142,18 +1164,18 @@ int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smas
     // parameters / states as the reference leaves them (forward.f90:33-38,72; mwd_cost.f90:284-298):
     // denormalised; base_forward additionally sends them through normalise -> denormalise inside compute_cost.
     if (p->opt.denormalize_forward) {
-        for (int i = 0; i < 6; ++i) {
-            const int f = kParamFields[i];
-            if (!uses_param(st, f) || !params || !params->f[f]) continue;
+        for (int i = 0; i < NPS; ++i) {
+            const int f = param_field(st, i);
+            if (f < 0 || !params || !params->f[f]) continue;
             if (!adjoint) {
                 hipLaunchKernelGGL(k_normalize, gfull, b, 0, p->stream, p->d_fullP[f], p->n2, p->opt.lb_parameters[f], p->opt.ub_parameters[f]);
                 hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullP[f], p->n2, p->opt.lb_parameters[f], p->opt.ub_parameters[f]);
             }
             HIPCHK(hipMemcpyAsync(params->f[f], p->d_fullP[f], (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
         }
-        for (int i = 0; i < 5; ++i) {
-            const int f = kStateFields[i];
-            if (!uses_state(st, f) || !states || !states->f[f]) continue;
+        for (int i = 0; i < NSS; ++i) {
+            const int f = state_field(st, i);
+            if (f < 0 || !states || !states->f[f]) continue;
             if (!adjoint) {
                 hipLaunchKernelGGL(k_normalize, gfull, b, 0, p->stream, p->d_fullS[f], p->n2, p->opt.lb_states[f], p->opt.ub_states[f]);
                 hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullS[f], p->n2, p->opt.lb_states[f], p->opt.ub_states[f]);
@@ -1165,19 +1187,18 @@ int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smas
     }
     if (adjoint) {
         if (!p->adj_ready) return fail(SMASHX_E_STATE, "no adjoint sweep has run");
-        float* gp[6] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.lr_b};
+        float* gp[NPS] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.lr_b, p->A.px_b[0], p->A.px_b[1], p->A.px_b[2]};
         float* gs[5] = {p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b, p->A.hlr_b};
         // parameters_b / states_b are fully overwritten (forward_db.f90:10869-10870); DENORMALIZE_*_B multiplies by (ub-lb)
         if (params_b)
             for (int f = 0; f < SMASHX_GNP; ++f) {
                 if (!params_b->f[f]) continue;
-                int i = -1;
-                for (int q = 0; q < 6; ++q) if (kParamFields[q] == f) i = q;
+                const int i = param_slot_of(st, f);
                 const bool jr = p->opt.njr > 0 && jreg_optim(p, f) > 0;      // inactive cells / unused fields: the regulariser's part
                 if (jr) hipLaunchKernelGGL(sx_k_plane_scale, gfull, b, 0, p->stream, p->d_stage, p->d_jg[f],
                                            p->opt.ub_parameters[f] - p->opt.lb_parameters[f], p->opt.denormalize_forward, p->n2);
                 else HIPCHK(hipMemsetAsync(p->d_stage, 0, (size_t)p->n2 * 4, p->stream));
-                if (i < 0 || !uses_param(st, f)) {
+                if (i < 0) {
                     if (!jr) { std::memset(params_b->f[f], 0, (size_t)p->n2 * 4); continue; }
                     HIPCHK(hipMemcpyAsync(params_b->f[f], p->d_stage, (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
                     HIPCHK(hipStreamSynchronize(p->stream));
@@ -1191,13 +1212,12 @@ int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smas
         if (states_b)
             for (int f = 0; f < SMASHX_GNS; ++f) {
                 if (!states_b->f[f]) continue;
-                int i = -1;
-                for (int q = 0; q < 5; ++q) if (kStateFields[q] == f) i = q;
+                const int i = state_slot_of(st, f);
                 const bool jr = p->opt.njr > 0 && jreg_optim(p, SMASHX_GNP + f) > 0;
                 if (jr) hipLaunchKernelGGL(sx_k_plane_scale, gfull, b, 0, p->stream, p->d_stage, p->d_jg[SMASHX_GNP + f],
                                            p->opt.ub_states[f] - p->opt.lb_states[f], p->opt.denormalize_forward, p->n2);
                 else HIPCHK(hipMemsetAsync(p->d_stage, 0, (size_t)p->n2 * 4, p->stream));
-                if (i < 0 || !uses_state(st, f)) {
+                if (i < 0) {
                     if (!jr) { std::memset(states_b->f[f], 0, (size_t)p->n2 * 4); continue; }
                     HIPCHK(hipMemcpyAsync(states_b->f[f], p->d_stage, (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
                     HIPCHK(hipStreamSynchronize(p->stream));
@@ -1233,6 +1253,7 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
                      float* qsim_d, smashx_costs* costs, float* cost_d) {
     if (!p || !params || !states || !params_d || !states_d || !cost_d) return fail(SMASHX_E_ARG, "null argument");
     if (p->tiled) return fail(SMASHX_E_UNSUPPORTED, "tangent model on a tiled plan");
+    if (p->st == 5) return fail(SMASHX_E_UNSUPPORTED, "tangent model of vic-a (VIC_A_FORWARD_D) is not built");
     int rc = smashx_upload(p, params, params_bgd, states, states_bgd); if (rc) return rc;
     if (!p->have_forcing) return fail(SMASHX_E_STATE, "forcing not set");
     if ((rc = set_device(p))) return rc;
@@ -1253,9 +1274,9 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
     float* tp[6] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.lr_b};
     float* ts[5] = {p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b, p->A.hlr_b};
     for (int i = 0; i < 6; ++i) {
-        const int f = kParamFields[i];
+        const int f = param_field(st, i);
         HIPCHK(hipMemsetAsync(tp[i], 0, (size_t)p->npad * 4, sV));
-        if (!uses_param(st, f)) continue;
+        if (f < 0) continue;
         if (!params_d->f[f]) return fail(SMASHX_E_ARG, "a tangent field the structure uses is NULL");
         HIPCHK(hipMemcpyAsync(p->d_stage, params_d->f[f], (size_t)p->n2 * 4, hipMemcpyHostToDevice, sV));
         if (p->opt.denormalize_forward)
@@ -1264,9 +1285,9 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
         HIPCHK(hipStreamSynchronize(sV));
     }
     for (int i = 0; i < 5; ++i) {
-        const int f = kStateFields[i];
+        const int f = state_field(st, i);
         HIPCHK(hipMemsetAsync(ts[i], 0, (size_t)p->npad * 4, sV));
-        if (!uses_state(st, f)) continue;
+        if (f < 0) continue;
         if (!states_d->f[f]) return fail(SMASHX_E_ARG, "a tangent field the structure uses is NULL");
         HIPCHK(hipMemcpyAsync(p->d_stage, states_d->f[f], (size_t)p->n2 * 4, hipMemcpyHostToDevice, sV));
         if (p->opt.denormalize_forward)

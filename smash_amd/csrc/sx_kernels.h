@@ -19,6 +19,7 @@
 
 #include "sx_ops.h"
 #include "sx_tangent.h"
+#include "sx_vic.h"
 
 #define SX_BT 4           // time steps per routing super-step (one float4 per cell per super-step)
 #define SX_VBLOCK 256     // threads (cells) per vertical workgroup
@@ -104,6 +105,9 @@ struct SxDeviceArrays {
     const float* prcp; const float* pet;
     // parameters (denormalised) and per-cell invariants
     float *ci, *cp, *cft, *cst, *exc, *lr;
+    // vic-a reuses the slots above (b -> ci, cusl1 -> cp, cusl2 -> cft, clsl -> cst, ks -> exc; husl1 -> hi, husl2 -> hp,
+    // hlsl -> hft, same for the tapes and gradients) and adds three: ds, dsm, ws
+    float* px[3]; float* px_b[3];
     float *rt_a, *rt_f, *rt_denf, *rt_denb;   // exp(-dt/(60 lr)), real(flwacc-1), forward / adjoint denominators
     int* flwacc;
     // states (running) and adjoint state
@@ -198,6 +202,70 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
     A.hp[k] = hp;
     A.hft[k] = hft;
     if (ST == 3) A.hst[k] = hst;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vic-a: vertical forward and adjoint (vic_a_forward md_forward_structure.f90:804-829, VIC_A_FORWARD_B
+// forward_db.f90:10271-10316).  Same thread-per-cell time march, T4 qt, three tapes (husl1, husl2, hlsl).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ SxVicParams sx_vic_load(const SxDeviceArrays& A, int k) {
+    SxVicParams P;
+    P.b = A.ci[k]; P.cusl1 = A.cp[k]; P.cusl2 = A.cft[k]; P.clsl = A.cst[k]; P.ks = A.exc[k];
+    P.ds = A.px[0][k]; P.dsm = A.px[1][k]; P.ws = A.px[2][k];
+    return P;
+}
+template <bool TAPE>
+__global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A, int t0, int T) {
+    const int k = blockIdx.x * SX_VBLOCK + threadIdx.x;
+    if (k >= A.n) return;
+    const size_t npad = (size_t)A.npad;
+    const SxVicParams P = sx_vic_load(A, k);
+    const float cusl2_m4 = sx_pow_m4(P.cusl2);
+    float husl1 = A.hi[k], husl2 = A.hp[k], hlsl = A.hft[k];
+    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
+    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    float4* qt4 = reinterpret_cast<float4*>(A.qtT) + k;
+    for (int tq = 0; tq * 4 < T; ++tq) {
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int tt = tq * 4 + i;
+            if (tt < T) {
+                if (TAPE) {
+                    const size_t o = (size_t)tt * npad + k;
+                    A.tape_hi[o] = husl1; A.tape_hp[o] = husl2; A.tape_hft[o] = hlsl;
+                }
+                const float v = sx_vic_step(P, cusl2_m4, prcp_p[(size_t)tt * npad], pet_p[(size_t)tt * npad], husl1, husl2, hlsl);
+                if (i == 0) q[0] = v; else if (i == 1) q[1] = v; else if (i == 2) q[2] = v; else q[3] = v;
+            }
+        }
+        qt4[(size_t)tq * npad] = make_float4(q[0], q[1], q[2], q[3]);
+    }
+    A.hi[k] = husl1; A.hp[k] = husl2; A.hft[k] = hlsl;
+}
+
+__global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A, int t0, int T) {
+    const int k = blockIdx.x * SX_VBLOCK + threadIdx.x;
+    if (k >= A.n) return;
+    const size_t npad = (size_t)A.npad;
+    const SxVicParams P = sx_vic_load(A, k);
+    float cusl2_m4, cusl2_m5;
+    sx_pow_m4_m5(P.cusl2, &cusl2_m4, &cusl2_m5);
+    SxVicGrads G;
+    G.b_b = A.ci_b[k]; G.cusl1_b = A.cp_b[k]; G.cusl2_b = A.cft_b[k]; G.clsl_b = A.cst_b[k]; G.ks_b = A.exc_b[k];
+    G.ds_b = A.px_b[0][k]; G.dsm_b = A.px_b[1][k]; G.ws_b = A.px_b[2][k];
+    G.husl1_b = A.hi_b[k]; G.husl2_b = A.hp_b[k]; G.hlsl_b = A.hft_b[k];
+    const float* qtb = A.qtT + (size_t)k * 4;
+    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
+    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    for (int tt = T - 1; tt >= 0; --tt) {
+        const size_t o = (size_t)tt * npad;
+        const float q_b = qtb[(size_t)(tt >> 2) * npad * 4 + (tt & 3)];
+        sx_vic_step_b(P, cusl2_m4, cusl2_m5, prcp_p[o], pet_p[o], A.tape_hi[o + k], A.tape_hp[o + k], A.tape_hft[o + k], q_b, G);
+    }
+    A.ci_b[k] = G.b_b; A.cp_b[k] = G.cusl1_b; A.cft_b[k] = G.cusl2_b; A.cst_b[k] = G.clsl_b; A.exc_b[k] = G.ks_b;
+    A.px_b[0][k] = G.ds_b; A.px_b[1][k] = G.dsm_b; A.px_b[2][k] = G.ws_b;
+    A.hi_b[k] = G.husl1_b; A.hp_b[k] = G.husl2_b; A.hft_b[k] = G.hlsl_b;
 }
 
 // ------------------------------------------------------------------------------------------------

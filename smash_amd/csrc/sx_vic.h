@@ -1,0 +1,348 @@
+// sx_vic.h -- operators of the vic-a structure as device functions (gfx950), forward and adjoint.
+//
+// Forward: smash/solver/operator/md_vic_operator.f90:22-202 statement by statement (vic_infiltration,
+// vic_vertical_transfer, vic_interflow, vic_baseflow, brooks_and_corey_flow, linear_evapotranspiration).
+// Adjoint: the local adjoint expressions of forward_db.f90 in their order (VIC_INFILTRATION_B :6808-6973,
+// VIC_VERTICAL_TRANSFER_B :7102-7197, VIC_INTERFLOW_B :7300-7368, VIC_BASEFLOW_B :7442-7503,
+// BROOKS_AND_COREY_FLOW_B :7582-7643, LINEAR_EVAPOTRANSPIRATION_B :7700-7723), each given the levels its operator saw
+// on entry.  libm: x**y with run-time exponents (1/(b+1), b+1, b, ...) -> sx_powf / sx_logf (fp64 evaluation, one
+// rounding: correctly rounded like glibc's in 99.94 % of calls); the fixed powers of the interflow store (n = 5) use
+// the same routines as gr_transfer; lambda = 1 in brooks_and_corey_flow is the identity.  Divisions are IEEE.
+#pragma once
+
+#include "sx_math.h"
+
+#ifndef SX_DEV
+#define SX_DEV __device__ __forceinline__
+#endif
+
+struct SxVicParams { float b, cusl1, cusl2, clsl, ks, ds, dsm, ws; };
+struct SxVicGrads { float b_b, cusl1_b, cusl2_b, clsl_b, ks_b, ds_b, dsm_b, ws_b, husl1_b, husl2_b, hlsl_b; };
+
+// ---------------------------------------------------------------- forward
+SX_DEV void sx_vic_infiltration(float prcp, float cusl1, float cusl2, float b, float& husl1, float& husl2, float& runoff) {
+    const float bp1 = b + 1.f;
+    float ifl;
+    if (prcp <= 0.f) ifl = 0.f;
+    else {
+        const float cusl = cusl1 + cusl2;
+        float wusl = husl1 * cusl1 + husl2 * cusl2;
+        wusl = fmaxf(1.e-6f, wusl);
+        wusl = fminf(cusl - 1e-6f, wusl);
+        const float iflm = cusl * bp1;
+        const float iflc = iflm * (1.f - sx_powf(1.f - (wusl / cusl), 1.f / bp1));
+        if (iflc + prcp >= iflm) ifl = cusl - wusl;
+        else ifl = (cusl - wusl) - cusl * sx_powf(1.f - ((iflc + prcp) / iflm), bp1);
+        ifl = fminf(prcp, ifl);
+    }
+    const float ifl_usl1 = fminf((1.f - husl1) * cusl1, ifl);
+    ifl = ifl - ifl_usl1;
+    const float ifl_usl2 = fminf((1.f - husl2) * cusl2, ifl);
+    ifl = ifl - ifl_usl2;
+    husl1 = husl1 + ifl_usl1 / cusl1;
+    husl2 = husl2 + ifl_usl2 / cusl2;
+    runoff = prcp - (ifl_usl1 + ifl_usl2);
+}
+
+// residual = 0, porosity = 1, lambda = 1 at both call sites (md_vic_operator.f90:94,99): pwx1 = h_upper / 1, pwx1**1 = pwx1
+SX_DEV float sx_brooks_corey(float ks, float c_upper, float c_lower, float h_upper, float h_lower) {
+    const float flow = ks * ((h_upper - 0.f) / (1.f - 0.f));
+    const float w_upper = h_upper * c_upper * 1.f;
+    const float w_lower = h_lower * c_lower * 1.f;
+    const float max_flow = fminf(w_upper, c_lower - w_lower);
+    return fminf(max_flow, flow);
+}
+SX_DEV float sx_linear_evap(float e, float c, float h) { return fminf(c * h, e * h); }
+
+SX_DEV void sx_vic_vertical_transfer(float pet, float cusl1, float cusl2, float clsl, float ks, float& husl1, float& husl2, float& hlsl) {
+    float fbc = sx_brooks_corey(ks, cusl1, cusl2, husl1, husl2);
+    husl1 = husl1 - fbc / cusl1;
+    husl2 = husl2 + fbc / cusl2;
+    fbc = sx_brooks_corey(ks, cusl2, clsl, husl2, hlsl);
+    husl2 = husl2 - fbc / cusl2;
+    hlsl = hlsl + fbc / clsl;
+    float fe = sx_linear_evap(pet, cusl1, husl1);
+    husl1 = husl1 - fe / cusl1;
+    float pet_remain = fmaxf(0.f, pet - fe);
+    fe = sx_linear_evap(pet_remain, cusl2, husl2);
+    husl2 = husl2 - fe / cusl2;
+    pet_remain = fmaxf(0.f, pet_remain - fe);
+    fe = sx_linear_evap(pet_remain, clsl, hlsl);
+    hlsl = hlsl - fe / clsl;
+}
+
+SX_DEV void sx_vic_interflow(float cusl2, float cusl2_m4, float& husl2, float& qi) {   // n = 5
+    const float husl2_imd = husl2;
+    husl2 = sx_pow_m025(sx_pow_m4(husl2_imd * cusl2) + cusl2_m4) / cusl2;
+    qi = (husl2_imd - husl2) * cusl2;
+}
+
+SX_DEV void sx_vic_baseflow(float clsl, float ds, float dsm, float ws, float& hlsl, float& qb) {
+    float q;
+    if (hlsl <= ws) q = (ds * dsm) / ws * hlsl;
+    else q = dsm * (1.f - ds / ws) * (hlsl - ws) / (1.f - ws);
+    const float wlsl = clsl * hlsl;
+    q = fminf(wlsl, q);
+    hlsl = hlsl - q / clsl;
+    qb = q;
+}
+
+// one vertical cell-step of vic_a_forward (md_forward_structure.f90:804-829); returns qt
+SX_DEV float sx_vic_step(const SxVicParams& P, float cusl2_m4, float prcp, float pet, float& husl1, float& husl2, float& hlsl) {
+    float runoff = 0.f, qi, qb;
+    if (prcp >= 0.f && pet >= 0.f) {
+        sx_vic_infiltration(prcp, P.cusl1, P.cusl2, P.b, husl1, husl2, runoff);
+        sx_vic_vertical_transfer(pet, P.cusl1, P.cusl2, P.clsl, P.ks, husl1, husl2, hlsl);
+    }
+    sx_vic_interflow(P.cusl2, cusl2_m4, husl2, qi);
+    sx_vic_baseflow(P.clsl, P.ds, P.dsm, P.ws, hlsl, qb);
+    return (runoff + qi + qb);
+}
+
+// ---------------------------------------------------------------- adjoint
+SX_DEV float sx_pow_guard_b(float x, float y, float r_b) {
+    if (x <= 0.f && (y == 0.f || y != (float)(int)y)) return 0.f;
+    return y * sx_powf(x, y - 1.f) * r_b;
+}
+
+SX_DEV void sx_vic_infiltration_b(float prcp, float cusl1, float cusl2, float b, float husl1, float husl2, float runoff_b, SxVicGrads& G) {
+    float bp1 = b + 1.f, ifl, cusl = 0.f, wusl = 0.f, iflm = 0.f, iflc = 0.f, pwx1 = 0.f, pwy1 = 0.f, pwr1 = 0.f, pwr1_first = 0.f;
+    int c_prcp, c_w1 = 0, c_w2 = 0, c_full = 0, c_min;
+    if (prcp <= 0.f) { ifl = 0.f; c_prcp = 0; c_min = 0; }
+    else {
+        c_prcp = 1;
+        cusl = cusl1 + cusl2;
+        wusl = husl1 * cusl1 + husl2 * cusl2;
+        if (1.e-6f < wusl) c_w1 = 0; else { wusl = 1.e-6f; c_w1 = 1; }
+        if (cusl - 1e-6f > wusl) c_w2 = 0; else { wusl = cusl - 1e-6f; c_w2 = 1; }
+        iflm = cusl * bp1;
+        pwx1 = 1.f - wusl / cusl;
+        pwy1 = 1.f / bp1;
+        pwr1 = sx_powf(pwx1, pwy1);
+        iflc = iflm * (1.f - pwr1);
+        if (iflc + prcp >= iflm) { ifl = cusl - wusl; c_full = 1; }
+        else {
+            pwx1 = 1.f - (iflc + prcp) / iflm;
+            pwr1_first = pwr1;
+            pwr1 = sx_powf(pwx1, bp1);
+            ifl = cusl - wusl - cusl * pwr1;
+            c_full = 0;
+        }
+        if (prcp > ifl) c_min = 2; else { ifl = prcp; c_min = 1; }
+    }
+    float ifl_usl1, ifl_usl2;
+    int c_u1, c_u2;
+    if ((1.f - husl1) * cusl1 > ifl) { ifl_usl1 = ifl; c_u1 = 0; } else { ifl_usl1 = (1.f - husl1) * cusl1; c_u1 = 1; }
+    ifl = ifl - ifl_usl1;
+    if ((1.f - husl2) * cusl2 > ifl) { ifl_usl2 = ifl; c_u2 = 0; } else { ifl_usl2 = (1.f - husl2) * cusl2; c_u2 = 1; }
+    float ifl_usl1_b = G.husl1_b / cusl1 - runoff_b;
+    float ifl_usl2_b = G.husl2_b / cusl2 - runoff_b;
+    G.cusl2_b = G.cusl2_b - ifl_usl2 * G.husl2_b / (cusl2 * cusl2);
+    G.cusl1_b = G.cusl1_b - ifl_usl1 * G.husl1_b / (cusl1 * cusl1);
+    float ifl_b;
+    if (c_u2 == 0) ifl_b = ifl_usl2_b;
+    else {
+        G.husl2_b = G.husl2_b - cusl2 * ifl_usl2_b;
+        G.cusl2_b = G.cusl2_b + (1.f - husl2) * ifl_usl2_b;
+        ifl_b = 0.f;
+    }
+    ifl_usl1_b = ifl_usl1_b - ifl_b;
+    if (c_u1 == 0) ifl_b = ifl_b + ifl_usl1_b;
+    else {
+        G.husl1_b = G.husl1_b - cusl1 * ifl_usl1_b;
+        G.cusl1_b = G.cusl1_b + (1.f - husl1) * ifl_usl1_b;
+    }
+    float bp1_b;
+    if (c_prcp == 0) bp1_b = 0.f;
+    else {
+        if (c_min == 1) ifl_b = 0.f;
+        float cusl_b, wusl_b, iflc_b, iflm_b, pwr1_b, pwx1_b, pwy1_b;
+        if (c_full == 0) {
+            cusl_b = (1.0f - pwr1) * ifl_b;
+            wusl_b = -ifl_b;
+            pwr1_b = -(cusl * ifl_b);
+            pwr1 = pwr1_first;
+            if (pwx1 <= 0.0f && (bp1 == 0.0f || bp1 != (float)(int)bp1)) pwx1_b = 0.f;
+            else pwx1_b = bp1 * sx_powf(pwx1, bp1 - 1.f) * pwr1_b;
+            if (pwx1 <= 0.0f) bp1_b = 0.f;
+            else bp1_b = sx_powf(pwx1, bp1) * sx_logf(pwx1) * pwr1_b;
+            iflc_b = -(pwx1_b / iflm);
+            iflm_b = (prcp + iflc) * pwx1_b / (iflm * iflm);
+            pwy1 = 1.f / bp1;
+            pwx1 = 1.f - wusl / cusl;
+        } else {
+            cusl_b = ifl_b;
+            wusl_b = -ifl_b;
+            iflc_b = 0.f;
+            iflm_b = 0.f;
+            bp1_b = 0.f;
+        }
+        iflm_b = iflm_b + (1.f - pwr1) * iflc_b;
+        pwr1_b = -(iflm * iflc_b);
+        if (pwx1 <= 0.0f && (pwy1 == 0.0f || pwy1 != (float)(int)pwy1)) pwx1_b = 0.f;
+        else pwx1_b = pwy1 * sx_powf(pwx1, pwy1 - 1.f) * pwr1_b;
+        if (pwx1 <= 0.0f) pwy1_b = 0.f;
+        else pwy1_b = sx_powf(pwx1, pwy1) * sx_logf(pwx1) * pwr1_b;
+        bp1_b = bp1_b + cusl * iflm_b - pwy1_b / (bp1 * bp1);
+        wusl_b = wusl_b - pwx1_b / cusl;
+        cusl_b = cusl_b + wusl * pwx1_b / (cusl * cusl) + bp1 * iflm_b;
+        if (c_w2 != 0) { cusl_b = cusl_b + wusl_b; wusl_b = 0.f; }
+        if (c_w1 != 0) wusl_b = 0.f;
+        G.husl1_b = G.husl1_b + cusl1 * wusl_b;
+        G.cusl1_b = G.cusl1_b + husl1 * wusl_b + cusl_b;
+        G.husl2_b = G.husl2_b + cusl2 * wusl_b;
+        G.cusl2_b = G.cusl2_b + husl2 * wusl_b + cusl_b;
+    }
+    G.b_b = G.b_b + bp1_b;
+}
+
+// residual = 0, porosity = 1, lambda = 1: pwr1 = pwx1, d(pwx1**1) = pwr1_b
+SX_DEV void sx_brooks_corey_b(float ks, float& ks_b, float c_upper, float& c_upper_b, float c_lower, float& c_lower_b, float h_upper,
+                              float& h_upper_b, float h_lower, float& h_lower_b, float flow_b) {
+    const float pwx1 = (h_upper - 0.f) / (1.f - 0.f);
+    const float pwr1 = pwx1;
+    const float flow = ks * pwr1;
+    const float w_upper = h_upper * c_upper * 1.f;
+    const float w_lower = h_lower * c_lower * 1.f;
+    float max_flow, max_flow_b, w_lower_b, w_upper_b;
+    int br;
+    if (w_upper > c_lower - w_lower) { max_flow = c_lower - w_lower; br = 0; } else { max_flow = w_upper; br = 1; }
+    if (max_flow > flow) max_flow_b = 0.f;
+    else { max_flow_b = flow_b; flow_b = 0.f; }
+    if (br == 0) { c_lower_b = c_lower_b + max_flow_b; w_lower_b = -max_flow_b; w_upper_b = 0.f; }
+    else { w_upper_b = max_flow_b; w_lower_b = 0.f; }
+    const float pwr1_b = ks * flow_b;
+    const float pwx1_b = 1.f * 1.f * pwr1_b;          // lambda * pwx1**(lambda - 1) * pwr1_b
+    h_lower_b = h_lower_b + c_lower * 1.f * w_lower_b;
+    c_lower_b = c_lower_b + h_lower * 1.f * w_lower_b;
+    h_upper_b = h_upper_b + c_upper * 1.f * w_upper_b + pwx1_b / (1.f - 0.f);
+    c_upper_b = c_upper_b + h_upper * 1.f * w_upper_b;
+    ks_b = ks_b + pwr1 * flow_b;
+}
+
+SX_DEV void sx_linear_evap_b(float e, float& e_b, float c, float& c_b, float h, float& h_b, float flow_b) {
+    const float flow = e * h, w = c * h;
+    float w_b;
+    if (w > flow) w_b = 0.f;
+    else { w_b = flow_b; flow_b = 0.f; }
+    c_b = c_b + h * w_b;
+    h_b = h_b + c * w_b + e * flow_b;
+    e_b = e_b + h * flow_b;
+}
+
+// husl1, husl2, hlsl: the levels on entry of vic_vertical_transfer
+SX_DEV void sx_vic_vertical_transfer_b(float pet, float cusl1, float cusl2, float clsl, float ks, float husl1, float husl2, float hlsl,
+                                       SxVicGrads& G) {
+    const float h1_0 = husl1, h2_0 = husl2;
+    const float fbc1 = sx_brooks_corey(ks, cusl1, cusl2, husl1, husl2);
+    husl1 = husl1 - fbc1 / cusl1;
+    husl2 = husl2 + fbc1 / cusl2;
+    const float h2_1 = husl2, hl_1 = hlsl;
+    const float fbc2 = sx_brooks_corey(ks, cusl2, clsl, husl2, hlsl);
+    husl2 = husl2 - fbc2 / cusl2;
+    hlsl = hlsl + fbc2 / clsl;
+    const float h1_2 = husl1, h2_2 = husl2, hl_2 = hlsl;
+    const float fe1 = sx_linear_evap(pet, cusl1, husl1);
+    float pet_remain1, pet_remain2;
+    int br1, br2;
+    if (0.f < pet - fe1) { pet_remain1 = pet - fe1; br1 = 0; } else { pet_remain1 = 0.f; br1 = 1; }
+    const float fe2 = sx_linear_evap(pet_remain1, cusl2, h2_2);
+    if (0.f < pet_remain1 - fe2) { pet_remain2 = pet_remain1 - fe2; br2 = 0; } else { pet_remain2 = 0.f; br2 = 1; }
+    const float fe3 = sx_linear_evap(pet_remain2, clsl, hl_2);
+    float fe_b = -(G.hlsl_b / clsl);
+    G.clsl_b = G.clsl_b + fe3 * G.hlsl_b / (clsl * clsl);
+    float pet_remain_b = 0.f;
+    sx_linear_evap_b(pet_remain2, pet_remain_b, clsl, G.clsl_b, hl_2, G.hlsl_b, fe_b);
+    if (br2 == 0) fe_b = -pet_remain_b;
+    else { pet_remain_b = 0.f; fe_b = 0.f; }
+    fe_b = fe_b - G.husl2_b / cusl2;
+    G.cusl2_b = G.cusl2_b + fe2 * G.husl2_b / (cusl2 * cusl2);
+    sx_linear_evap_b(pet_remain1, pet_remain_b, cusl2, G.cusl2_b, h2_2, G.husl2_b, fe_b);
+    if (br1 == 0) fe_b = -pet_remain_b;
+    else fe_b = 0.f;
+    fe_b = fe_b - G.husl1_b / cusl1;
+    G.cusl1_b = G.cusl1_b + fe1 * G.husl1_b / (cusl1 * cusl1);
+    float pet_b = 0.f;
+    sx_linear_evap_b(pet, pet_b, cusl1, G.cusl1_b, h1_2, G.husl1_b, fe_b);
+    float fbc_b = G.hlsl_b / clsl - G.husl2_b / cusl2;
+    G.clsl_b = G.clsl_b - fbc2 * G.hlsl_b / (clsl * clsl);
+    G.cusl2_b = G.cusl2_b + fbc2 * G.husl2_b / (cusl2 * cusl2);
+    sx_brooks_corey_b(ks, G.ks_b, cusl2, G.cusl2_b, clsl, G.clsl_b, h2_1, G.husl2_b, hl_1, G.hlsl_b, fbc_b);
+    fbc_b = G.husl2_b / cusl2 - G.husl1_b / cusl1;
+    G.cusl2_b = G.cusl2_b - fbc1 * G.husl2_b / (cusl2 * cusl2);
+    G.cusl1_b = G.cusl1_b + fbc1 * G.husl1_b / (cusl1 * cusl1);
+    sx_brooks_corey_b(ks, G.ks_b, cusl1, G.cusl1_b, cusl2, G.cusl2_b, h1_0, G.husl1_b, h2_0, G.husl2_b, fbc_b);
+}
+
+// husl2: level on entry; n = 5
+SX_DEV void sx_vic_interflow_b(float cusl2, float cusl2_m4, float cusl2_m5, float husl2, float qi_b, SxVicGrads& G) {
+    const float husl2_imd = husl2;
+    const float pwx1 = husl2_imd * cusl2;
+    float pwr1, pwx1_m5;
+    sx_pow_m4_m5(pwx1, &pwr1, &pwx1_m5);
+    const float pwx3 = pwr1 + cusl2_m4;
+    float pwr3, pwx3_m125;
+    sx_pow_m025_m125(pwx3, &pwr3, &pwx3_m125);
+    const float husl2_new = pwr3 / cusl2;
+    const float hb = G.husl2_b - cusl2 * qi_b;
+    const float pwr3_b = hb / cusl2;
+    const float pwx3_b = (pwx3 <= 0.f) ? 0.f : -0.25f * pwx3_m125 * pwr3_b;
+    const float pwr1_b = pwx3_b, pwr2_b = pwx3_b;
+    const float pwx1_b = -4.f * pwx1_m5 * pwr1_b;
+    const float husl2_imd_b = cusl2 * qi_b + cusl2 * pwx1_b;
+    G.cusl2_b = G.cusl2_b + (husl2_imd - husl2_new) * qi_b + -4.f * cusl2_m5 * pwr2_b - pwr3 * hb / (cusl2 * cusl2) + husl2_imd * pwx1_b;
+    G.husl2_b = husl2_imd_b;
+}
+
+// hlsl: level on entry
+SX_DEV void sx_vic_baseflow_b(float clsl, float ds, float dsm, float ws, float hlsl, float qb_b, SxVicGrads& G) {
+    float qb;
+    int br1, br2;
+    if (hlsl <= ws) { qb = ds * dsm / ws * hlsl; br1 = 1; }
+    else { qb = dsm * (1.f - ds / ws) * (hlsl - ws) / (1.f - ws); br1 = 0; }
+    const float wlsl = clsl * hlsl;
+    if (wlsl > qb) br2 = 0; else { qb = wlsl; br2 = 1; }
+    qb_b = qb_b - G.hlsl_b / clsl;
+    G.clsl_b = G.clsl_b + qb * G.hlsl_b / (clsl * clsl);
+    float wlsl_b;
+    if (br2 == 0) wlsl_b = 0.f;
+    else { wlsl_b = qb_b; qb_b = 0.f; }
+    G.clsl_b = G.clsl_b + hlsl * wlsl_b;
+    G.hlsl_b = G.hlsl_b + clsl * wlsl_b;
+    if (br1 == 0) {
+        const float temp = dsm / (-ws + 1.f);
+        const float temp_b0 = -((hlsl - ws) * temp * qb_b / ws);
+        const float temp_b1 = (1.f - ds / ws) * qb_b;
+        G.hlsl_b = G.hlsl_b + temp * temp_b1;
+        const float temp_b = (hlsl - ws) * temp_b1 / (1.f - ws);
+        G.ws_b = G.ws_b + temp * temp_b - temp * temp_b1 - ds * temp_b0 / ws;
+        G.dsm_b = G.dsm_b + temp_b;
+        G.ds_b = G.ds_b + temp_b0;
+    } else {
+        const float temp = hlsl / ws;
+        G.ds_b = G.ds_b + dsm * temp * qb_b;
+        G.dsm_b = G.dsm_b + ds * temp * qb_b;
+        const float temp_b = ds * dsm * qb_b / ws;
+        G.hlsl_b = G.hlsl_b + temp_b;
+        G.ws_b = G.ws_b - temp * temp_b;
+    }
+}
+
+// reverse of sx_vic_step given the pre-step levels and qt_b (inner body of VIC_A_FORWARD_B, forward_db.f90:10271-10316)
+SX_DEV void sx_vic_step_b(const SxVicParams& P, float cusl2_m4, float cusl2_m5, float prcp, float pet, float husl1, float husl2, float hlsl,
+                          float qt_b, SxVicGrads& G) {
+    const bool wet = (prcp >= 0.f && pet >= 0.f);
+    float h1 = husl1, h2 = husl2, hl = hlsl, runoff = 0.f;
+    float h1_1 = h1, h2_1 = h2;
+    if (wet) {
+        sx_vic_infiltration(prcp, P.cusl1, P.cusl2, P.b, h1, h2, runoff);
+        h1_1 = h1; h2_1 = h2;
+        sx_vic_vertical_transfer(pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1, h2, hl);
+    }
+    sx_vic_baseflow_b(P.clsl, P.ds, P.dsm, P.ws, hl, qt_b, G);
+    sx_vic_interflow_b(P.cusl2, cusl2_m4, cusl2_m5, h2, qt_b, G);
+    if (wet) {
+        sx_vic_vertical_transfer_b(pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1_1, h2_1, hlsl, G);
+        sx_vic_infiltration_b(prcp, P.cusl1, P.cusl2, P.b, husl1, husl2, qt_b, G);
+    }
+}

@@ -17,7 +17,8 @@ from oracle import refbind
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not refbind.available("dropin"), reason="oracle/_ref/libsmash_dropin.so not built")]
 
-CASES = ["gr_a_12x12x48_nse", "gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask", "gr_d_48x48x480_nse"]
+CASES = ["gr_a_12x12x48_nse", "gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask", "gr_d_48x48x480_nse",
+         "vic_a_16x16x96_nse_gaps"]
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -102,10 +102,14 @@ def test_adjoint_vs_reference_golden(name):
     for k in synth.PARAM_NAMES:
         if k not in gu.STRUCT_PARAMS[g.structure]:
             assert np.array_equal(getattr(par_b, k), g.adj["parameters_b"][k]), k
-    assert not np.any(par_b.beta) and not np.any(sta_b.husl1)
+    for k in synth.STATE_NAMES:
+        if k not in gu.STRUCT_STATES[g.structure]:
+            assert np.array_equal(getattr(sta_b, k), g.adj["states_b"][k]), k
+    assert not np.any(par_b.beta)
 
 
-@pytest.mark.parametrize("name", ["gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask", "gr_c_32x32x240_d8_ragged"])
+@pytest.mark.parametrize("name", ["gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask", "gr_c_32x32x240_d8_ragged",
+                                  "vic_a_24x24x240_d8_kge"])
 @pytest.mark.parametrize("chunk,pipe,group", [(16, 0, 64), (32, 16, 128), (48, 32, 512), (0, 16, 256)])
 def test_chunking_and_grouping_do_not_change_results(name, chunk, pipe, group):
     """Time-chunk checkpointing, the two-stream chunk pipeline and the routing partition only reorder
