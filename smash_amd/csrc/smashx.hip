@@ -165,6 +165,9 @@ struct smashx_plan {
     hipStream_t stream_r = nullptr;  // routing + cost kernels ("R stream"); overlaps the V stream chunk by chunk
     int Tp = 0;                      // pipeline sub-chunk length inside a storage chunk
     int chain_from = 1;              // first chained round
+    bool split_v = false;            // SMASHX_SPLIT_V=1: vertical kernels in two cell ranges so that routing round 0 overlaps the second.
+                                     // Measured slower (185 vs 175 ms at 1024^2 x 8760: both kernels lose more than the overlap hides): off.
+    int n0 = 0;                      // cells of the round-0 groups = [0, n0) in device order
     bool chain_used = false;         // a chained launch ran in the current sweep: check the stall flag afterwards
     bool chain = true;               // all routing rounds in one launch (progress counters), see sx_kernels.h
     // tile boundary exchange
@@ -315,6 +318,7 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
 // view of the chunk buffers shifted to local step `off` (multiple of 4) of the current storage chunk
 SxDeviceArrays view_at(const smashx_plan* p, int off) {
     SxDeviceArrays B = p->A;
+    B.k0 = 0; B.k1 = p->n;
     const size_t q = (size_t)(off / 4);
     B.qtT = p->A.qtT + q * p->npad * 4;
     if (p->A.hrT) B.hrT = p->A.hrT + q * p->npad * 4;
@@ -327,22 +331,25 @@ SxDeviceArrays view_at(const smashx_plan* p, int off) {
     return B;
 }
 
+// vertical launches on the cell range [k0, k1) (cells are numbered in routing-group order: round 0 first)
 template <int ST>
 void launch_vert_fwd(smashx_plan* p, const SxDeviceArrays& B, bool tape, int t0, int T) {
-    const dim3 grid(p->npad / SX_VBLOCK), block(SX_VBLOCK);
+    const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
     p->mark_begin(0, p->stream);
     if (tape) hipLaunchKernelGGL((sx_k_vert_fwd<ST, true>), grid, block, 0, p->stream, B, t0, T);
     else      hipLaunchKernelGGL((sx_k_vert_fwd<ST, false>), grid, block, 0, p->stream, B, t0, T);
     p->mark_end();
 }
-void vert_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
-    const SxDeviceArrays B = view_at(p, off);
+void vert_fwd(smashx_plan* p, int off, bool tape, int t0, int T, int k0 = 0, int k1 = -1) {
+    SxDeviceArrays B = view_at(p, off);
+    B.k0 = k0; B.k1 = k1 < 0 ? p->n : k1;
+    if (B.k1 <= B.k0) return;
     switch (p->st) {
         case 1: launch_vert_fwd<1>(p, B, tape, t0, T); break;
         case 2: launch_vert_fwd<2>(p, B, tape, t0, T); break;
         case 3: launch_vert_fwd<3>(p, B, tape, t0, T); break;
         case 5: {
-            const dim3 grid(p->npad / SX_VBLOCK), block(SX_VBLOCK);
+            const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
             p->mark_begin(0, p->stream);
             if (tape) hipLaunchKernelGGL((sx_k_vert_fwd_vic<true>), grid, block, 0, p->stream, B, t0, T);
             else      hipLaunchKernelGGL((sx_k_vert_fwd_vic<false>), grid, block, 0, p->stream, B, t0, T);
@@ -351,9 +358,11 @@ void vert_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
         default: launch_vert_fwd<4>(p, B, tape, t0, T); break;
     }
 }
-void vert_adj(smashx_plan* p, int off, int t0, int T) {
-    const SxDeviceArrays B = view_at(p, off);
-    const dim3 grid(p->npad / SX_VBLOCK), block(SX_VBLOCK);
+void vert_adj(smashx_plan* p, int off, int t0, int T, int k0 = 0, int k1 = -1) {
+    SxDeviceArrays B = view_at(p, off);
+    B.k0 = k0; B.k1 = k1 < 0 ? p->n : k1;
+    if (B.k1 <= B.k0) return;
+    const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
     p->mark_begin(3, p->stream);
     switch (p->st) {
         case 1: hipLaunchKernelGGL((sx_k_vert_adj<1>), grid, block, 0, p->stream, B, t0, T); break;
@@ -367,13 +376,15 @@ void vert_adj(smashx_plan* p, int off, int t0, int T) {
 // Routing launches of one pass.  Rounds below p->chain_from keep one launch per round (they are wide and
 // HBM-bound); the narrow, latency-bound rounds from chain_from on run chained inside a single launch
 // (sx_kernels.h "rounds chained inside one launch"), which turns their sum into roughly the longest of them.
-void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
+// wait_rest: event the launches after round 0 have to wait for (the vertical kernel of the cells outside round 0)
+void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T, hipEvent_t wait_rest = nullptr) {
     SxDeviceArrays B = view_at(p, off);
     if (!p->dom_q_active) B.qdT = nullptr;
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
     const int nr = p->sch.nrounds;
     const int cf = (p->chain && nr - p->chain_from >= 2) ? p->chain_from : nr;
     for (int r = 0; r < cf; ++r) {
+        if (r == 1 && wait_rest) (void)hipStreamWaitEvent(p->stream_r, wait_rest, 0);
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
         p->mark_begin(1, p->stream_r);
         if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
@@ -382,6 +393,7 @@ void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
     }
     if (cf < nr) {
         const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
+        if (cf <= 1 && wait_rest) (void)hipStreamWaitEvent(p->stream_r, wait_rest, 0);
         (void)hipMemsetAsync(p->A.prog, 0, (size_t)p->sch.ngroups * sizeof(int), p->stream_r);
         p->mark_begin(1, p->stream_r);
         if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(g1 - g0), dim3(p->M), lds, p->stream_r, B, g0, g1, t0, T);
@@ -390,7 +402,8 @@ void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
         p->chain_used = true;
     }
 }
-void route_adj(smashx_plan* p, int off, int t0, int T) {
+// after_rest: recorded once every round but round 0 has run (their cells' qt_b is final)
+void route_adj(smashx_plan* p, int off, int t0, int T, hipEvent_t after_rest = nullptr) {
     const SxDeviceArrays B = view_at(p, off);
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
     const int nr = p->sch.nrounds;
@@ -403,7 +416,9 @@ void route_adj(smashx_plan* p, int off, int t0, int T) {
         p->mark_end();
         p->chain_used = true;
     }
+    if (cf <= 1 && after_rest) (void)hipEventRecord(after_rest, p->stream_r);
     for (int r = cf - 1; r >= 0; --r) {
+        if (r == 0 && cf > 1 && after_rest) (void)hipEventRecord(after_rest, p->stream_r);
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
         p->mark_begin(2, p->stream_r);
         hipLaunchKernelGGL((sx_k_route_adj<false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
@@ -512,6 +527,10 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         A.ngroups = p->sch.ngroups;
         const char* e = getenv("SMASHX_CHAIN_ROUNDS");
         p->chain = !(e && e[0] == '0');
+        const char* sv = getenv("SMASHX_SPLIT_V");
+        p->split_v = sv && sv[0] == '1';
+        for (int g = p->sch.round_group_begin[0]; g < p->sch.round_group_begin[1]; ++g)
+            for (int q = p->sch.g_slot_begin[g]; q < p->sch.g_slot_begin[g + 1]; ++q) p->n0 += p->sch.s_cell[q] >= 0;
         const char* cfm = getenv("SMASHX_CHAIN_FROM");
         p->chain_from = cfm ? std::max(0, atoi(cfm)) : 1;
         A.gtime = nullptr;
@@ -858,16 +877,25 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
         const int rc2 = p->halo_fn(p->halo_user, phase, t0, T);
         return rc2 ? fail(SMASHX_E_ARG, "halo callback failed") : 0;
     };
+    const bool split = p->split_v && !halo && p->sch.nrounds > 1 && p->n0 > 0 && p->n0 < p->n;
     auto forward_chunk = [&](int c, bool tape) -> int {
         const int t0c = c * p->Tc, Tcur = chunk_len(p, c), ns = nsub_of(Tcur);
+        std::vector<hipEvent_t> ev(ns), ev_rest(ns, nullptr);
+        // split: the cells of round 0 first; routing round 0 then runs under the vertical kernel of the remaining cells
         auto launch_v = [&](int jb) -> int {
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
-            vert_fwd(p, off, tape, t0c + off, T);
+            if (split) {
+                vert_fwd(p, off, tape, t0c + off, T, 0, p->n0);
+                ev[jb] = p->event(); HIPCHK(hipEventRecord(ev[jb], sV));
+                vert_fwd(p, off, tape, t0c + off, T, p->n0, p->n);
+                ev_rest[jb] = p->event(); HIPCHK(hipEventRecord(ev_rest[jb], sV));
+            } else {
+                vert_fwd(p, off, tape, t0c + off, T);
+                ev[jb] = p->event(); HIPCHK(hipEventRecord(ev[jb], sV));
+            }
             return 0;
         };
-        std::vector<hipEvent_t> ev(ns);
         if ((rc = launch_v(0))) return rc;
-        ev[0] = p->event(); HIPCHK(hipEventRecord(ev[0], sV));
         for (int jb = 0; jb < ns; ++jb) {
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
             if (halo && p->n_in > 0) {
@@ -875,10 +903,9 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
                 halo_move(false, false, off, T);
             }
             HIPCHK(hipStreamWaitEvent(sR, ev[jb], 0));
-            route_fwd(p, off, tape, t0c + off, T);
+            route_fwd(p, off, tape, t0c + off, T, ev_rest[jb]);
             if (jb + 1 < ns) {                                     // keep the V stream busy while we wait on the R stream
                 if ((rc = launch_v(jb + 1))) return rc;
-                ev[jb + 1] = p->event(); HIPCHK(hipEventRecord(ev[jb + 1], sV));
             }
             if (halo && p->n_out > 0) {
                 halo_move(true, true, off, T);
@@ -974,11 +1001,19 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
                     if ((rc = hook(2, t0c + off, T))) return rc;  // out_buf now holds the downstream tiles' adjoint contributions
                     halo_move(false, true, off, T);
                 }
-                route_adj(p, off, t0c + off, T);
+                hipEvent_t e_rest = split ? p->event() : nullptr;
+                route_adj(p, off, t0c + off, T, e_rest);
                 hipEvent_t e = p->event();
                 HIPCHK(hipEventRecord(e, sR));
-                HIPCHK(hipStreamWaitEvent(sV, e, 0));
-                vert_adj(p, off, t0c + off, T);
+                if (split) {   // the cells outside round 0 start while routing round 0 is still running
+                    HIPCHK(hipStreamWaitEvent(sV, e_rest, 0));
+                    vert_adj(p, off, t0c + off, T, p->n0, p->n);
+                    HIPCHK(hipStreamWaitEvent(sV, e, 0));
+                    vert_adj(p, off, t0c + off, T, 0, p->n0);
+                } else {
+                    HIPCHK(hipStreamWaitEvent(sV, e, 0));
+                    vert_adj(p, off, t0c + off, T);
+                }
                 if (halo && p->n_in > 0) {
                     halo_move(true, false, off, T);
                     HIPCHK(hipStreamSynchronize(sR));

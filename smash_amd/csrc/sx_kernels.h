@@ -99,6 +99,7 @@ __device__ __forceinline__ void sx_publish(int* prog, int blocks) {
 struct SxDeviceArrays {
     // sizes
     int n, npad, nt, Tc;          // Tc = allocated chunk length (multiple of 16)
+    int k0, k1;                   // cell range [k0, k1) of a vertical launch (whole domain: 0, n)
     int nx;                       // exchange series count (>= 1)
     float dt, dx;
     // forcing
@@ -153,8 +154,8 @@ __global__ void sx_k_prep_routing(SxDeviceArrays A) {
 // ------------------------------------------------------------------------------------------------
 template <int ST, bool TAPE>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
-    const int k = blockIdx.x * SX_VBLOCK + threadIdx.x;
-    if (k >= A.n) return;
+    const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
+    if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;
 
     SxCellParams P;
@@ -216,8 +217,8 @@ __device__ __forceinline__ SxVicParams sx_vic_load(const SxDeviceArrays& A, int 
 }
 template <bool TAPE>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A, int t0, int T) {
-    const int k = blockIdx.x * SX_VBLOCK + threadIdx.x;
-    if (k >= A.n) return;
+    const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
+    if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;
     const SxVicParams P = sx_vic_load(A, k);
     const float cusl2_m4 = sx_pow_m4(P.cusl2);
@@ -245,8 +246,8 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A,
 }
 
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A, int t0, int T) {
-    const int k = blockIdx.x * SX_VBLOCK + threadIdx.x;
-    if (k >= A.n) return;
+    const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
+    if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;
     const SxVicParams P = sx_vic_load(A, k);
     float cusl2_m4, cusl2_m5;
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A,
 // ------------------------------------------------------------------------------------------------
 template <int ST>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, int t0, int T) {
-    const int k = blockIdx.x * SX_VBLOCK + threadIdx.x;
-    if (k >= A.n) return;
+    const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
+    if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;
     SxCellParams P;
     P.ci = (ST == 2 || ST == 3) ? A.ci[k] : 1.f;
@@ -708,8 +709,8 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
 #endif
 template <int ST>
 __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
-    const int k = blockIdx.x * SX_VBLOCK + threadIdx.x;
-    if (k >= A.n) return;
+    const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
+    if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;
     SxCellParams P;
     P.ci = (ST == 2 || ST == 3) ? A.ci[k] : 1.f;
