@@ -20,8 +20,9 @@
 #include <stdlib.h>
 #include <string.h>
 
-enum { P_CI = 0, P_CP = 1, P_CFT = 3, P_CST = 4, P_EXC = 6, P_LR = 15 };
-enum { S_HI = 0, S_HP = 1, S_HFT = 2, S_HST = 3, S_HLR = 7 };
+enum { P_CI = 0, P_CP = 1, P_CFT = 3, P_CST = 4, P_EXC = 6, P_B = 7, P_CUSL1 = 8, P_CUSL2 = 9, P_CLSL = 10, P_KS = 11, P_DS = 12,
+       P_DSM = 13, P_WS = 14, P_LR = 15 };
+enum { S_HI = 0, S_HP = 1, S_HFT = 2, S_HST = 3, S_HUSL1 = 4, S_HUSL2 = 5, S_HLSL = 6, S_HLR = 7 };
 
 typedef struct { float v, d; } dual;
 
@@ -146,10 +147,151 @@ static dual routing_d(float dt, dual qup, dual lr, dual* hr) {
 #define FLD(A, f, c) (A)[(f) * n2 + (c)]
 static dual mk(float v, float d) { dual x; x.v = v; x.d = d; return x; }
 
+/* ---- vic-a tangents: VIC_INFILTRATION_D :6691-6802, VIC_VERTICAL_TRANSFER_D :7042-7095, VIC_INTERFLOW_D :7235-7295,
+ * VIC_BASEFLOW_D :7402-7437, BROOKS_AND_COREY_FLOW_D :7530-7575, LINEAR_EVAPOTRANSPIRATION_D :7675-7695.  The primal
+ * follows the _D code, which re-associates vic_baseflow (qb = ds*dsm*(hlsl/ws); (1-ds/ws)*((hlsl-ws)*(dsm/(1-ws)))). */
+static float powd_full(float x, float y, float x_d, float y_d, float* r) {   /* d(x**y), both active, Tapenade's three cases */
+    float t = powf(x, y);
+    *r = t;
+    if (x <= 0.f && (y == 0.f || y != (float)(int)y)) return 0.f;
+    if (x <= 0.f) return y * powf(x, y - 1.f) * x_d;
+    return y * powf(x, y - 1.f) * x_d + t * logf(x) * y_d;
+}
+static void vic_infiltration_d(float prcp, dual cusl1, dual cusl2, dual b, dual* husl1, dual* husl2, dual* runoff) {
+    float bp1_d = b.d, bp1 = b.v + 1.f, ifl, ifl_d;
+    if (prcp <= 0.f) { ifl = 0.f; ifl_d = 0.f; }
+    else {
+        float cusl_d = cusl1.d + cusl2.d, cusl = cusl1.v + cusl2.v;
+        float wusl_d = cusl1.v * husl1->d + husl1->v * cusl1.d + cusl2.v * husl2->d + husl2->v * cusl2.d;
+        float wusl = husl1->v * cusl1.v + husl2->v * cusl2.v;
+        if (!(1.e-6f < wusl)) { wusl = 1.e-6f; wusl_d = 0.f; }
+        if (!(cusl - 1e-6f > wusl)) { wusl_d = cusl_d; wusl = cusl - 1e-6f; }
+        float iflm_d = bp1 * cusl_d + cusl * bp1_d, iflm = cusl * bp1;
+        float pwx1_d = -((wusl_d - wusl * cusl_d / cusl) / cusl), pwx1 = 1.f - wusl / cusl;
+        float pwy1_d = -(bp1_d / (bp1 * bp1)), pwy1 = 1.f / bp1;
+        float pwr1, pwr1_d = powd_full(pwx1, pwy1, pwx1_d, pwy1_d, &pwr1);
+        float iflc_d = (1.f - pwr1) * iflm_d - iflm * pwr1_d, iflc = iflm * (1.f - pwr1);
+        if (iflc + prcp >= iflm) { ifl_d = cusl_d - wusl_d; ifl = cusl - wusl; }
+        else {
+            float temp = (prcp + iflc) / iflm;
+            pwx1_d = -((iflc_d - temp * iflm_d) / iflm);
+            pwx1 = 1.f - temp;
+            pwr1_d = powd_full(pwx1, bp1, pwx1_d, bp1_d, &pwr1);
+            ifl_d = (1.0f - pwr1) * cusl_d - wusl_d - cusl * pwr1_d;
+            ifl = cusl - wusl - cusl * pwr1;
+        }
+        if (!(prcp > ifl)) { ifl = prcp; ifl_d = 0.f; }
+    }
+    float u1, u1_d, u2, u2_d;
+    if ((1.f - husl1->v) * cusl1.v > ifl) { u1_d = ifl_d; u1 = ifl; }
+    else { u1_d = (1.f - husl1->v) * cusl1.d - cusl1.v * husl1->d; u1 = (1.f - husl1->v) * cusl1.v; }
+    ifl_d = ifl_d - u1_d; ifl = ifl - u1;
+    if ((1.f - husl2->v) * cusl2.v > ifl) { u2_d = ifl_d; u2 = ifl; }
+    else { u2_d = (1.f - husl2->v) * cusl2.d - cusl2.v * husl2->d; u2 = (1.f - husl2->v) * cusl2.v; }
+    husl1->d = husl1->d + (u1_d - u1 * cusl1.d / cusl1.v) / cusl1.v;
+    husl1->v = husl1->v + u1 / cusl1.v;
+    husl2->d = husl2->d + (u2_d - u2 * cusl2.d / cusl2.v) / cusl2.v;
+    husl2->v = husl2->v + u2 / cusl2.v;
+    runoff->d = -u1_d - u2_d;
+    runoff->v = prcp - (u1 + u2);
+}
+static dual brooks_d(dual ks, dual c_upper, dual c_lower, dual h_upper, dual h_lower) {   /* residual 0, porosity 1, lambda 1 */
+    dual flow;
+    float pwx1_d = h_upper.d / (1.f - 0.f), pwx1 = (h_upper.v - 0.f) / (1.f - 0.f);
+    float pwr1_d = 1.f * powf(pwx1, 0.f) * pwx1_d, pwr1 = powf(pwx1, 1.f);
+    flow.d = pwr1 * ks.d + ks.v * pwr1_d;
+    flow.v = ks.v * pwr1;
+    float w_upper_d = 1.f * (c_upper.v * h_upper.d + h_upper.v * c_upper.d), w_upper = h_upper.v * c_upper.v * 1.f;
+    float w_lower_d = 1.f * (c_lower.v * h_lower.d + h_lower.v * c_lower.d), w_lower = h_lower.v * c_lower.v * 1.f;
+    float max_flow, max_flow_d;
+    if (w_upper > c_lower.v - w_lower) { max_flow_d = c_lower.d - w_lower_d; max_flow = c_lower.v - w_lower; }
+    else { max_flow_d = w_upper_d; max_flow = w_upper; }
+    if (!(max_flow > flow.v)) { flow.d = max_flow_d; flow.v = max_flow; }
+    return flow;
+}
+static dual evap_d(dual e, dual c, dual h) {
+    dual flow;
+    flow.d = h.v * e.d + e.v * h.d; flow.v = e.v * h.v;
+    float w_d = h.v * c.d + c.v * h.d, w = c.v * h.v;
+    if (!(w > flow.v)) { flow.d = w_d; flow.v = w; }
+    return flow;
+}
+static void vic_vertical_transfer_d(float pet, dual cusl1, dual cusl2, dual clsl, dual ks, dual* husl1, dual* husl2, dual* hlsl) {
+    dual fbc = brooks_d(ks, cusl1, cusl2, *husl1, *husl2);
+    husl1->d = husl1->d - (fbc.d - fbc.v * cusl1.d / cusl1.v) / cusl1.v; husl1->v = husl1->v - fbc.v / cusl1.v;
+    husl2->d = husl2->d + (fbc.d - fbc.v * cusl2.d / cusl2.v) / cusl2.v; husl2->v = husl2->v + fbc.v / cusl2.v;
+    fbc = brooks_d(ks, cusl2, clsl, *husl2, *hlsl);
+    husl2->d = husl2->d - (fbc.d - fbc.v * cusl2.d / cusl2.v) / cusl2.v; husl2->v = husl2->v - fbc.v / cusl2.v;
+    hlsl->d = hlsl->d + (fbc.d - fbc.v * clsl.d / clsl.v) / clsl.v; hlsl->v = hlsl->v + fbc.v / clsl.v;
+    dual fe = evap_d(mk(pet, 0.f), cusl1, *husl1);
+    husl1->d = husl1->d - (fe.d - fe.v * cusl1.d / cusl1.v) / cusl1.v; husl1->v = husl1->v - fe.v / cusl1.v;
+    dual pr;
+    if (0.f < pet - fe.v) { pr.d = -fe.d; pr.v = pet - fe.v; } else { pr.v = 0.f; pr.d = 0.f; }
+    fe = evap_d(pr, cusl2, *husl2);
+    husl2->d = husl2->d - (fe.d - fe.v * cusl2.d / cusl2.v) / cusl2.v; husl2->v = husl2->v - fe.v / cusl2.v;
+    if (0.f < pr.v - fe.v) { pr.d = pr.d - fe.d; pr.v = pr.v - fe.v; } else { pr.v = 0.f; pr.d = 0.f; }
+    fe = evap_d(pr, clsl, *hlsl);
+    hlsl->d = hlsl->d - (fe.d - fe.v * clsl.d / clsl.v) / clsl.v; hlsl->v = hlsl->v - fe.v / clsl.v;
+}
+static void vic_interflow_d(float n, dual cusl2, dual* husl2, dual* qi) {
+    const float nm1 = n - 1.f, d1pnm1 = 1.f / nm1;
+    dual him = *husl2;
+    float pwx1_d = cusl2.v * him.d + him.v * cusl2.d, pwx1 = him.v * cusl2.v;
+    float pwr1_d = pow_d(pwx1, -nm1, pwx1_d), pwr1 = powf(pwx1, -nm1);
+    float pwr2_d = pow_d(cusl2.v, -nm1, cusl2.d), pwr2 = powf(cusl2.v, -nm1);
+    float pwx3_d = pwr1_d + pwr2_d, pwx3 = pwr1 + pwr2;
+    float pwr3_d = pow_d(pwx3, -d1pnm1, pwx3_d), pwr3 = powf(pwx3, -d1pnm1);
+    husl2->d = (pwr3_d - pwr3 * cusl2.d / cusl2.v) / cusl2.v;
+    husl2->v = pwr3 / cusl2.v;
+    qi->d = cusl2.v * (him.d - husl2->d) + (him.v - husl2->v) * cusl2.d;
+    qi->v = (him.v - husl2->v) * cusl2.v;
+}
+static void vic_baseflow_d(dual clsl, dual ds, dual dsm, dual ws, dual* hlsl, dual* qb) {
+    float q, q_d;
+    if (hlsl->v <= ws.v) {
+        float temp = hlsl->v / ws.v;
+        q_d = temp * (dsm.v * ds.d + ds.v * dsm.d) + ds.v * dsm.v * (hlsl->d - temp * ws.d) / ws.v;
+        q = ds.v * dsm.v * temp;
+    } else {
+        float temp = dsm.v / (-ws.v + 1.f), temp0 = ds.v / ws.v;
+        q_d = (1.f - temp0) * (temp * (hlsl->d - ws.d) + (hlsl->v - ws.v) * (dsm.d + temp * ws.d) / (1.f - ws.v)) -
+              (hlsl->v - ws.v) * temp * (ds.d - temp0 * ws.d) / ws.v;
+        q = (1.f - temp0) * ((hlsl->v - ws.v) * temp);
+    }
+    float wlsl_d = hlsl->v * clsl.d + clsl.v * hlsl->d, wlsl = clsl.v * hlsl->v;
+    if (!(wlsl > q)) { q_d = wlsl_d; q = wlsl; }
+    hlsl->d = hlsl->d - (q_d - q * clsl.d / clsl.v) / clsl.v;
+    hlsl->v = hlsl->v - q / clsl.v;
+    qb->d = q_d; qb->v = q;
+}
+
+
 /* GR_{A,B,C,D}_FORWARD_D: one cell-step */
 static void cell_step_d(int st, float dt, float dx, int nrow, int ncol, const int* flwdir, const int* flwacc, int row, int col,
                         float prcp, float pet, const float* P, const float* P_d, float* S, float* S_d, float* q, float* q_d) {
     const long n2 = (long)nrow * ncol, c = row + (long)col * nrow;
+    if (st == ORC_VIC_A) {   /* VIC_A_FORWARD_D, forward_db.f90:9949-10095 */
+#define DP(f) mk(FLD(P, f, c), FLD(P_d, f, c))
+        dual h1 = mk(FLD(S, S_HUSL1, c), FLD(S_d, S_HUSL1, c)), h2 = mk(FLD(S, S_HUSL2, c), FLD(S_d, S_HUSL2, c));
+        dual hl = mk(FLD(S, S_HLSL, c), FLD(S_d, S_HLSL, c)), hr = mk(FLD(S, S_HLR, c), FLD(S_d, S_HLR, c));
+        dual runoff = {0.f, 0.f}, qi, qb, qtv;
+        if (prcp >= 0.f && pet >= 0.f) {
+            vic_infiltration_d(prcp, DP(P_CUSL1), DP(P_CUSL2), DP(P_B), &h1, &h2, &runoff);
+            vic_vertical_transfer_d(pet, DP(P_CUSL1), DP(P_CUSL2), DP(P_CLSL), DP(P_KS), &h1, &h2, &hl);
+        }
+        vic_interflow_d(5.f, DP(P_CUSL2), &h2, &qi);
+        vic_baseflow_d(DP(P_CLSL), DP(P_DS), DP(P_DSM), DP(P_WS), &hl, &qb);
+        qtv.d = runoff.d + qi.d + qb.d; qtv.v = runoff.v + qi.v + qb.v;
+        dual qupv = upstream_d(dt, dx, nrow, ncol, flwdir, flwacc, row, col, q, q_d);
+        dual qro = routing_d(dt, qupv, DP(P_LR), &hr);
+        const float fv = (float)(flwacc[c] - 1), tempv = 0.001f * (dx * dx);
+        q_d[c] = tempv * (qtv.d + fv * qro.d) / dt;
+        q[c] = tempv * ((qtv.v + fv * qro.v) / dt);
+        FLD(S, S_HUSL1, c) = h1.v; FLD(S_d, S_HUSL1, c) = h1.d; FLD(S, S_HUSL2, c) = h2.v; FLD(S_d, S_HUSL2, c) = h2.d;
+        FLD(S, S_HLSL, c) = hl.v; FLD(S_d, S_HLSL, c) = hl.d; FLD(S, S_HLR, c) = hr.v; FLD(S_d, S_HLR, c) = hr.d;
+#undef DP
+        return;
+    }
     dual ei = {0, 0}, pn = {0, 0}, en = {0, 0}, pr = {0, 0}, perc = {0, 0}, l = {0, 0}, qr = {0, 0}, ql = {0, 0}, qd, qt;
     dual hi = mk(FLD(S, S_HI, c), FLD(S_d, S_HI, c)), hp = mk(FLD(S, S_HP, c), FLD(S_d, S_HP, c));
     dual hft = mk(FLD(S, S_HFT, c), FLD(S_d, S_HFT, c)), hst = mk(FLD(S, S_HST, c), FLD(S_d, S_HST, c));
@@ -396,7 +538,7 @@ int orc_forward_d(const orc_config* cfg, const int* flwdir, const int* flwacc, c
                   float* qsim, float* qsim_d, float* costs, float* cost_d) {
     const int nrow = cfg->nrow, ncol = cfg->ncol;
     const long n2 = (long)nrow * ncol;
-    if (cfg->structure < ORC_GR_A || cfg->structure > ORC_GR_D) return -2;
+    if (cfg->structure < ORC_GR_A || cfg->structure > ORC_VIC_A) return -2;
     if (cfg->denormalize_forward) {   /* DENORMALIZE_*_D */
         for (int i = 0; i < ORC_GNP; ++i)
             for (long c = 0; c < n2; ++c) {

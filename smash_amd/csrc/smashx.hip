@@ -1288,7 +1288,6 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
                      float* qsim_d, smashx_costs* costs, float* cost_d) {
     if (!p || !params || !states || !params_d || !states_d || !cost_d) return fail(SMASHX_E_ARG, "null argument");
     if (p->tiled) return fail(SMASHX_E_UNSUPPORTED, "tangent model on a tiled plan");
-    if (p->st == 5) return fail(SMASHX_E_UNSUPPORTED, "tangent model of vic-a (VIC_A_FORWARD_D) is not built");
     int rc = smashx_upload(p, params, params_bgd, states, states_bgd); if (rc) return rc;
     if (!p->have_forcing) return fail(SMASHX_E_STATE, "forcing not set");
     if ((rc = set_device(p))) return rc;
@@ -1306,9 +1305,9 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
         p->tan_ready = true;
     }
     // direction -> per-cell arrays (the gradient arrays double as tangent storage); DENORMALIZE_*_D scales by (ub - lb)
-    float* tp[6] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.lr_b};
+    float* tp[NPS] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.lr_b, p->A.px_b[0], p->A.px_b[1], p->A.px_b[2]};
     float* ts[5] = {p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b, p->A.hlr_b};
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NPS; ++i) {
         const int f = param_field(st, i);
         HIPCHK(hipMemsetAsync(tp[i], 0, (size_t)p->npad * 4, sV));
         if (f < 0) continue;
@@ -1400,6 +1399,7 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
             case 1: hipLaunchKernelGGL((sx_k_vert_fwd_d<1>), vgrid, vblock, 0, sV, B, t0c, Tcur); break;
             case 2: hipLaunchKernelGGL((sx_k_vert_fwd_d<2>), vgrid, vblock, 0, sV, B, t0c, Tcur); break;
             case 3: hipLaunchKernelGGL((sx_k_vert_fwd_d<3>), vgrid, vblock, 0, sV, B, t0c, Tcur); break;
+            case 5: hipLaunchKernelGGL(sx_k_vert_fwd_vic_d, vgrid, vblock, 0, sV, B, t0c, Tcur); break;
             default: hipLaunchKernelGGL((sx_k_vert_fwd_d<4>), vgrid, vblock, 0, sV, B, t0c, Tcur); break;
         }
         p->mark_end();

@@ -269,6 +269,30 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A,
     A.hi_b[k] = G.husl1_b; A.hp_b[k] = G.husl2_b; A.hft_b[k] = G.hlsl_b;
 }
 
+// vic-a with tangents (VIC_A_FORWARD_D): tangents of the parameters / levels live in the gradient arrays
+__global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic_d(SxDeviceArrays A, int t0, int T) {
+    const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;
+    if (k >= A.k1) return;
+    const size_t npad = (size_t)A.npad;
+    const SxVicParams P = sx_vic_load(A, k);
+    SxVicTan D;
+    D.b_d = A.ci_b[k]; D.cusl1_d = A.cp_b[k]; D.cusl2_d = A.cft_b[k]; D.clsl_d = A.cst_b[k]; D.ks_d = A.exc_b[k];
+    D.ds_d = A.px_b[0][k]; D.dsm_d = A.px_b[1][k]; D.ws_d = A.px_b[2][k];
+    float cusl2_m4, cusl2_m5;
+    sx_pow_m4_m5(P.cusl2, &cusl2_m4, &cusl2_m5);
+    SxVD husl1 = sx_vd(A.hi[k], A.hi_b[k]), husl2 = sx_vd(A.hp[k], A.hp_b[k]), hlsl = sx_vd(A.hft[k], A.hft_b[k]);
+    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
+    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    float* qt = A.qtT + (size_t)k * 4;
+    float* qd = A.qtdT + (size_t)k * 4;
+    for (int tt = 0; tt < T; ++tt) {
+        const SxVD r = sx_vic_step_d(P, D, cusl2_m4, cusl2_m5, prcp_p[(size_t)tt * npad], pet_p[(size_t)tt * npad], husl1, husl2, hlsl);
+        const size_t o = (size_t)(tt >> 2) * npad * 4 + (tt & 3);
+        qt[o] = r.v; qd[o] = r.d;
+    }
+    A.hi[k] = husl1.v; A.hi_b[k] = husl1.d; A.hp[k] = husl2.v; A.hp_b[k] = husl2.d; A.hft[k] = hlsl.v; A.hft_b[k] = hlsl.d;
+}
+
 // ------------------------------------------------------------------------------------------------
 // vertical forward with tangents (inner body of GR_x_FORWARD_D, forward_db.f90:7748-9602): thread per cell; writes
 // qt to qtT and qt_d to qtdT; the tangents of the states march along in the *_b arrays

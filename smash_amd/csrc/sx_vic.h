@@ -346,3 +346,145 @@ SX_DEV void sx_vic_step_b(const SxVicParams& P, float cusl2_m4, float cusl2_m5, 
         sx_vic_infiltration_b(prcp, P.cusl1, P.cusl2, P.b, husl1, husl2, qt_b, G);
     }
 }
+
+// ---------------------------------------------------------------- tangent (VIC_*_D, forward_db.f90:6691-7695)
+// (value, tangent) pairs; the primal follows the _D code, which re-associates vic_baseflow.
+struct SxVD { float v, d; };
+SX_DEV SxVD sx_vd(float v, float d) { SxVD x; x.v = v; x.d = d; return x; }
+
+SX_DEV float sx_powd_full(float x, float y, float x_d, float y_d, float& r) {   // d(x**y), both active: Tapenade's three cases
+    const float t = sx_powf(x, y);
+    r = t;
+    if (x <= 0.f && (y == 0.f || y != (float)(int)y)) return 0.f;
+    if (x <= 0.f) return y * sx_powf(x, y - 1.f) * x_d;
+    return y * sx_powf(x, y - 1.f) * x_d + t * sx_logf(x) * y_d;
+}
+
+SX_DEV void sx_vic_infiltration_d(float prcp, SxVD cusl1, SxVD cusl2, SxVD b, SxVD& husl1, SxVD& husl2, SxVD& runoff) {
+    const float bp1_d = b.d, bp1 = b.v + 1.f;
+    float ifl, ifl_d;
+    if (prcp <= 0.f) { ifl = 0.f; ifl_d = 0.f; }
+    else {
+        const float cusl_d = cusl1.d + cusl2.d, cusl = cusl1.v + cusl2.v;
+        float wusl_d = cusl1.v * husl1.d + husl1.v * cusl1.d + cusl2.v * husl2.d + husl2.v * cusl2.d;
+        float wusl = husl1.v * cusl1.v + husl2.v * cusl2.v;
+        if (!(1.e-6f < wusl)) { wusl = 1.e-6f; wusl_d = 0.f; }
+        if (!(cusl - 1e-6f > wusl)) { wusl_d = cusl_d; wusl = cusl - 1e-6f; }
+        const float iflm_d = bp1 * cusl_d + cusl * bp1_d, iflm = cusl * bp1;
+        float pwx1_d = -((wusl_d - wusl * cusl_d / cusl) / cusl), pwx1 = 1.f - wusl / cusl;
+        const float pwy1_d = -(bp1_d / (bp1 * bp1)), pwy1 = 1.f / bp1;
+        float pwr1;
+        float pwr1_d = sx_powd_full(pwx1, pwy1, pwx1_d, pwy1_d, pwr1);
+        const float iflc_d = (1.f - pwr1) * iflm_d - iflm * pwr1_d, iflc = iflm * (1.f - pwr1);
+        if (iflc + prcp >= iflm) { ifl_d = cusl_d - wusl_d; ifl = cusl - wusl; }
+        else {
+            const float temp = (prcp + iflc) / iflm;
+            pwx1_d = -((iflc_d - temp * iflm_d) / iflm);
+            pwx1 = 1.f - temp;
+            pwr1_d = sx_powd_full(pwx1, bp1, pwx1_d, bp1_d, pwr1);
+            ifl_d = (1.0f - pwr1) * cusl_d - wusl_d - cusl * pwr1_d;
+            ifl = cusl - wusl - cusl * pwr1;
+        }
+        if (!(prcp > ifl)) { ifl = prcp; ifl_d = 0.f; }
+    }
+    float u1, u1_d, u2, u2_d;
+    if ((1.f - husl1.v) * cusl1.v > ifl) { u1_d = ifl_d; u1 = ifl; }
+    else { u1_d = (1.f - husl1.v) * cusl1.d - cusl1.v * husl1.d; u1 = (1.f - husl1.v) * cusl1.v; }
+    ifl_d = ifl_d - u1_d; ifl = ifl - u1;
+    if ((1.f - husl2.v) * cusl2.v > ifl) { u2_d = ifl_d; u2 = ifl; }
+    else { u2_d = (1.f - husl2.v) * cusl2.d - cusl2.v * husl2.d; u2 = (1.f - husl2.v) * cusl2.v; }
+    husl1.d = husl1.d + (u1_d - u1 * cusl1.d / cusl1.v) / cusl1.v;
+    husl1.v = husl1.v + u1 / cusl1.v;
+    husl2.d = husl2.d + (u2_d - u2 * cusl2.d / cusl2.v) / cusl2.v;
+    husl2.v = husl2.v + u2 / cusl2.v;
+    runoff.d = -u1_d - u2_d;
+    runoff.v = prcp - (u1 + u2);
+}
+SX_DEV SxVD sx_brooks_corey_d(SxVD ks, SxVD c_upper, SxVD c_lower, SxVD h_upper, SxVD h_lower) {
+    SxVD flow;
+    const float pwx1_d = h_upper.d / (1.f - 0.f), pwx1 = (h_upper.v - 0.f) / (1.f - 0.f);
+    const float pwr1_d = 1.f * 1.f * pwx1_d, pwr1 = pwx1;
+    flow.d = pwr1 * ks.d + ks.v * pwr1_d;
+    flow.v = ks.v * pwr1;
+    const float w_upper_d = 1.f * (c_upper.v * h_upper.d + h_upper.v * c_upper.d), w_upper = h_upper.v * c_upper.v * 1.f;
+    const float w_lower_d = 1.f * (c_lower.v * h_lower.d + h_lower.v * c_lower.d), w_lower = h_lower.v * c_lower.v * 1.f;
+    float max_flow, max_flow_d;
+    if (w_upper > c_lower.v - w_lower) { max_flow_d = c_lower.d - w_lower_d; max_flow = c_lower.v - w_lower; }
+    else { max_flow_d = w_upper_d; max_flow = w_upper; }
+    if (!(max_flow > flow.v)) { flow.d = max_flow_d; flow.v = max_flow; }
+    return flow;
+}
+SX_DEV SxVD sx_linear_evap_d(SxVD e, SxVD c, SxVD h) {
+    SxVD flow;
+    flow.d = h.v * e.d + e.v * h.d; flow.v = e.v * h.v;
+    const float w_d = h.v * c.d + c.v * h.d, w = c.v * h.v;
+    if (!(w > flow.v)) { flow.d = w_d; flow.v = w; }
+    return flow;
+}
+SX_DEV void sx_vic_vertical_transfer_d(float pet, SxVD cusl1, SxVD cusl2, SxVD clsl, SxVD ks, SxVD& husl1, SxVD& husl2, SxVD& hlsl) {
+    SxVD fbc = sx_brooks_corey_d(ks, cusl1, cusl2, husl1, husl2);
+    husl1.d = husl1.d - (fbc.d - fbc.v * cusl1.d / cusl1.v) / cusl1.v; husl1.v = husl1.v - fbc.v / cusl1.v;
+    husl2.d = husl2.d + (fbc.d - fbc.v * cusl2.d / cusl2.v) / cusl2.v; husl2.v = husl2.v + fbc.v / cusl2.v;
+    fbc = sx_brooks_corey_d(ks, cusl2, clsl, husl2, hlsl);
+    husl2.d = husl2.d - (fbc.d - fbc.v * cusl2.d / cusl2.v) / cusl2.v; husl2.v = husl2.v - fbc.v / cusl2.v;
+    hlsl.d = hlsl.d + (fbc.d - fbc.v * clsl.d / clsl.v) / clsl.v; hlsl.v = hlsl.v + fbc.v / clsl.v;
+    SxVD fe = sx_linear_evap_d(sx_vd(pet, 0.f), cusl1, husl1);
+    husl1.d = husl1.d - (fe.d - fe.v * cusl1.d / cusl1.v) / cusl1.v; husl1.v = husl1.v - fe.v / cusl1.v;
+    SxVD pr;
+    if (0.f < pet - fe.v) { pr.d = -fe.d; pr.v = pet - fe.v; } else { pr.v = 0.f; pr.d = 0.f; }
+    fe = sx_linear_evap_d(pr, cusl2, husl2);
+    husl2.d = husl2.d - (fe.d - fe.v * cusl2.d / cusl2.v) / cusl2.v; husl2.v = husl2.v - fe.v / cusl2.v;
+    if (0.f < pr.v - fe.v) { pr.d = pr.d - fe.d; pr.v = pr.v - fe.v; } else { pr.v = 0.f; pr.d = 0.f; }
+    fe = sx_linear_evap_d(pr, clsl, hlsl);
+    hlsl.d = hlsl.d - (fe.d - fe.v * clsl.d / clsl.v) / clsl.v; hlsl.v = hlsl.v - fe.v / clsl.v;
+}
+SX_DEV void sx_vic_interflow_d(SxVD cusl2, float cusl2_m4, float cusl2_m5, SxVD& husl2, SxVD& qi) {   // n = 5
+    const SxVD him = husl2;
+    const float pwx1_d = cusl2.v * him.d + him.v * cusl2.d, pwx1 = him.v * cusl2.v;
+    float pwr1, pwx1_m5;
+    sx_pow_m4_m5(pwx1, &pwr1, &pwx1_m5);
+    const float pwr1_d = -4.f * pwx1_m5 * pwx1_d;
+    const float pwr2_d = -4.f * cusl2_m5 * cusl2.d;
+    const float pwx3_d = pwr1_d + pwr2_d, pwx3 = pwr1 + cusl2_m4;
+    float pwr3, pwx3_m125;
+    sx_pow_m025_m125(pwx3, &pwr3, &pwx3_m125);
+    const float pwr3_d = (pwx3 <= 0.f) ? 0.f : -0.25f * pwx3_m125 * pwx3_d;
+    husl2.d = (pwr3_d - pwr3 * cusl2.d / cusl2.v) / cusl2.v;
+    husl2.v = pwr3 / cusl2.v;
+    qi.d = cusl2.v * (him.d - husl2.d) + (him.v - husl2.v) * cusl2.d;
+    qi.v = (him.v - husl2.v) * cusl2.v;
+}
+SX_DEV void sx_vic_baseflow_d(SxVD clsl, SxVD ds, SxVD dsm, SxVD ws, SxVD& hlsl, SxVD& qb) {
+    float q, q_d;
+    if (hlsl.v <= ws.v) {
+        const float temp = hlsl.v / ws.v;
+        q_d = temp * (dsm.v * ds.d + ds.v * dsm.d) + ds.v * dsm.v * (hlsl.d - temp * ws.d) / ws.v;
+        q = ds.v * dsm.v * temp;
+    } else {
+        const float temp = dsm.v / (-ws.v + 1.f), temp0 = ds.v / ws.v;
+        q_d = (1.f - temp0) * (temp * (hlsl.d - ws.d) + (hlsl.v - ws.v) * (dsm.d + temp * ws.d) / (1.f - ws.v)) -
+              (hlsl.v - ws.v) * temp * (ds.d - temp0 * ws.d) / ws.v;
+        q = (1.f - temp0) * ((hlsl.v - ws.v) * temp);
+    }
+    const float wlsl_d = hlsl.v * clsl.d + clsl.v * hlsl.d, wlsl = clsl.v * hlsl.v;
+    if (!(wlsl > q)) { q_d = wlsl_d; q = wlsl; }
+    hlsl.d = hlsl.d - (q_d - q * clsl.d / clsl.v) / clsl.v;
+    hlsl.v = hlsl.v - q / clsl.v;
+    qb.d = q_d; qb.v = q;
+}
+struct SxVicTan { float b_d, cusl1_d, cusl2_d, clsl_d, ks_d, ds_d, dsm_d, ws_d; };
+// one vertical cell-step of VIC_A_FORWARD_D (forward_db.f90:9949-10095): returns qt (value, tangent)
+SX_DEV SxVD sx_vic_step_d(const SxVicParams& P, const SxVicTan& D, float cusl2_m4, float cusl2_m5, float prcp, float pet, SxVD& husl1,
+                          SxVD& husl2, SxVD& hlsl) {
+    SxVD runoff = sx_vd(0.f, 0.f), qi, qb, qt;
+    const SxVD cusl1 = sx_vd(P.cusl1, D.cusl1_d), cusl2 = sx_vd(P.cusl2, D.cusl2_d), clsl = sx_vd(P.clsl, D.clsl_d);
+    if (prcp >= 0.f && pet >= 0.f) {
+        sx_vic_infiltration_d(prcp, cusl1, cusl2, sx_vd(P.b, D.b_d), husl1, husl2, runoff);
+        sx_vic_vertical_transfer_d(pet, cusl1, cusl2, clsl, sx_vd(P.ks, D.ks_d), husl1, husl2, hlsl);
+    }
+    sx_vic_interflow_d(cusl2, cusl2_m4, cusl2_m5, husl2, qi);
+    sx_vic_baseflow_d(clsl, sx_vd(P.ds, D.ds_d), sx_vd(P.dsm, D.dsm_d), sx_vd(P.ws, D.ws_d), hlsl, qb);
+    qt.d = runoff.d + qi.d + qb.d;
+    qt.v = runoff.v + qi.v + qb.v;
+    return qt;
+}

@@ -167,7 +167,8 @@ def tangent_direction(g):
 
 
 TANGENT_CASES = ["gr_a_12x12x48_nse", "gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask", "gr_d_12x12x48_rmse_kge2_start",
-                 "gr_b_24x24x120_norm_jreg", "gr_b_16x16x96_median2", "gr_c_32x32x240_d8_ragged"]
+                 "gr_b_24x24x120_norm_jreg", "gr_b_16x16x96_median2", "gr_c_32x32x240_d8_ragged",
+                 "vic_a_16x16x96_nse_gaps", "vic_a_24x24x240_d8_kge"]
 
 
 def main_tangent():

@@ -43,7 +43,7 @@ def test_tangent_vs_reference_golden(name):
     assert abs(cost - g.fwd["cost"]) <= 1e-4 * abs(g.fwd["cost"]) + 1e-6
 
 
-@pytest.mark.parametrize("name", ["gr_b_64x64x720_nse", "gr_c_32x32x240_d8_ragged"])
+@pytest.mark.parametrize("name", ["gr_b_64x64x720_nse", "gr_c_32x32x240_d8_ragged", "vic_a_24x24x240_d8_kge"])
 def test_scalar_product(name):
     import smash_amd
     g = gu.load(name)
