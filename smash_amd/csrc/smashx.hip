@@ -130,16 +130,6 @@ __global__ void k_fill(float* dst, float v, size_t n) {
     if (i < n) dst[i] = v;
 }
 
-// fp64 dot product of two float arrays (one block): cost_d = <d cost / d y, y_d>
-__global__ void k_dot(const float* a, const float* b, size_t n, double* out, int accumulate) {
-    __shared__ double sh[256];
-    double acc = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) acc += (double)a[i] * (double)b[i];
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.0) + sh[0];
-}
 // qsim_d(g, t) from the per-gauge-cell tangent series
 __global__ void k_gauge_rows(float* dst, const float* src, const int* gid, int ng, int nt) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
@@ -202,7 +192,6 @@ struct smashx_plan {
     // tangent sweep (smashx_forward_d)
     bool tan_ready = false;
     float* d_qsim_d = nullptr;       // [ng][nt]
-    double* d_dot = nullptr;
     float* d_tanplane[SMASHX_GNP + SMASHX_GNS] = {nullptr};   // full planes of the (denormalised) direction, jreg only
     // regularisation (sx_jreg.h): planes 0..15 = parameters, 16..23 = states
     bool tiled = false;
@@ -1300,7 +1289,6 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
         if ((rc = p->dmalloc(&p->A.xdT, (size_t)std::max(p->sch.nxslots, 1) * p->Tc))) return rc;
         if ((rc = p->dmalloc(&p->A.qgd, (size_t)std::max(p->ngc, 1) * p->nt))) return rc;
         if ((rc = p->dmalloc(&p->d_qsim_d, (size_t)std::max(p->ng, 1) * p->nt))) return rc;
-        if ((rc = p->dmalloc(&p->d_dot, 2))) return rc;
         HIPCHK(hipMemset(p->A.xdT, 0, (size_t)std::max(p->sch.nxslots, 1) * p->Tc * 4));
         p->tan_ready = true;
     }
