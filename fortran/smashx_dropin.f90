@@ -94,6 +94,12 @@ module smashx_c
             type(smashx_options), intent(in) :: opt
             integer(c_int) :: rc
         end function
+        function smashx_abi_sizes(sizes) bind(C, name="smashx_abi_sizes") result(ver)
+            import
+            integer(c_int) :: sizes(7)
+            integer(c_int) :: ver
+        end function smashx_abi_sizes
+
         function smashx_set_domain_outputs(plan, qsim_domain, net_prcp_domain, sparse) &
         & bind(C, name="smashx_set_domain_outputs") result(rc)
             import
@@ -136,6 +142,7 @@ module smashx_c
 
     !  one cached plan (the reference calls forward/forward_b many times on the same setup/mesh/input_data)
     type(c_ptr), save :: sx_plan = c_null_ptr
+    logical, save :: sx_abi_checked = .false.
     type(c_ptr), save :: sx_key_forcing = c_null_ptr
     integer, save :: sx_key(6) = 0
 
@@ -226,6 +233,22 @@ subroutine smashx_prepare(setup, mesh, input_data)
     real(c_float), allocatable, target, save :: wg(:)
     type(c_ptr) :: fkey
     integer :: key(6), j
+    integer(c_int) :: abi(7), ver
+    type(smashx_parameters) :: abi_p
+    type(smashx_states) :: abi_s
+    type(smashx_costs) :: abi_c
+
+    !  the derived types above mirror include/smashx.h by hand: refuse to run against a library built from another layout
+    if (.not. sx_abi_checked) then
+        ver = smashx_abi_sizes(abi)
+        if (abi(1) .ne. int(c_sizeof(cfg)) .or. abi(2) .ne. int(c_sizeof(cm)) .or. abi(3) .ne. int(c_sizeof(opt)) .or. &
+        &   abi(4) .ne. int(c_sizeof(abi_p)) .or. abi(5) .ne. int(c_sizeof(abi_s)) .or. abi(6) .ne. int(c_sizeof(abi_c))) then
+            write (*, '(a,i0,a)') "smashx drop-in: libsmashx (ABI version ", ver, &
+            & ") does not match the struct layout this shim was compiled for -- rebuild fortran/smashx_dropin.f90"
+            error stop 1
+        end if
+        sx_abi_checked = .true.
+    end if
 
     if (setup%sparse_storage) then
         fkey = c_loc(input_data%sparse_prcp)

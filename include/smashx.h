@@ -113,6 +113,11 @@ typedef struct smashx_plan smashx_plan;
 
 const char* smashx_last_error(void);
 int smashx_device_count(void);
+/* ABI guard for bindings that mirror the structs by hand (the Fortran shim, ctypes): sizes in bytes of
+ * {smashx_config, smashx_mesh, smashx_options, smashx_parameters, smashx_states, smashx_costs, smashx_timing};
+ * returns SMASHX_ABI_VERSION. */
+#define SMASHX_ABI_VERSION 4
+int smashx_abi_sizes(int sizes[7]);
 
 /* builds the routing schedule from the mesh and allocates device storage */
 int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx_plan** out);

@@ -13,7 +13,7 @@ GNP, GNS = 16, 8
 E_OK, E_ARG, E_UNSUPPORTED, E_HIP, E_NODEVICE, E_MESH, E_STATE = 0, -1, -2, -3, -4, -5, -6
 
 SYMBOLS = [
-    "smashx_last_error", "smashx_device_count", "smashx_plan_create", "smashx_plan_destroy", "smashx_plan_ncells",
+    "smashx_last_error", "smashx_abi_sizes", "smashx_device_count", "smashx_plan_create", "smashx_plan_destroy", "smashx_plan_ncells",
     "smashx_plan_cell_order", "smashx_set_forcing", "smashx_set_forcing_device_block", "smashx_set_qobs",
     "smashx_set_options", "smashx_forward", "smashx_forward_b", "smashx_upload", "smashx_sweep", "smashx_download",
     "smashx_get_timing", "smashx_halo_counts", "smashx_halo_edges", "smashx_plan_chunking", "smashx_set_halo", "smashx_tile_probe", "smashx_debug_group_times", "smashx_set_domain_outputs", "smashx_forward_d", "smashx_selftest_math",

@@ -461,6 +461,15 @@ extern "C" {
 
 const char* smashx_last_error(void) { return g_err.c_str(); }
 
+int smashx_abi_sizes(int sizes[7]) {
+    if (sizes) {
+        sizes[0] = (int)sizeof(smashx_config); sizes[1] = (int)sizeof(smashx_mesh); sizes[2] = (int)sizeof(smashx_options);
+        sizes[3] = (int)sizeof(smashx_parameters); sizes[4] = (int)sizeof(smashx_states); sizes[5] = (int)sizeof(smashx_costs);
+        sizes[6] = (int)sizeof(smashx_timing);
+    }
+    return SMASHX_ABI_VERSION;
+}
+
 int smashx_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

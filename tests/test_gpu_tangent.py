@@ -50,3 +50,20 @@ def test_scalar_product(name):
     setup, mesh, inp, par, sta, out = _types(g)
     sp1, sp2 = smash_amd.scalar_product_test(setup, mesh, inp, par, sta, out)
     assert abs(sp1 - sp2) <= 2e-5 * abs(sp1), (sp1, sp2)
+
+
+def test_tangent_across_storage_chunks():
+    """The tangent sweep cut into storage chunks (state tangents and hlr_d carried from chunk to chunk) is bit-identical
+    to the single-chunk sweep."""
+    import smash_amd
+    from smash_amd.solver import Solver
+    g = gu.load("gr_c_32x32x240_d8_ragged")
+    pd, sd = mg.tangent_direction(g)
+    res = []
+    for chunk in (0, 32):
+        setup, mesh, inp, par, sta, out = _types(g, chunk_steps=chunk) if chunk else _types(g)
+        par_d, sta_d = smash_amd.ParametersDT.from_dict(mesh, pd), smash_amd.StatesDT.from_dict(mesh, sd)
+        out_d = smash_amd.OutputDT(setup, mesh)
+        _, cost_d = smash_amd.forward_d(setup, mesh, inp, par, par_d, inp._bgd[0], par.copy(), sta, sta_d, inp._bgd[1], sta.copy(), out, out_d)
+        res.append((cost_d, out_d.qsim.copy(), out.qsim.copy()))
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
