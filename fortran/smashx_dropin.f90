@@ -218,13 +218,15 @@ module smashx_glue
 
 contains
 
-subroutine smashx_prepare(setup, mesh, input_data)
+!  plain = .true. (the hyper entry points): no denormalisation, no regulariser -- base_hyper_forward ignores both
+subroutine smashx_prepare(setup, mesh, input_data, plain)
 
     implicit none
 
     type(SetupDT), intent(in), target :: setup
     type(MeshDT), intent(in), target :: mesh
     type(Input_DataDT), intent(in), target :: input_data
+    logical, intent(in), optional :: plain
 
     type(smashx_config) :: cfg
     type(smashx_mesh) :: cm
@@ -312,6 +314,12 @@ subroutine smashx_prepare(setup, mesh, input_data)
     wg = 0._c_float
     if (mesh%ng .gt. 0) wg(1:mesh%ng) = setup%optimize%wgauge
     opt%wgauge = c_loc(wg)
+    if (present(plain)) then
+        if (plain) then
+            opt%denormalize_forward = 0
+            opt%njr = 0
+        end if
+    end if
     call sx_check(smashx_set_options(sx_plan, opt), "set_options")
 
 end subroutine smashx_prepare
@@ -516,3 +524,129 @@ subroutine base_forward_d(setup, mesh, input_data, parameters, parameters_d, par
     output%cost_jreg = cc%cost_jreg
 
 end subroutine base_forward_d
+
+!  The hyper-linear / hyper-polynomial mappings (forward.f90:82-157, BASE_HYPER_FORWARD_B forward_db.f90:11231-11560): the
+!  descriptor -> parameter mapping and its adjoint are one pass over the parameter planes and stay the reference's own host
+!  code (mwd_parameters_manipulation, mwd_states_manipulation and their _DIFF twins); the time loop, the cost and their
+!  adjoints between them run on the GPU.  base_hyper_forward leaves states at their final values and ignores
+!  denormalize_forward and the regularisers (hyper_compute_cost: jreg = 0).
+subroutine base_hyper_forward(setup, mesh, input_data, parameters, hyper_parameters, hyper_parameters_bgd, &
+& states, hyper_states, hyper_states_bgd, output, cost)
+
+    use iso_c_binding
+    use md_constant
+    use mwd_setup
+    use mwd_mesh
+    use mwd_input_data
+    use mwd_parameters
+    use mwd_states
+    use mwd_output
+    use mwd_parameters_manipulation, only: hyper_parameters_to_parameters
+    use mwd_states_manipulation, only: hyper_states_to_states
+    use smashx_c
+    use smashx_glue
+
+    implicit none
+
+    type(SetupDT), intent(in), target :: setup
+    type(MeshDT), intent(in), target :: mesh
+    type(Input_DataDT), intent(inout), target :: input_data
+    type(ParametersDT), intent(inout), target :: parameters
+    type(Hyper_ParametersDT), intent(in) :: hyper_parameters, hyper_parameters_bgd
+    type(StatesDT), intent(inout), target :: states
+    type(Hyper_StatesDT), intent(in) :: hyper_states, hyper_states_bgd
+    type(OutputDT), intent(inout), target :: output
+    real(sp), intent(inout) :: cost
+
+    type(smashx_parameters) :: cp
+    type(smashx_states) :: cs, cf
+    type(smashx_costs) :: cc
+    type(c_ptr) :: qs
+
+    call hyper_parameters_to_parameters(hyper_parameters, parameters, setup, mesh, input_data)
+    call hyper_states_to_states(hyper_states, states, setup, mesh, input_data)
+    call smashx_prepare(setup, mesh, input_data, .true.)
+    call smashx_pack_parameters(parameters, cp)
+    call smashx_pack_states(states, cs)
+    call smashx_pack_states(output%fstates, cf)
+    qs = c_null_ptr
+    if (mesh%ng .gt. 0) qs = c_loc(output%qsim)
+    call sx_check(smashx_forward(sx_plan, cp, cp, cs, cs, qs, cc, cf), "hyper forward")
+    states = output%fstates                 !  forward.f90:150: fstates = states, no restore
+    cost = cc%cost
+    output%cost = cc%cost
+    output%cost_jobs = cc%cost_jobs
+
+end subroutine base_hyper_forward
+
+subroutine base_hyper_forward_b(setup, mesh, input_data, parameters, parameters_b, hyper_parameters, hyper_parameters_b, &
+& hyper_parameters_bgd, states, states_b, hyper_states, hyper_states_b, hyper_states_bgd, output, output_b, cost, cost_b)
+
+    use iso_c_binding
+    use md_constant
+    use mwd_setup
+    use mwd_mesh
+    use mwd_input_data
+    use mwd_parameters_diff
+    use mwd_states_diff
+    use mwd_output_diff
+    use mwd_parameters_manipulation_diff, only: hyper_parameters_to_parameters, hyper_parameters_to_parameters_b, &
+    & set_hyper_parameters
+    use mwd_states_manipulation_diff, only: hyper_states_to_states, hyper_states_to_states_b, set_hyper_states
+    use smashx_c
+    use smashx_glue, only: smashx_prepare, sx_plan, sx_check
+
+    implicit none
+
+    type(SetupDT), intent(in), target :: setup
+    type(MeshDT), intent(in), target :: mesh
+    type(Input_DataDT), intent(inout), target :: input_data
+    type(ParametersDT), intent(inout), target :: parameters, parameters_b
+    type(Hyper_ParametersDT), intent(in) :: hyper_parameters, hyper_parameters_bgd
+    type(Hyper_ParametersDT), intent(inout) :: hyper_parameters_b
+    type(StatesDT), intent(inout), target :: states, states_b
+    type(Hyper_StatesDT), intent(in) :: hyper_states, hyper_states_bgd
+    type(Hyper_StatesDT), intent(inout) :: hyper_states_b
+    type(OutputDT), intent(inout), target :: output
+    type(OutputDT), intent(inout) :: output_b
+    real(sp), intent(inout) :: cost, cost_b
+
+    type(smashx_parameters) :: cp, cpg
+    type(smashx_states) :: cs, csg
+    type(smashx_costs) :: cc
+    type(c_ptr) :: qs
+
+    call hyper_parameters_to_parameters(hyper_parameters, parameters, setup, mesh, input_data)
+    call hyper_states_to_states(hyper_states, states, setup, mesh, input_data)
+    call smashx_prepare(setup, mesh, input_data, .true.)
+    !  the _DIFF twins of the derived types have the layout of the originals: marshal by address
+    cp%f(1) = c_loc(parameters%ci); cp%f(2) = c_loc(parameters%cp); cp%f(3) = c_loc(parameters%beta)
+    cp%f(4) = c_loc(parameters%cft); cp%f(5) = c_loc(parameters%cst); cp%f(6) = c_loc(parameters%alpha)
+    cp%f(7) = c_loc(parameters%exc); cp%f(8) = c_loc(parameters%b); cp%f(9) = c_loc(parameters%cusl1)
+    cp%f(10) = c_loc(parameters%cusl2); cp%f(11) = c_loc(parameters%clsl); cp%f(12) = c_loc(parameters%ks)
+    cp%f(13) = c_loc(parameters%ds); cp%f(14) = c_loc(parameters%dsm); cp%f(15) = c_loc(parameters%ws)
+    cp%f(16) = c_loc(parameters%lr)
+    cpg%f(1) = c_loc(parameters_b%ci); cpg%f(2) = c_loc(parameters_b%cp); cpg%f(3) = c_loc(parameters_b%beta)
+    cpg%f(4) = c_loc(parameters_b%cft); cpg%f(5) = c_loc(parameters_b%cst); cpg%f(6) = c_loc(parameters_b%alpha)
+    cpg%f(7) = c_loc(parameters_b%exc); cpg%f(8) = c_loc(parameters_b%b); cpg%f(9) = c_loc(parameters_b%cusl1)
+    cpg%f(10) = c_loc(parameters_b%cusl2); cpg%f(11) = c_loc(parameters_b%clsl); cpg%f(12) = c_loc(parameters_b%ks)
+    cpg%f(13) = c_loc(parameters_b%ds); cpg%f(14) = c_loc(parameters_b%dsm); cpg%f(15) = c_loc(parameters_b%ws)
+    cpg%f(16) = c_loc(parameters_b%lr)
+    cs%f(1) = c_loc(states%hi); cs%f(2) = c_loc(states%hp); cs%f(3) = c_loc(states%hft); cs%f(4) = c_loc(states%hst)
+    cs%f(5) = c_loc(states%husl1); cs%f(6) = c_loc(states%husl2); cs%f(7) = c_loc(states%hlsl); cs%f(8) = c_loc(states%hlr)
+    csg%f(1) = c_loc(states_b%hi); csg%f(2) = c_loc(states_b%hp); csg%f(3) = c_loc(states_b%hft); csg%f(4) = c_loc(states_b%hst)
+    csg%f(5) = c_loc(states_b%husl1); csg%f(6) = c_loc(states_b%husl2); csg%f(7) = c_loc(states_b%hlsl)
+    csg%f(8) = c_loc(states_b%hlr)
+    qs = c_null_ptr
+    if (mesh%ng .gt. 0) qs = c_loc(output%qsim)
+    call sx_check(smashx_forward_b(sx_plan, cp, cp, cs, cs, cost_b, qs, cc, cpg, csg), "hyper forward_b")
+    cost = cc%cost
+    output%cost = cc%cost
+    output%cost_jobs = cc%cost_jobs
+    !  BASE_HYPER_FORWARD_B: hyper_*_b zeroed (forward_db.f90:11317-11318), then the adjoint of the two mappings (:11557-11560)
+    call set_hyper_parameters(setup, hyper_parameters_b, 0._sp)
+    call set_hyper_states(setup, hyper_states_b, 0._sp)
+    call hyper_states_to_states_b(hyper_states, hyper_states_b, states, states_b, setup, mesh, input_data)
+    call hyper_parameters_to_parameters_b(hyper_parameters, hyper_parameters_b, parameters, parameters_b, setup, mesh, input_data)
+
+end subroutine base_hyper_forward_b

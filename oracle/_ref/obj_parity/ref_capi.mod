@@ -1,4 +1,4 @@
-﻿!mod$ v1 sum:fff1b636aef91bde
+﻿!mod$ v1 sum:b4ff4a9a3b3e22fd
 !need$ 0bde2ac47243ead2 i iso_c_binding
 !need$ b74288d896965ed5 n mw_sparse_storage
 !need$ 5646c8d7b79c7ea8 n mw_optimize
@@ -16,6 +16,8 @@ module ref_capi
 use mw_forward,only:forward
 use mw_forward,only:forward_b
 use mw_forward,only:forward_d
+use mw_forward,only:hyper_forward
+use mw_forward,only:hyper_forward_b
 use mw_optimize,only:optimize_lbfgsb
 use,intrinsic::iso_c_binding,only:c_associated
 use,intrinsic::iso_c_binding,only:c_funloc
@@ -161,7 +163,7 @@ function jreg_name(code) result(s)
 integer(4),intent(in)::code
 character(20_4,1)::s
 end
-subroutine ref_core(icfg,rcfg,flwdir,flwacc,path,active_cell,gauge_pos,area,prcp,pet,qobs,params,params_bgd,states,states_bgd,wgauge,jobs_codes,wjobs,jreg_codes,wjreg_fun,optim_p,optim_s,lbp,ubp,lbs,ubs,qsim,costs,fstates,params_out,states_out,params_b,states_b,elapsed,params_d,states_d,params_bgd_d,states_bgd_d,qsim_d,cost_d_out)
+subroutine ref_core(icfg,rcfg,flwdir,flwacc,path,active_cell,gauge_pos,area,prcp,pet,qobs,params,params_bgd,states,states_bgd,wgauge,jobs_codes,wjobs,jreg_codes,wjreg_fun,optim_p,optim_s,lbp,ubp,lbs,ubs,qsim,costs,fstates,params_out,states_out,params_b,states_b,elapsed,params_d,states_d,params_bgd_d,states_bgd_d,qsim_d,cost_d_out,descriptor,hyper_p,hyper_s,hyper_p_b,hyper_s_b)
 integer(4),intent(in)::icfg(1_8:16_8)
 real(4),intent(in)::rcfg(1_8:4_8)
 integer(4),intent(in)::flwdir(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8))
@@ -202,6 +204,11 @@ real(4),intent(in),optional::params_bgd_d(1_8:int(icfg(2_8),kind=8),1_8:int(icfg
 real(4),intent(in),optional::states_bgd_d(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:8_8)
 real(4),intent(inout),optional::qsim_d(1_8:int(icfg(5_8),kind=8),1_8:int(icfg(4_8),kind=8))
 real(4),intent(inout),optional::cost_d_out
+real(4),intent(in),optional::descriptor(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:*)
+real(4),intent(in),optional::hyper_p(1_8:int(1_4+icfg(15_8)*icfg(14_8),kind=8),1_8:1_8,1_8:16_8)
+real(4),intent(in),optional::hyper_s(1_8:int(1_4+icfg(15_8)*icfg(14_8),kind=8),1_8:1_8,1_8:8_8)
+real(4),intent(inout),optional::hyper_p_b(1_8:int(1_4+icfg(15_8)*icfg(14_8),kind=8),1_8:1_8,1_8:16_8)
+real(4),intent(inout),optional::hyper_s_b(1_8:int(1_4+icfg(15_8)*icfg(14_8),kind=8),1_8:1_8,1_8:8_8)
 end
 subroutine ref_run(icfg,rcfg,flwdir,flwacc,path,active_cell,gauge_pos,area,prcp,pet,qobs,params,params_bgd,states,states_bgd,wgauge,jobs_codes,wjobs,jreg_codes,wjreg_fun,optim_p,optim_s,lbp,ubp,lbs,ubs,qsim,costs,fstates,params_out,states_out,params_b,states_b,elapsed) bind(c,name="ref_run")
 integer(4),intent(in)::icfg(1_8:16_8)
@@ -280,5 +287,46 @@ real(4),intent(in)::params_bgd_d(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kin
 real(4),intent(in)::states_bgd_d(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:8_8)
 real(4),intent(inout)::qsim_d(1_8:int(icfg(5_8),kind=8),1_8:int(icfg(4_8),kind=8))
 real(4),intent(inout)::cost_d
+end
+subroutine ref_run_hyper(icfg,rcfg,flwdir,flwacc,path,active_cell,gauge_pos,area,prcp,pet,qobs,params,params_bgd,states,states_bgd,wgauge,jobs_codes,wjobs,jreg_codes,wjreg_fun,optim_p,optim_s,lbp,ubp,lbs,ubs,qsim,costs,fstates,params_out,states_out,params_b,states_b,elapsed,descriptor,hyper_p,hyper_s,hyper_p_b,hyper_s_b) bind(c,name="ref_run_hyper")
+integer(4),intent(in)::icfg(1_8:16_8)
+real(4),intent(in)::rcfg(1_8:4_8)
+integer(4),intent(in)::flwdir(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8))
+integer(4),intent(in)::flwacc(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8))
+integer(4),intent(in)::path(1_8:2_8,1_8:int(icfg(2_8)*icfg(3_8),kind=8))
+integer(4),intent(in)::active_cell(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8))
+integer(4),intent(in)::gauge_pos(1_8:int(icfg(5_8),kind=8),1_8:2_8)
+real(4),intent(in)::area(1_8:int(icfg(5_8),kind=8))
+real(4),intent(in)::prcp(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:int(icfg(4_8),kind=8))
+real(4),intent(in)::pet(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:int(icfg(4_8),kind=8))
+real(4),intent(in)::qobs(1_8:int(icfg(5_8),kind=8),1_8:int(icfg(4_8),kind=8))
+real(4),intent(in)::params(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:16_8)
+real(4),intent(in)::params_bgd(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:16_8)
+real(4),intent(in)::states(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:8_8)
+real(4),intent(in)::states_bgd(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:8_8)
+real(4),intent(in)::wgauge(1_8:int(icfg(5_8),kind=8))
+integer(4),intent(in)::jobs_codes(1_8:*)
+real(4),intent(in)::wjobs(1_8:*)
+integer(4),intent(in)::jreg_codes(1_8:*)
+real(4),intent(in)::wjreg_fun(1_8:*)
+integer(4),intent(in)::optim_p(1_8:16_8)
+integer(4),intent(in)::optim_s(1_8:8_8)
+real(4),intent(in)::lbp(1_8:16_8)
+real(4),intent(in)::ubp(1_8:16_8)
+real(4),intent(in)::lbs(1_8:8_8)
+real(4),intent(in)::ubs(1_8:8_8)
+real(4),intent(inout)::qsim(1_8:int(icfg(5_8),kind=8),1_8:int(icfg(4_8),kind=8))
+real(4),intent(inout)::costs(1_8:3_8)
+real(4),intent(inout)::fstates(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:8_8)
+real(4),intent(inout)::params_out(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:16_8)
+real(4),intent(inout)::states_out(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:8_8)
+real(4),intent(inout)::params_b(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:16_8)
+real(4),intent(inout)::states_b(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:8_8)
+real(8),intent(inout)::elapsed
+real(4),intent(in)::descriptor(1_8:int(icfg(2_8),kind=8),1_8:int(icfg(3_8),kind=8),1_8:*)
+real(4),intent(in)::hyper_p(1_8:int(1_4+icfg(15_8)*icfg(14_8),kind=8),1_8:1_8,1_8:16_8)
+real(4),intent(in)::hyper_s(1_8:int(1_4+icfg(15_8)*icfg(14_8),kind=8),1_8:1_8,1_8:8_8)
+real(4),intent(inout)::hyper_p_b(1_8:int(1_4+icfg(15_8)*icfg(14_8),kind=8),1_8:1_8,1_8:16_8)
+real(4),intent(inout)::hyper_s_b(1_8:int(1_4+icfg(15_8)*icfg(14_8),kind=8),1_8:1_8,1_8:8_8)
 end
 end

@@ -22,7 +22,7 @@ module ref_capi
     use mwd_parameters_manipulation
     use mwd_states_manipulation
     use mw_sparse_storage
-    use mw_forward, only: forward, forward_b, forward_d
+    use mw_forward, only: forward, forward_b, forward_d, hyper_forward, hyper_forward_b
     use mw_optimize, only: optimize_lbfgsb
 
     implicit none
@@ -60,6 +60,8 @@ contains
     !  icfg(8)  optimize_start_step (1-based) icfg(9)  njf      icfg(10) njr
     !  icfg(11) mode: 0 = forward, 1 = forward_b, 2 = optimize_lbfgsb (mw_optimize.f90:484-676),
     !           3 = forward_d (tangent model, mw_forward.f90:70-97; entry point ref_run_d only)
+    !           4 = hyper_forward, 5 = hyper_forward_b (mw_forward.f90:99-152; entry point ref_run_hyper only)
+    !  icfg(14) nd (descriptors)   icfg(15) mapping: 1 hyper-linear, 2 hyper-polynomial
     !  icfg(12) nrep (timing repetitions, >=1)     icfg(13) maxiter (mode 2)
     !  rcfg(1) dt  rcfg(2) dx  rcfg(3) wjreg  rcfg(4) cost_b
     !  Arrays are column-major exactly as the reference holds them; path and gauge_pos are 1-based.
@@ -69,7 +71,8 @@ contains
     & prcp, pet, qobs, params, params_bgd, states, states_bgd, &
     & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
     & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed, &
-    & params_d, states_d, params_bgd_d, states_bgd_d, qsim_d, cost_d_out)
+    & params_d, states_d, params_bgd_d, states_bgd_d, qsim_d, cost_d_out, &
+    & descriptor, hyper_p, hyper_s, hyper_p_b, hyper_s_b)
 
         integer(c_int), intent(in) :: icfg(16)
         real(c_float), intent(in) :: rcfg(4)
@@ -98,7 +101,12 @@ contains
         real(c_float), intent(in), optional :: params_bgd_d(icfg(2), icfg(3), GNP), states_bgd_d(icfg(2), icfg(3), GNS)
         real(c_float), intent(inout), optional :: qsim_d(icfg(5), icfg(4))
         real(c_float), intent(inout), optional :: cost_d_out
+        real(c_float), intent(in), optional :: descriptor(icfg(2), icfg(3), *)
+        real(c_float), intent(in), optional :: hyper_p(1 + icfg(15)*icfg(14), 1, GNP), hyper_s(1 + icfg(15)*icfg(14), 1, GNS)
+        real(c_float), intent(inout), optional :: hyper_p_b(1 + icfg(15)*icfg(14), 1, GNP), hyper_s_b(1 + icfg(15)*icfg(14), 1, GNS)
 
+        type(Hyper_ParametersDT) :: hp, hp_b, hp_bgd
+        type(Hyper_StatesDT) :: hs, hs_b, hs_bgd
         type(ParametersDT) :: p_d
         type(StatesDT) :: s_d
         type(OutputDT) :: output_d
@@ -126,7 +134,14 @@ contains
         setup%dt = rcfg(1)
         setup%sparse_storage = (icfg(6) .ne. 0)
         setup%ntime_step = nt
-        call SetupDT_initialise(setup, 0, ng)
+        call SetupDT_initialise(setup, icfg(14), ng)
+        if (icfg(15) .eq. 1) then
+            deallocate (setup%optimize%wgauge)
+            call Optimize_SetupDT_initialise(setup%optimize, nt, icfg(14), ng, "hyper-linear", 0, 0)
+        else if (icfg(15) .eq. 2) then
+            deallocate (setup%optimize%wgauge)
+            call Optimize_SetupDT_initialise(setup%optimize, nt, icfg(14), ng, "hyper-polynomial", 0, 0)
+        end if
 
         call MeshDT_initialise(mesh, setup, nrow, ncol, ng)
         mesh%dx = rcfg(2)
@@ -153,6 +168,7 @@ contains
             input_data%pet = pet
         end if
 
+        if (icfg(14) .gt. 0 .and. present(descriptor)) input_data%descriptor = descriptor(:, :, 1:icfg(14))
         call ParametersDT_initialise(p, mesh)
         call ParametersDT_initialise(p_b, mesh)
         call ParametersDT_initialise(p_bgd, mesh)
@@ -202,6 +218,25 @@ contains
             call system_clock(c0, crate)
             if (icfg(11) .eq. 0) then
                 call forward(setup, mesh, input_data, p, p_bgd, s, s_bgd, output, cost)
+            else if (icfg(11) .eq. 4 .or. icfg(11) .eq. 5) then
+                call Hyper_ParametersDT_initialise(hp, setup)
+                call Hyper_ParametersDT_initialise(hp_b, setup)
+                call Hyper_ParametersDT_initialise(hp_bgd, setup)
+                call Hyper_StatesDT_initialise(hs, setup)
+                call Hyper_StatesDT_initialise(hs_b, setup)
+                call Hyper_StatesDT_initialise(hs_bgd, setup)
+                call set_hyper_parameters(setup, hp, hyper_p)
+                call set_hyper_parameters(setup, hp_bgd, hyper_p)
+                call set_hyper_states(setup, hs, hyper_s)
+                call set_hyper_states(setup, hs_bgd, hyper_s)
+                if (icfg(11) .eq. 4) then
+                    call hyper_forward(setup, mesh, input_data, p, hp, hp_bgd, s, hs, hs_bgd, output, cost)
+                else
+                    call hyper_forward_b(setup, mesh, input_data, p, p_b, hp, hp_b, hp_bgd, s, s_b, hs, hs_b, hs_bgd, &
+                    & output, output_b, cost, cost_b)
+                    call get_hyper_parameters(setup, hp_b, hyper_p_b)
+                    call get_hyper_states(setup, hs_b, hyper_s_b)
+                end if
             else if (icfg(11) .eq. 3) then
                 !  tangent model: p_b / s_b objects double as the (scratch) background tangents
                 call ParametersDT_initialise(p_d, mesh)
@@ -318,5 +353,44 @@ contains
         & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed, &
         & params_d, states_d, params_bgd_d, states_bgd_d, qsim_d, cost_d)
     end subroutine ref_run_d
+
+    !  icfg(11) = 4 / 5: mw_forward::hyper_forward / hyper_forward_b (descriptor -> parameter mappings)
+    subroutine ref_run_hyper(icfg, rcfg, flwdir, flwacc, path, active_cell, gauge_pos, area, &
+    & prcp, pet, qobs, params, params_bgd, states, states_bgd, &
+    & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
+    & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed, &
+    & descriptor, hyper_p, hyper_s, hyper_p_b, hyper_s_b) bind(C, name="ref_run_hyper")
+        integer(c_int), intent(in) :: icfg(16)
+        real(c_float), intent(in) :: rcfg(4)
+        integer(c_int), intent(in) :: flwdir(icfg(2), icfg(3)), flwacc(icfg(2), icfg(3))
+        integer(c_int), intent(in) :: path(2, icfg(2)*icfg(3)), active_cell(icfg(2), icfg(3))
+        integer(c_int), intent(in) :: gauge_pos(icfg(5), 2)
+        real(c_float), intent(in) :: area(icfg(5))
+        real(c_float), intent(in) :: prcp(icfg(2), icfg(3), icfg(4)), pet(icfg(2), icfg(3), icfg(4))
+        real(c_float), intent(in) :: qobs(icfg(5), icfg(4))
+        real(c_float), intent(in) :: params(icfg(2), icfg(3), GNP), params_bgd(icfg(2), icfg(3), GNP)
+        real(c_float), intent(in) :: states(icfg(2), icfg(3), GNS), states_bgd(icfg(2), icfg(3), GNS)
+        real(c_float), intent(in) :: wgauge(icfg(5))
+        integer(c_int), intent(in) :: jobs_codes(*)
+        real(c_float), intent(in) :: wjobs(*)
+        integer(c_int), intent(in) :: jreg_codes(*)
+        real(c_float), intent(in) :: wjreg_fun(*)
+        integer(c_int), intent(in) :: optim_p(GNP), optim_s(GNS)
+        real(c_float), intent(in) :: lbp(GNP), ubp(GNP), lbs(GNS), ubs(GNS)
+        real(c_float), intent(inout) :: qsim(icfg(5), icfg(4))
+        real(c_float), intent(inout) :: costs(3)
+        real(c_float), intent(inout) :: fstates(icfg(2), icfg(3), GNS)
+        real(c_float), intent(inout) :: params_out(icfg(2), icfg(3), GNP), states_out(icfg(2), icfg(3), GNS)
+        real(c_float), intent(inout) :: params_b(icfg(2), icfg(3), GNP), states_b(icfg(2), icfg(3), GNS)
+        real(c_double), intent(inout) :: elapsed
+        real(c_float), intent(in) :: descriptor(icfg(2), icfg(3), *)
+        real(c_float), intent(in) :: hyper_p(1 + icfg(15)*icfg(14), 1, GNP), hyper_s(1 + icfg(15)*icfg(14), 1, GNS)
+        real(c_float), intent(inout) :: hyper_p_b(1 + icfg(15)*icfg(14), 1, GNP), hyper_s_b(1 + icfg(15)*icfg(14), 1, GNS)
+        call ref_core(icfg, rcfg, flwdir, flwacc, path, active_cell, gauge_pos, area, &
+        & prcp, pet, qobs, params, params_bgd, states, states_bgd, &
+        & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
+        & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed, &
+        & descriptor=descriptor, hyper_p=hyper_p, hyper_s=hyper_s, hyper_p_b=hyper_p_b, hyper_s_b=hyper_s_b)
+    end subroutine ref_run_hyper
 
 end module ref_capi

@@ -68,23 +68,34 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         jobs_fun=("nse",), wjobs_fun=(1.0,), jreg_fun=(), wjreg_fun=(), wjreg=0.0, wgauge=None,
         optim_parameters=None, optim_states=None, lb_parameters=None, ub_parameters=None,
         lb_states=None, ub_states=None, cost_b=1.0, nrep=1, fast=False, optimize_maxiter=None,
-        params_d=None, states_d=None, params_bgd_d=None, states_bgd_d=None):
+        params_d=None, states_d=None, params_bgd_d=None, states_bgd_d=None,
+        descriptor=None, hyper_params=None, hyper_states=None, mapping=None):
     """Call the reference forward / forward_b (mw_forward.f90:18-68) on flat arrays.
 
     mesh: object with nrow, ncol, dx, flwdir, flwacc, path (0-based), active_cell, gauge_pos (0-based),
     area.  params/states: dict name -> (nrow, ncol) float32.  Returns a dict of outputs.
     params_d / states_d (dicts): run the tangent model forward_d (mw_forward.f90:70-97) along that direction
-    instead; the result also holds cost_d and qsim_d."""
+    instead; the result also holds cost_d and qsim_d.
+    mapping ("hyper-linear" | "hyper-polynomial") with descriptor (nrow, ncol, nd), hyper_params / hyper_states
+    (dict name -> (nhyper,)): mw_forward::hyper_forward / hyper_forward_b (mw_forward.f90:99-152); the result also holds
+    hyper_parameters_b / hyper_states_b."""
     from smash_amd.synth import PARAM_NAMES, STATE_NAMES
     lib = _lib(fast)
     nrow, ncol, ng = mesh.nrow, mesh.ncol, mesh.ng
     nt = prcp.shape[2]
     jobs_fun, jreg_fun = list(jobs_fun), list(jreg_fun)
     tangent = params_d is not None or states_d is not None
+    hyper = mapping is not None
     mode = 3 if tangent else (2 if optimize_maxiter is not None else int(adjoint))
+    nd = mcode = 0
+    if hyper:
+        mode = 5 if adjoint else 4
+        descriptor = np.asfortranarray(descriptor, dtype=np.float32)
+        nd = descriptor.shape[2]
+        mcode = {"hyper-linear": 1, "hyper-polynomial": 2}[mapping]
     icfg = np.array([STRUCTURES[structure], nrow, ncol, nt, ng, int(sparse_storage),
                      int(denormalize_forward), optimize_start_step, len(jobs_fun), len(jreg_fun),
-                     mode, nrep, optimize_maxiter or 0, 0, 0, 0], dtype=np.int32)
+                     mode, nrep, optimize_maxiter or 0, nd, mcode, 0], dtype=np.int32)
     rcfg = np.array([dt, mesh.dx, wjreg, cost_b], dtype=np.float32)
     P = pack(params, PARAM_NAMES, nrow, ncol)
     S = pack(states, STATE_NAMES, nrow, ncol)
@@ -124,11 +135,21 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         qsim_d = np.zeros((max(ng, 1), nt), np.float32, order="F")
         cost_d = C.c_float(0.0)
         cargs += [_ptr(P_d), _ptr(S_d), _ptr(Pb_d), _ptr(Sb_d), _ptr(qsim_d), C.byref(cost_d)]
+    if hyper:
+        nh = 1 + mcode * nd
+        HP = np.zeros((nh, 1, GNP), np.float32, order="F")
+        HS = np.zeros((nh, 1, GNS), np.float32, order="F")
+        for i, k in enumerate(PARAM_NAMES):
+            HP[:, 0, i] = hyper_params[k]
+        for i, k in enumerate(STATE_NAMES):
+            HS[:, 0, i] = hyper_states[k]
+        HP_b, HS_b = np.zeros_like(HP, order="F"), np.zeros_like(HS, order="F")
+        cargs += [_ptr(descriptor), _ptr(HP), _ptr(HS), _ptr(HP_b), _ptr(HS_b)]
     err = []
 
     def call():
         try:
-            (lib.ref_run_d if tangent else lib.ref_run)(*cargs)
+            (lib.ref_run_hyper if hyper else lib.ref_run_d if tangent else lib.ref_run)(*cargs)
         except Exception as e:  # pragma: no cover
             err.append(e)
 
@@ -144,4 +165,6 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
                 fstates=unpack(fstates, STATE_NAMES), parameters=unpack(pout, PARAM_NAMES),
                 states=unpack(sout, STATE_NAMES), parameters_b=unpack(p_b, PARAM_NAMES),
                 states_b=unpack(s_b, STATE_NAMES), elapsed=elapsed.value,
-                cost_d=float(cost_d.value) if tangent else None, qsim_d=qsim_d[:ng] if tangent else None)
+                cost_d=float(cost_d.value) if tangent else None, qsim_d=qsim_d[:ng] if tangent else None,
+                hyper_parameters_b={k: HP_b[:, 0, i].copy() for i, k in enumerate(PARAM_NAMES)} if hyper else None,
+                hyper_states_b={k: HS_b[:, 0, i].copy() for i, k in enumerate(STATE_NAMES)} if hyper else None)

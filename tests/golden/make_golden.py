@@ -188,6 +188,58 @@ def main_tangent():
         print(f"tangent {name}: cost_d={r['cost_d']:.8g} noise={abs(r3['cost_d'] - r['cost_d']) / abs(r['cost_d']):.2g}")
 
 
+def hyper_inputs(g, mapping):
+    """Two smooth descriptors and hyper-parameter vectors whose mapped fields sit near the case's own parameters:
+    intercept = logit of the normalised field mean, small descriptor coefficients (and exponents for the polynomial map)."""
+    r = np.arange(g.mesh.nrow)[:, None] / g.mesh.nrow
+    c = np.arange(g.mesh.ncol)[None, :] / g.mesh.ncol
+    desc = np.asfortranarray(np.stack([0.2 + r + 0 * c, 0.5 + 0.5 * np.sin(3 * c) + 0 * r], axis=2).astype(np.float32))
+    nh = 3 if mapping == "hyper-linear" else 5
+
+    def mk(vals, lb, ub, names):
+        out = {}
+        for i, k in enumerate(names):
+            t = float(np.mean(vals[k]))
+            tt = min(max((t - lb[i]) / (ub[i] - lb[i]), 1e-4), 1 - 1e-4)
+            h = np.zeros(nh, np.float32)
+            h[0] = np.log(tt / (1 - tt))
+            h[1:] = [0.05, -0.03] if mapping == "hyper-linear" else [0.05, 1.2, -0.03, 0.8]
+            out[k] = h
+        return out
+    return desc, mk(g.params, GLB_P, GUB_P, synth.PARAM_NAMES), mk(g.states, GLB_S, GUB_S, synth.STATE_NAMES)
+
+
+HYPER_CASES = [("gr_b_16x16x96_nse_gaps", "hyper-linear"), ("gr_c_32x32x240_d8_ragged", "hyper-polynomial"),
+               ("vic_a_16x16x96_nse_gaps", "hyper-polynomial")]
+
+
+def main_hyper():
+    """mw_forward::hyper_forward / hyper_forward_b of the reference (mw_forward.f90:99-152) on hyper_inputs()."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import golden_util as gu
+    os.makedirs(os.path.join(OUT, "hyper"), exist_ok=True)
+    for name, mapping in HYPER_CASES:
+        g = gu.load(name)
+        desc, hp, hs = hyper_inputs(g, mapping)
+        kw = dict(descriptor=desc, hyper_params=hp, hyper_states=hs, mapping=mapping,
+                  **{k: v for k, v in g.opts.items() if k in ("jobs_fun", "wjobs_fun", "optimize_start_step", "wgauge")})
+        run = lambda **o: refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, **kw, **o)
+        f, b, f3, b3 = run(), run(adjoint=True), run(fast=True), run(adjoint=True, fast=True)
+        d = dict(mapping=mapping, fwd_qsim=f["qsim"], fwd_cost=np.float32(f["cost"]), adj_cost=np.float32(b["cost"]),
+                 noise_qsim=np.array([rel_l2(f3["qsim"][i], f["qsim"][i]) for i in range(g.mesh.ng)]),
+                 noise_cost=np.float64(abs(f3["cost"] - f["cost"]) / abs(f["cost"])))
+        for k in synth.PARAM_NAMES:
+            d["fwd_p_" + k] = f["parameters"][k]
+            d["adj_hp_b_" + k] = b["hyper_parameters_b"][k]
+            d["noise_hp_b_" + k] = np.float64(rel_l2(b3["hyper_parameters_b"][k], b["hyper_parameters_b"][k]))
+        for k in synth.STATE_NAMES:
+            d["fwd_s_" + k] = f["states"][k]
+            d["adj_hs_b_" + k] = b["hyper_states_b"][k]
+            d["noise_hs_b_" + k] = np.float64(rel_l2(b3["hyper_states_b"][k], b["hyper_states_b"][k]))
+        np.savez_compressed(os.path.join(OUT, "hyper", f"{name}__{mapping}.npz"), **d)
+        print(f"hyper {name} {mapping}: cost={f['cost']:.8g} |cp hyper_b|={np.abs(b['hyper_parameters_b']['cp']).max():.3g}")
+
+
 def main_lbfgsb():
     """Row f1: the reference's own optimize_lbfgsb (mw_optimize.f90:484-676) on the gr-b 24x24x120 case,
     distributed mapping over cp, cft, exc, lr: cost after 0..4 iterations and the final parameter fields."""
@@ -220,3 +272,4 @@ if __name__ == "__main__":
         os.makedirs(os.path.join(OUT, "lbfgsb"), exist_ok=True)
         main_lbfgsb()
         main_tangent()
+        main_hyper()

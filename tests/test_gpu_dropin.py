@@ -81,3 +81,39 @@ def test_reference_forward_d_through_dropin(name):
         assert gu.rel_l2(r["qsim_d"][i], z["qsim_d"][i]) <= gu.tol(z["noise_qsim_d"][i]), i
     ref = float(z["cost_d"])
     assert abs(r["cost_d"] - ref) <= 1e-5 * abs(ref), (r["cost_d"], ref)
+
+
+def _hyper_cases():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+    return mg.HYPER_CASES
+
+
+@pytest.mark.parametrize("name,mapping", _hyper_cases())
+def test_reference_hyper_forward_through_dropin(name, mapping):
+    """mw_forward::hyper_forward / hyper_forward_b (mw_forward.f90:99-152): the descriptor -> parameter mapping and its
+    adjoint stay the reference's host code, the time loop, cost and their adjoints run on the GPU (base_hyper_forward /
+    base_hyper_forward_b in fortran/smashx_dropin.f90); against the golden vectors of the all-CPU reference."""
+    import make_golden as mg
+    from smash_amd import synth
+    g = gu.load(name)
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "hyper", f"{name}__{mapping}.npz"))
+    desc, hp, hs = mg.hyper_inputs(g, mapping)
+    kw = dict(descriptor=desc, hyper_params=hp, hyper_states=hs, mapping=mapping, fast="dropin",
+              **{k: v for k, v in g.opts.items() if k in ("jobs_fun", "wjobs_fun", "optimize_start_step", "wgauge")})
+    f = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, **kw)
+    b = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, adjoint=True, **kw)
+    for i in range(g.mesh.ng):
+        assert gu.rel_l2(f["qsim"][i], z["fwd_qsim"][i]) <= gu.tol(z["noise_qsim"][i]), i
+    assert abs(f["cost"] - float(z["fwd_cost"])) <= gu.tol_cost(float(z["noise_cost"]), float(z["fwd_cost"]))
+    assert abs(b["cost"] - float(z["adj_cost"])) <= gu.tol_cost(float(z["noise_cost"]), float(z["adj_cost"]))
+    for k in synth.PARAM_NAMES:          # the mapped fields come from the reference's own host code: identical
+        assert np.array_equal(f["parameters"][k], z["fwd_p_" + k]), k
+    for k in gu.STRUCT_STATES[g.structure]:   # base_hyper_forward leaves the states at their final values
+        assert gu.rel_l2(f["states"][k], z["fwd_s_" + k]) <= gu.tol_fstate(k, 1e-5), k
+    for k in gu.STRUCT_PARAMS[g.structure]:
+        assert gu.rel_l2(b["hyper_parameters_b"][k], z["adj_hp_b_" + k]) <= gu.tol(float(z["noise_hp_b_" + k]), base=5e-6), k
+    for k in gu.STRUCT_STATES[g.structure]:
+        assert gu.rel_l2(b["hyper_states_b"][k], z["adj_hs_b_" + k]) <= gu.tol(float(z["noise_hs_b_" + k]), base=5e-6), k
