@@ -8,3 +8,4 @@ from .solver import Solver, forward, forward_b, forward_d, scalar_product_test  
 from .types import (Input_DataDT, MeshDT, Optimize_SetupDT, OutputDT, ParametersDT, SetupDT,  # noqa: F401
                     StatesDT)
 from ._lib import SmashxError  # noqa: F401
+from .optimize import optimize_lbfgsb  # noqa: F401

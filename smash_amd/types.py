@@ -36,6 +36,7 @@ class Optimize_SetupDT:
         self.wjreg_fun = []
         self.denormalize_forward = False
         self.optimize_start_step = 1  # 1-based like the Fortran field
+        self.maxiter = 100
         self.optim_parameters = np.zeros(16, np.int32)
         self.optim_states = np.zeros(8, np.int32)
         self.lb_parameters = GLB_PARAMETERS.copy()

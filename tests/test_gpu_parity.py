@@ -235,3 +235,27 @@ def test_domain_outputs(name, sparse):
             assert np.array_equal(qd[g.mesh.gauge_pos[i, 0], g.mesh.gauge_pos[i, 1], :], out.qsim[i])
     # net rainfall of the data-gap steps is a difference of nearly equal powers (md_gr_operator.f90:94-96): 2e-6 there
     assert gu.rel_l2(qd, rq) <= 1e-6 and gu.rel_l2(pd, rp) <= 5e-6, (gu.rel_l2(qd, rq), gu.rel_l2(pd, rp))
+
+
+def test_optimize_lbfgsb_python_host():
+    """smash_amd.optimize_lbfgsb (host mirror of mw_optimize::optimize_lbfgsb over GPU sweeps) against the reference's own
+    trajectory (tests/golden/lbfgsb, all-CPU): iteration-0 cost identical, same decrease after 4 iterations.  With the CPU
+    oracle as the gradient provider this loop reproduces the reference's costs bit for bit (test_oracle_golden.py)."""
+    import os
+    import smash_amd
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "opt_gr_b_24x24x120.npz"))
+    g = gu.load("gr_b_24x24x120_norm_jreg")
+    g.opts = dict(jobs_fun=("nse",), wjobs_fun=(1.0,))
+    g.params, g.states, g.qobs = synth.make_parameters(24, 24), synth.make_states(24, 24, warm=True), z["qobs"]
+    costs = []
+    for it in (1, 4):
+        setup, mesh, inp, par, sta, out = _types(g)
+        setup.optimize.optim_parameters = np.asarray(z["optim_parameters"], np.int32)
+        setup.optimize.maxiter = it
+        h = smash_amd.optimize_lbfgsb(setup, mesh, inp, par, sta, out)
+        costs.append(h["final_cost"])
+        assert len(h["cost"]) == it
+    ref = z["costs"]
+    assert abs(costs[0] - ref[1]) <= 3e-7 + 1e-5 * abs(ref[1]), (costs, ref)
+    assert abs(costs[1] - ref[4]) <= 0.02 * abs(ref[0]), (costs, ref)
+    assert np.all(par.cp > 1.0)          # calibrated fields come back denormalised

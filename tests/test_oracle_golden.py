@@ -67,3 +67,41 @@ def test_tangent_oracle_is_bit_identical_to_reference_forward_d():
         r = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, params_d=pd, states_d=sd, **g.opts)
         assert np.float32(r["cost_d"]) == z["cost_d"], name
         assert np.array_equal(r["qsim_d"], z["qsim_d"]), name
+
+
+def test_python_lbfgsb_loop_reproduces_reference_trajectory():
+    """The host loop of smash_amd.optimize_lbfgsb (scipy's L-BFGS-B, the reference's control-vector order and settings),
+    fed by the CPU oracle instead of the GPU: the cost after 1..4 iterations equals the reference's own
+    optimize_lbfgsb bit for bit (tests/golden/lbfgsb)."""
+    import os
+    from scipy.optimize import fmin_l_bfgs_b
+    from oracle import pyoracle
+    from oracle.refbind import GLB_P, GLB_S, GUB_P, GUB_S
+    from smash_amd import synth
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "opt_gr_b_24x24x120.npz"))
+    g = gu.load("gr_b_24x24x120_norm_jreg")
+    mesh, op = g.mesh, z["optim_parameters"]
+    nrm = lambda d, lb, ub, names: {k: np.asfortranarray(((d[k] - lb[i]) / (ub[i] - lb[i])).astype(np.float32)) for i, k in enumerate(names)}
+    Pn = nrm(synth.make_parameters(24, 24), GLB_P, GUB_P, synth.PARAM_NAMES)
+    Sn = nrm(synth.make_states(24, 24, warm=True), GLB_S, GUB_S, synth.STATE_NAMES)
+    fields = [k for i, k in enumerate(synth.PARAM_NAMES) if op[i] > 0]
+    cr = np.argwhere((mesh.active_cell == 1).T)
+    cols, rows = cr[:, 0], cr[:, 1]
+    m = len(rows)
+    kw = dict(params_bgd=Pn, states_bgd=Sn, denormalize_forward=True, optim_parameters=op, jobs_fun=("nse",), wjobs_fun=(1.0,))
+
+    def unpack(x):
+        out = {k: v.copy() for k, v in Pn.items()}
+        for j, k in enumerate(fields):
+            out[k][rows, cols] = x[j * m:(j + 1) * m].astype(np.float32)
+        return out
+
+    def fg(x):
+        r = pyoracle.run("gr-b", mesh, g.dt, g.prcp, g.pet, z["qobs"], unpack(x), Sn, adjoint=True, **kw)
+        return float(np.float32(r["cost"])), np.concatenate([r["parameters_b"][k][rows, cols].astype(np.float64) for k in fields])
+
+    x0 = np.concatenate([Pn[k][rows, cols].astype(np.float64) for k in fields])
+    for it in (1, 3):
+        x, f, d = fmin_l_bfgs_b(fg, x0, m=10, factr=10.0, pgtol=1e-12, bounds=[(0.0, 1.0)] * len(x0), maxiter=it, maxfun=100)
+        r = pyoracle.run("gr-b", mesh, g.dt, g.prcp, g.pet, z["qobs"], unpack(x), Sn, **kw)
+        assert np.float32(r["cost"]) == z["costs"][it], (it, r["cost"], z["costs"][it])
