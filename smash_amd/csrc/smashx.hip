@@ -893,7 +893,10 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
             }
             return 0;
         };
-        if ((rc = launch_v(0))) return rc;
+        // every vertical sub-chunk is queued at once: they only depend on each other (state carry, stream order) and write
+        // disjoint parts of the chunk buffers, so the V stream never waits for the host, which blocks in the halo hooks
+        // of the routing pipeline below (tiles) -- the vertical work then hides the pipeline fill across tiles
+        for (int jb = 0; jb < ns; ++jb) if ((rc = launch_v(jb))) return rc;
         for (int jb = 0; jb < ns; ++jb) {
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
             if (halo && p->n_in > 0) {
@@ -902,9 +905,6 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
             }
             HIPCHK(hipStreamWaitEvent(sR, ev[jb], 0));
             route_fwd(p, off, tape, t0c + off, T, ev_rest[jb]);
-            if (jb + 1 < ns) {                                     // keep the V stream busy while we wait on the R stream
-                if ((rc = launch_v(jb + 1))) return rc;
-            }
             if (halo && p->n_out > 0) {
                 halo_move(true, true, off, T);
                 HIPCHK(hipStreamSynchronize(sR));
