@@ -53,13 +53,17 @@ SX_DEV SxProd sx_production_full(float pn, float en, float cp, float inv_cp, flo
     if (en > 0.f) R.es = sx_fdiv((hp * cp) * (2.f - hp) * R.the, 1.f + (1.f - hp) * R.the);
     R.hp_imd = hp + (R.ps - R.es) * inv_cp;
     if (pn > 0.f) R.pr = pn - (R.hp_imd - hp) * cp;
-    const float r = sx_div(R.hp_imd, dbeta);
-    const float r2 = r * r;
-    const float pwx1 = 1.f + r2 * r2;
+    // |hp_imd| < 15  =>  (hp_imd / 1000)^4 < 2^-24  =>  1 + r^4 rounds to exactly 1 (beta = 1000): the usual case needs
+    // neither the division nor the power
     R.pwr1 = 1.f; R.pw125 = 1.f;
-    if (pwx1 != 1.f) {
-        if (ADJ) sx_pow_m025_m125(pwx1, &R.pwr1, &R.pw125);
-        else R.pwr1 = sx_pow_m025(pwx1);
+    if (!(fabsf(R.hp_imd) < 15.f)) {
+        const float r = sx_div(R.hp_imd, dbeta);
+        const float r2 = r * r;
+        const float pwx1 = 1.f + r2 * r2;
+        if (pwx1 != 1.f) {
+            if (ADJ) sx_pow_m025_m125(pwx1, &R.pwr1, &R.pw125);
+            else R.pwr1 = sx_pow_m025(pwx1);
+        }
     }
     R.perc = (R.hp_imd * cp) * (1.f - R.pwr1);
     R.hp_new = R.hp_imd - R.perc * inv_cp;
