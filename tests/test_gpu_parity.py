@@ -259,3 +259,50 @@ def test_optimize_lbfgsb_python_host():
     assert abs(costs[0] - ref[1]) <= 3e-7 + 1e-5 * abs(ref[1]), (costs, ref)
     assert abs(costs[1] - ref[4]) <= 0.02 * abs(ref[0]), (costs, ref)
     assert np.all(par.cp > 1.0)          # calibrated fields come back denormalised
+
+
+@pytest.mark.parametrize("case", ["nt5", "thin", "allgap", "one_cell", "no_gauge"])
+def test_edge_cases_vs_oracle(case):
+    """Ragged sizes the kernels' blocking must survive (steps not a multiple of 4, a 1-row grid, a single active cell),
+    forcing that is one long data gap, and a plan without gauges: forward and adjoint against the oracle."""
+    import smash_amd
+    from oracle import pyoracle
+    nrow, ncol, nt, ng = 9, 11, 23, 2
+    if case == "nt5":
+        nt = 5
+    if case == "thin":
+        nrow, ncol = 1, 37
+    if case == "no_gauge":
+        ng = 0
+    m = synth.make_mesh(nrow, ncol, ng=max(ng, 1))
+    if case == "one_cell":
+        act = np.zeros((nrow, ncol), np.int32, order="F")
+        r, c = int(m.gauge_pos[0, 0]), int(m.gauge_pos[0, 1])
+        act[r, c] = 1
+        fd = np.asfortranarray(np.where(act == 1, m.flwdir, -99).astype(np.int32))
+        fa = synth.flow_accumulation(fd, act)
+        m = synth.Mesh(nrow, ncol, m.dx, fd, fa, synth.make_path(np.where(act == 1, fa, -99)), act, m.gauge_pos[:1], m.area[:1] * 0 + m.dx * m.dx)
+        ng = 1
+    if case == "no_gauge":
+        m = synth.Mesh(nrow, ncol, m.dx, m.flwdir, m.flwacc, m.path, m.active_cell, np.zeros((0, 2), np.int32), np.zeros(0, np.float32))
+    prcp, pet = synth.dense_forcing(m, nt, gap_per_million=20000)
+    if case == "allgap":
+        prcp[...] = -99.0
+    P, S = synth.make_parameters(nrow, ncol), synth.make_states(nrow, ncol, warm=True)
+    qobs = np.asfortranarray(np.abs(np.random.default_rng(3).standard_normal((m.ng, nt))).astype(np.float32) + 0.1)
+    g = type("G", (), {})()
+    g.structure, g.dt, g.nt, g.mesh, g.prcp, g.pet, g.qobs, g.params, g.states, g.opts = "gr-c", 3600.0, nt, m, prcp, pet, qobs, P, S, {}
+    fo = pyoracle.run("gr-c", m, 3600.0, prcp, pet, qobs, P, S)
+    bo = pyoracle.run("gr-c", m, 3600.0, prcp, pet, qobs, P, S, adjoint=True)
+    par, sta, out = _run_forward(g)
+    par, sta, out2, par_b, sta_b = _run_adjoint(g)
+    if m.ng:
+        assert gu.rel_l2(out.qsim, fo["qsim"]) <= 2e-6 and abs(out.cost - fo["cost"]) <= 1e-5 * abs(fo["cost"]) + 3e-7
+    else:
+        assert out.cost == 0.0
+    for k in gu.STRUCT_STATES["gr-c"]:
+        assert gu.rel_l2(getattr(out.fstates, k), fo["fstates"][k]) <= 2e-5, k
+    for k in gu.STRUCT_PARAMS["gr-c"]:
+        assert gu.rel_l2(getattr(par_b, k), bo["parameters_b"][k]) <= 2e-5, k
+    for k in gu.STRUCT_STATES["gr-c"]:
+        assert gu.rel_l2(getattr(sta_b, k), bo["states_b"][k]) <= 2e-5, k
