@@ -306,3 +306,31 @@ def test_edge_cases_vs_oracle(case):
         assert gu.rel_l2(getattr(par_b, k), bo["parameters_b"][k]) <= 2e-5, k
     for k in gu.STRUCT_STATES["gr-c"]:
         assert gu.rel_l2(getattr(sta_b, k), bo["states_b"][k]) <= 2e-5, k
+
+
+def test_error_behaviour():
+    """The reference has no error channel; the C ABI returns a code + message and the Python host raises:
+    a flow-direction cycle, a gauge outside the active domain, a signature-based criterion, a missing field."""
+    import smash_amd
+    from smash_amd import _lib
+    g = gu.load("gr_a_12x12x48_nse")
+    setup, mesh, inp, par, sta, out = _types(g)
+    bad = smash_amd.MeshDT.from_synth(setup, g.mesh)
+    fd = np.array(bad.flwdir, order="F")
+    fd[5, 5], fd[5, 6] = 3, 7                       # E <-> W: a pit pair
+    bad.flwdir = fd
+    inp2 = smash_amd.Input_DataDT(setup, bad)
+    inp2.prcp, inp2.pet, inp2.qobs = g.prcp, g.pet, g.qobs
+    with pytest.raises(smash_amd.SmashxError) as e:
+        smash_amd.forward(setup, bad, inp2, par, par.copy(), sta, sta.copy(), out, np.float32(0))
+    assert e.value.code == _lib.E_MESH
+    setup.optimize.jobs_fun = ["Crc"]
+    with pytest.raises(smash_amd.SmashxError) as e:
+        smash_amd.forward(setup, mesh, inp, par, par.copy(), sta, sta.copy(), out, np.float32(0))
+    assert e.value.code == _lib.E_UNSUPPORTED
+    setup.optimize.jobs_fun = ["nse"]
+    bgd = par.copy()
+    par.cp = None
+    with pytest.raises(smash_amd.SmashxError) as e:
+        smash_amd.forward(setup, mesh, inp, par, bgd, sta, sta.copy(), out, np.float32(0))
+    assert e.value.code == _lib.E_ARG
