@@ -33,6 +33,7 @@ module smashx_c
 
     type, bind(C) :: smashx_mesh
         type(c_ptr) :: flwdir, flwacc, active_cell, path, gauge_pos, area
+        type(c_ptr) :: owner_mask = c_null_ptr
     end type smashx_mesh
 
     type, bind(C) :: smashx_options

@@ -69,6 +69,9 @@ typedef struct {
     const int* path;         /* (2,nrow*ncol) 0-based visiting order; only needed for the sparse forcing layout; may be NULL */
     const int* gauge_pos;    /* (ng,2) 0-based (row, col)                         mwd_mesh.f90:63 */
     const float* area;       /* (ng) m^2                                          mwd_mesh.f90:65 */
+    const int* owner_mask;   /* multi-GPU, optional: (nrow,ncol) 1 = this rank owns the cell.  Overrides smashx_config.tile:
+                              * any partition whose rank graph is acyclic works, e.g. sub-catchments cut at confluences
+                              * (smash_amd.tiles.partition_subcatchments).  NULL: the tile rectangle / the whole grid. */
 } smashx_mesh;
 
 /* Optimize_SetupDT fields the path reads (mwd_setup.f90:57-105) */
@@ -116,7 +119,7 @@ int smashx_device_count(void);
 /* ABI guard for bindings that mirror the structs by hand (the Fortran shim, ctypes): sizes in bytes of
  * {smashx_config, smashx_mesh, smashx_options, smashx_parameters, smashx_states, smashx_costs, smashx_timing};
  * returns SMASHX_ABI_VERSION. */
-#define SMASHX_ABI_VERSION 4
+#define SMASHX_ABI_VERSION 5
 int smashx_abi_sizes(int sizes[7]);
 
 /* builds the routing schedule from the mesh and allocates device storage */

@@ -30,7 +30,7 @@ class Config(C.Structure):
 
 class Mesh(C.Structure):
     _fields_ = [("flwdir", C.c_void_p), ("flwacc", C.c_void_p), ("active_cell", C.c_void_p), ("path", C.c_void_p),
-                ("gauge_pos", C.c_void_p), ("area", C.c_void_p)]
+                ("gauge_pos", C.c_void_p), ("area", C.c_void_p), ("owner_mask", C.c_void_p)]
 
 
 class Options(C.Structure):

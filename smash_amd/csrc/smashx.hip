@@ -492,9 +492,10 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     if (set_device(p)) { delete p; return SMASHX_E_HIP; }
     p->M = cfg->group_size > 0 ? cfg->group_size : 512;
     if (p->M % 64 != 0 || p->M > SX_MAXGROUP || p->M < 64) { delete p; return fail(SMASHX_E_ARG, "group_size must be a multiple of 64 in [64, 512]"); }
-    const bool tiled = cfg->tile[1] > cfg->tile[0] && cfg->tile[3] > cfg->tile[2];
+    const bool rect_tile = cfg->tile[1] > cfg->tile[0] && cfg->tile[3] > cfg->tile[2];
+    const bool tiled = rect_tile || mesh->owner_mask;
     const int rc0 = sx_build_schedule(cfg->nrow, cfg->ncol, mesh->flwdir, mesh->active_cell, cfg->ng, mesh->gauge_pos, p->M,
-                                      tiled ? cfg->tile : nullptr, p->sch);
+                                      rect_tile ? cfg->tile : nullptr, p->sch, mesh->owner_mask);
     if (rc0 != 0) { std::string e = p->sch.error; delete p; return fail(rc0 == -5 ? SMASHX_E_MESH : SMASHX_E_ARG, e); }
     p->tiled = tiled;
     p->n = p->sch.n; p->npad = (p->n + SX_VBLOCK - 1) / SX_VBLOCK * SX_VBLOCK;
@@ -1104,7 +1105,7 @@ int smashx_tile_probe(const smashx_config* cfg, const smashx_mesh* mesh, int* in
     const bool tiled = cfg->tile[1] > cfg->tile[0] && cfg->tile[3] > cfg->tile[2];
     const int M = cfg->group_size > 0 ? cfg->group_size : 512;
     const int rc = sx_build_schedule(cfg->nrow, cfg->ncol, mesh->flwdir, mesh->active_cell, cfg->ng, mesh->gauge_pos, M,
-                                     tiled ? cfg->tile : nullptr, sch);
+                                     tiled ? cfg->tile : nullptr, sch, mesh->owner_mask);
     if (rc) return fail(rc == -5 ? SMASHX_E_MESH : SMASHX_E_ARG, sch.error);
     const int no = (int)sch.out_x.size(), ni = (int)sch.in_x.size();
     const int v[8] = {sch.n, sch.nrounds, sch.ngroups, sch.nslots, sch.nxslots, sch.max_stage, no, ni};

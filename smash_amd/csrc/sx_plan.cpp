@@ -15,7 +15,7 @@ const int DCOL[8] = {0, 1, 1, 1, 0, -1, -1, -1};
 }  // namespace
 
 int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_cell, int ng, const int* gauge_pos,
-                      int group_size, const int* rect, SxSchedule& s) {
+                      int group_size, const int* rect, SxSchedule& s, const int* own) {
     const int M = group_size;
     if (nrow <= 0 || ncol <= 0 || M < 16) { s.error = "bad sizes"; return -1; }
     const long n2 = (long)nrow * ncol;
@@ -23,7 +23,11 @@ int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_c
 
     // ---- local active cells in column-major order (temporary index a), parents, children in D8 order ----
     const int r0 = rect ? rect[0] : 0, r1 = rect ? rect[1] : nrow, c0 = rect ? rect[2] : 0, c1 = rect ? rect[3] : ncol;
-    auto inside = [&](int row, int col) { return row >= r0 && row < r1 && col >= c0 && col < c1; };
+    auto inside = [&](int row, int col) {
+        if (own) return own[row + (long)col * nrow] == 1;
+        return row >= r0 && row < r1 && col >= c0 && col < c1;
+    };
+    const bool part = rect || own;
     std::vector<int> a_of_flat(n2, -1), flat_of_a;
     flat_of_a.reserve((size_t)(r1 - r0) * (c1 - c0));
     for (long c = 0; c < n2; ++c)
@@ -37,7 +41,7 @@ int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_c
     for (int a = 0; a < n; ++a) {
         const int c = flat_of_a[a], row = c % nrow, col = c / nrow, fd = flwdir[c];
         code[a] = fd;
-        if (rect)
+        if (part)
             for (int i = 0; i < 8; ++i) {   // neighbour at -D[i] drains into me iff its code == i+1
                 const int rn = row - DROW[i], cn = col - DCOL[i];
                 if (rn < 0 || rn >= nrow || cn < 0 || cn >= ncol || inside(rn, cn)) continue;

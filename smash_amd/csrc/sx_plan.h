@@ -45,5 +45,6 @@ struct SxSchedule {
 // rect = {row0, row1, col0, col1} (half-open) restricts the schedule to the cells of one tile of the grid;
 // cells of other tiles that drain into it become inlets fed by received series, cells draining out of it
 // publish theirs.  rect == nullptr: the whole grid.
+// own (nullable, (nrow,ncol), 1 = owned) replaces rect for arbitrary partitions (sub-catchments).
 int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_cell, int ng, const int* gauge_pos,
-                      int group_size, const int* rect, SxSchedule& s);
+                      int group_size, const int* rect, SxSchedule& s, const int* own = nullptr);

@@ -49,9 +49,10 @@ class Solver:
     """A libsmashx plan: routing schedule + HBM-resident forcing for one (setup, mesh, input_data)."""
 
     def __init__(self, setup, mesh, *, chunk_steps: int = 0, pipe_steps: int = 0, group_size: int = 0, device: int = -1,
-                 tile=None):
+                 tile=None, owner_mask=None):
         """tile = (row0, row1, col0, col1): this plan only owns that rectangle of the grid (multi-GPU, see
-        smash_amd.tiles); mesh and field arrays stay global-sized."""
+        smash_amd.tiles); owner_mask (nrow, ncol), 1 = owned, does the same for an arbitrary partition (sub-catchments);
+        mesh and field arrays stay global-sized."""
         L = _lib.lib()
         self.nrow, self.ncol, self.nt, self.ng = mesh.nrow, mesh.ncol, setup.ntime_step, mesh.ng
         self.structure = setup.structure
@@ -61,6 +62,9 @@ class Solver:
         self._keep = [_i32(mesh.flwdir), _i32(mesh.flwacc), _i32(mesh.active_cell), _i32(mesh.path),
                       _i32(np.asarray(mesh.gauge_pos).reshape(-1, 2)), np.ascontiguousarray(mesh.area, np.float32)]
         m = _lib.Mesh(*[_ptr(a) for a in self._keep])
+        if owner_mask is not None:
+            self._keep.append(_i32(owner_mask))
+            m.owner_mask = self._keep[-1].ctypes.data
         self._h = C.c_void_p()
         _lib.check(L.smashx_plan_create(C.byref(cfg), C.byref(m), C.byref(self._h)))
         self.ncells = L.smashx_plan_ncells(self._h)

@@ -39,14 +39,59 @@ def owner_of(flat, nrow: int, ncol: int, pr: int, pc: int):
     return (i * pc + j).astype(np.int64)
 
 
-class PeerLists:
-    """For one tile: which rows of the out / in message buffers go to / come from which peer rank."""
+def partition_subcatchments(mesh, nparts: int):
+    """Cut the river tree of `mesh` into nparts sub-catchment sets of nac / nparts cells each (what replaces
+    rectangles when the flow field is not E/SE/S).  Part p is filled, largest first, with not-yet-assigned subtrees that
+    still fit; whatever a detached subtree drains into is assigned later, so part ids are a topological order of the rank
+    graph (acyclic by construction) and every part is a union of whole sub-catchments minus the ones cut off before.
+    Returns owner (nrow, ncol) int32: part id of every active cell, -1 elsewhere."""
+    from . import synth
+    nrow, ncol = mesh.nrow, mesh.ncol
+    act = (np.asarray(mesh.active_cell) == 1).reshape(-1)
+    ds, _ = synth.downstream_index(np.asarray(mesh.flwdir), np.asarray(mesh.active_cell))      # C-order flat, -1 = outlet
+    n = nrow * ncol
+    rem = np.where(act, np.asarray(mesh.flwacc).reshape(-1).astype(np.int64), 0)                # size of the unassigned subtree
+    owner = np.full(n, -1, np.int64)
+    up = [[] for _ in range(n)]
+    for c in np.flatnonzero(ds >= 0):
+        up[ds[c]].append(int(c))
+    nac = int(np.count_nonzero(act))
+    for part in range(nparts - 1):
+        cap = (nac * (part + 1)) // nparts - (nac * part) // nparts
+        while cap > 0:
+            fits = np.where((owner < 0) & act & (rem <= cap), rem, 0)
+            root = int(np.argmax(fits))
+            size = int(fits[root])
+            if size == 0:
+                break
+            stack = [root]
+            while stack:                                 # the unassigned upstream closure of root
+                c = stack.pop()
+                owner[c] = part
+                stack.extend(u for u in up[c] if owner[u] < 0)
+            d = ds[root]
+            while d >= 0:                                # its ancestors lose that many cells
+                rem[d] -= size
+                d = ds[d]
+            cap -= size
+    owner[(owner < 0) & act] = nparts - 1
+    return np.asfortranarray(owner.reshape(nrow, ncol).astype(np.int32))
 
-    def __init__(self, solver, nrow, ncol, pr, pc):
+
+class PeerLists:
+    """For one tile: which rows of the out / in message buffers go to / come from which peer rank.
+    owner: optional (nrow, ncol) part id per cell (partition_subcatchments) instead of the pr x pc rectangles."""
+
+    def __init__(self, solver, nrow, ncol, pr, pc, owner=None):
         out_src, out_dst, in_src, in_dst = solver.halo_edges()
         self.n_out, self.n_in = len(out_src), len(in_src)
-        o_owner = owner_of(out_dst, nrow, ncol, pr, pc) if self.n_out else np.zeros(0, np.int64)
-        i_owner = owner_of(in_src, nrow, ncol, pr, pc) if self.n_in else np.zeros(0, np.int64)
+        if owner is not None:
+            of = np.asarray(owner).reshape(-1, order="F").astype(np.int64)        # flat = row + col * nrow
+            o_owner = of[np.asarray(out_dst, np.int64)] if self.n_out else np.zeros(0, np.int64)
+            i_owner = of[np.asarray(in_src, np.int64)] if self.n_in else np.zeros(0, np.int64)
+        else:
+            o_owner = owner_of(out_dst, nrow, ncol, pr, pc) if self.n_out else np.zeros(0, np.int64)
+            i_owner = owner_of(in_src, nrow, ncol, pr, pc) if self.n_in else np.zeros(0, np.int64)
         self.out_peers = {int(p): np.flatnonzero(o_owner == p) for p in np.unique(o_owner)}
         self.in_peers = {int(p): np.flatnonzero(i_owner == p) for p in np.unique(i_owner)}
         self.out_src, self.out_dst, self.in_src, self.in_dst = out_src, out_dst, in_src, in_dst
@@ -55,12 +100,12 @@ class PeerLists:
 class TorchDistExchange:
     """Halo exchange over torch.distributed point-to-point ops (RCCL on GPUs)."""
 
-    def __init__(self, solver, nrow, ncol, pr, pc, device):
+    def __init__(self, solver, nrow, ncol, pr, pc, device, owner=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.dev = torch, dist, device
         self.host_staged = dist.get_backend() != "nccl"     # gloo (rehearsals without RCCL) moves host tensors
-        self.peers = PeerLists(solver, nrow, ncol, pr, pc)
+        self.peers = PeerLists(solver, nrow, ncol, pr, pc, owner)
         _, self.tp = solver.chunking()
         self.out_buf = torch.zeros(max(self.peers.n_out, 1) * self.tp, dtype=torch.float32, device=device)
         self.in_buf = torch.zeros(max(self.peers.n_in, 1) * self.tp, dtype=torch.float32, device=device)

@@ -15,11 +15,11 @@ pytestmark = pytest.mark.gpu
 
 
 class Loopback:
-    def __init__(self, rank, solver, nrow, ncol, pr, pc, box):
+    def __init__(self, rank, solver, nrow, ncol, pr, pc, box, owner=None):
         import torch
         from smash_amd import tiles
         self.torch, self.rank, self.box = torch, rank, box
-        self.peers = tiles.PeerLists(solver, nrow, ncol, pr, pc)
+        self.peers = tiles.PeerLists(solver, nrow, ncol, pr, pc, owner)
         _, self.tp = solver.chunking()
         self.out_buf = torch.zeros(max(self.peers.n_out, 1) * self.tp, dtype=torch.float32, device="cuda")
         self.in_buf = torch.zeros(max(self.peers.n_in, 1) * self.tp, dtype=torch.float32, device="cuda")
@@ -48,11 +48,14 @@ class Loopback:
         return 0
 
 
-def _tile_inputs(g, rect, ng_total):
+def _tile_inputs(g, rect, ng_total, mine=None):
     import smash_amd
-    r0, r1, c0, c1 = rect
     gp = np.asarray(g.mesh.gauge_pos)
-    loc = [i for i in range(g.mesh.ng) if r0 <= gp[i, 0] < r1 and c0 <= gp[i, 1] < c1]
+    if mine is not None:                          # arbitrary partition: mine[row, col] = this rank owns the cell
+        loc = [i for i in range(g.mesh.ng) if mine[gp[i, 0], gp[i, 1]]]
+    else:
+        r0, r1, c0, c1 = rect
+        loc = [i for i in range(g.mesh.ng) if r0 <= gp[i, 0] < r1 and c0 <= gp[i, 1] < c1]
     setup = smash_amd.SetupDT(0, len(loc), structure=g.structure, dt=g.dt, ntime_step=g.nt)
     setup.optimize.jobs_fun, setup.optimize.wjobs_fun = ["nse"], [1.0]
     setup.optimize.wgauge = np.full(len(loc), 1.0 / ng_total, np.float32)
@@ -63,18 +66,37 @@ def _tile_inputs(g, rect, ng_total):
     return setup, mesh, loc
 
 
+def _short(name, nt):
+    g = gu.load(name)
+    g.nt = nt                                     # a short window keeps 8 plans on one card cheap
+    g.prcp, g.pet, g.qobs = np.asfortranarray(g.prcp[:, :, :nt]), np.asfortranarray(g.pet[:, :, :nt]), np.asfortranarray(g.qobs[:, :nt])
+    g.opts = {}
+    return g
+
+
 @pytest.mark.parametrize("world,chunk,pipe", [(2, 0, 16), (4, 32, 16), (8, 0, 32)])
 def test_tiled_sweep_equals_single_domain(world, chunk, pipe):
+    _check_partitioned(_short("gr_b_64x64x720_nse", 96), world, chunk, pipe, None)
+
+
+@pytest.mark.parametrize("name,world,chunk,pipe", [("gr_c_32x32x240_d8_ragged", 3, 0, 16), ("gr_b_20x20x96_d8", 4, 32, 16),
+                                                   ("vic_a_24x24x240_d8_kge", 5, 0, 32)])
+def test_subcatchment_partition_equals_single_domain(name, world, chunk, pipe):
+    """A flow field with all eight D8 codes cut into sub-catchment parts (tiles.partition_subcatchments): each part is
+    a plan with an owner mask, the boundary series travel between the plans as between ranks."""
+    from smash_amd import tiles
+    g = _short(name, 96)
+    owner = tiles.partition_subcatchments(g.mesh, world)
+    _check_partitioned(g, world, chunk, pipe, owner)
+
+
+def _check_partitioned(g, world, chunk, pipe, owner):
     import torch
     torch.zeros(1, device="cuda")                 # initialise torch's HIP context in the main thread
     import smash_amd
     from smash_amd import tiles
     from smash_amd.solver import Solver
     from test_gpu_parity import _run_adjoint
-    g = gu.load("gr_b_64x64x720_nse")
-    g.nt = 96                                     # a short window keeps 8 plans on one card cheap
-    g.prcp, g.pet, g.qobs = np.asfortranarray(g.prcp[:, :, :96]), np.asfortranarray(g.pet[:, :, :96]), np.asfortranarray(g.qobs[:, :96])
-    g.opts = {}
     _, _, ref_out, ref_pb, ref_sb = _run_adjoint(g)
     pr, pc = tiles.tile_grid(world)
     nrow, ncol = g.mesh.nrow, g.mesh.ncol
@@ -83,15 +105,21 @@ def test_tiled_sweep_equals_single_domain(world, chunk, pipe):
 
     def run(rank):
         try:
-            rect = tiles.tile_rect(rank, nrow, ncol, pr, pc)
-            setup, mesh, loc = _tile_inputs(g, rect, g.mesh.ng)
-            sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=128, tile=rect)
+            if owner is None:
+                rect = tiles.tile_rect(rank, nrow, ncol, pr, pc)
+                setup, mesh, loc = _tile_inputs(g, rect, g.mesh.ng)
+                sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=128, tile=rect)
+            else:
+                mine = np.asarray(owner) == rank
+                setup, mesh, loc = _tile_inputs(g, None, g.mesh.ng, mine)
+                sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=128, owner_mask=mine)
+                assert sol.ncells == int(mine.sum())
             rows, cols = sol.cell_order()
             sol.set_forcing(g.prcp, g.pet)
             if loc:
                 sol.set_qobs(np.asfortranarray(g.qobs[loc]))
             sol.set_options(setup.optimize)
-            ex = Loopback(rank, sol, nrow, ncol, pr, pc, box)
+            ex = Loopback(rank, sol, nrow, ncol, pr, pc, box, owner)
             par = smash_amd.ParametersDT.from_dict(mesh, g.params)
             sta = smash_amd.StatesDT.from_dict(mesh, g.states)
             out = smash_amd.OutputDT(setup, mesh)

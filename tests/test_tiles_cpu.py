@@ -16,7 +16,7 @@ from smash_amd.solver import make_config
 import smash_amd
 
 
-def probe(m, rect, group=128):
+def probe(m, rect, group=128, owner_mask=None):
     setup = smash_amd.SetupDT(0, 0, structure="gr-b", ntime_step=16)
     mesh = smash_amd.MeshDT.from_synth(setup, m)
     mesh.ng = 0
@@ -24,6 +24,9 @@ def probe(m, rect, group=128):
     cfg.ng = 0
     keep = [np.asfortranarray(m.flwdir, np.int32), np.asfortranarray(m.flwacc, np.int32), np.asfortranarray(m.active_cell, np.int32)]
     cm = _lib.Mesh(keep[0].ctypes.data, keep[1].ctypes.data, keep[2].ctypes.data, None, None, None)
+    if owner_mask is not None:
+        keep.append(np.asfortranarray(owner_mask, np.int32))
+        cm.owner_mask = keep[-1].ctypes.data
     info = (C.c_int * 8)()
     cap = 4 * (m.nrow + m.ncol) + 16
     arr = [np.zeros(cap, np.int32) for _ in range(4)]
@@ -55,6 +58,36 @@ def test_tiles_partition_cells_and_agree_on_boundary_series(world, mask):
     for a in range(world):
         if P[a]["n_out"]:
             assert np.all(tiles.owner_of(P[a]["out_dst"], m.nrow, m.ncol, pr, pc) > a)
+
+
+@pytest.mark.parametrize("kind,world", [("d8", 3), ("d8", 5), ("ese", 4), ("d8", 8)])
+def test_subcatchment_partition_is_balanced_acyclic_and_agrees_on_boundary_series(kind, world):
+    """Arbitrary partitions (real catchments drain in all 8 directions, rectangles would give a cyclic rank graph):
+    partition_subcatchments cuts the river tree; each part is a plan with an owner mask."""
+    m = synth.make_mesh_d8(40, 56, ng=1, seed=3) if kind == "d8" else synth.make_mesh(48, 64, ng=1, mask_corner=True)
+    owner = tiles.partition_subcatchments(m, world)
+    act = np.asarray(m.active_cell) == 1
+    assert np.all(owner[act] >= 0) and np.all(owner[~act] == -1)
+    sizes = np.bincount(owner[act], minlength=world)
+    assert sizes.sum() == m.nac and sizes.max() - sizes.min() <= 1                  # balanced to the cell
+    ds, _ = synth.downstream_index(m.flwdir, m.active_cell)
+    oc = np.asarray(owner).reshape(-1)
+    src = np.flatnonzero(ds >= 0)
+    assert np.all(oc[ds[src]] >= oc[src])                                           # part ids = a topological order
+    of = np.asarray(owner).reshape(-1, order="F")                                   # flat = row + col * nrow
+    P = [probe(m, None, owner_mask=(owner == r)) for r in range(world)]
+    assert [p["cells"] for p in P] == sizes.tolist()
+    n_cross = int(np.count_nonzero(oc[ds[src]] != oc[src]))
+    assert sum(p["n_out"] for p in P) == sum(p["n_in"] for p in P) == n_cross > 0
+    for a in range(world):
+        own = of[P[a]["out_dst"]] if P[a]["n_out"] else np.zeros(0, int)
+        assert np.all(own > a)
+        assert np.all(of[P[a]["out_src"]] == a) and np.all(of[P[a]["in_dst"]] == a)
+        for b in np.unique(own):
+            sel = own == b
+            src_b = of[P[b]["in_src"]] == a
+            assert np.array_equal(P[a]["out_src"][sel], P[b]["in_src"][src_b])       # same edges, same order
+            assert np.array_equal(P[a]["out_dst"][sel], P[b]["in_dst"][src_b])
 
 
 def _gloo_worker(rank, world, port, q):
