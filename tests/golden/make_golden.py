@@ -60,7 +60,12 @@ CASES = [
     dict(name="gr_a_64x64x720_nse_cold", structure="gr-a", n=64, nt=720, ng=4, mask=False, gaps=1000, big=True, warm=False, opts={}),
     dict(name="gr_c_48x48x480_nse", structure="gr-c", n=48, nt=480, ng=4, mask=True, gaps=1000, big=True, opts={}),
     dict(name="gr_d_48x48x480_nse", structure="gr-d", n=48, nt=480, ng=4, mask=False, gaps=1000, big=True, opts={}),
+    # the reference's own real-data case (BASELINE.json configs[0]): Cance, 28 x 28 cells (383 active), 3 gauges, 1440 hourly
+    # steps, read from the dataset files by cance_io.py; uniform parameters = the SBS optimum printed in model.py:784
+    dict(name="gr_a_cance_28x28x1440", structure="gr-a", dataset="cance", n=28, nt=1440, ng=3, mask=True, gaps=0,
+         opts=dict(wgauge=[1.0, 0.0, 0.0])),
 ]
+CANCE_SBS = dict(cp=76.57858, cft=263.64627, exc=-1.455813, lr=30.859276)
 
 
 def rel_l2(a, b):
@@ -75,6 +80,12 @@ def sha(a):
 
 def build_case(c):
     n, nt = c["n"], c["nt"]
+    if c.get("dataset") == "cance":
+        import cance_io
+        mesh, prcp, pet, qobs, P, S = cance_io.load()
+        for k, v in CANCE_SBS.items():
+            P[k][:] = v
+        return mesh, prcp, pet, qobs, P, S, dict(c["opts"])
     if c.get("d8"):
         mesh = synth.make_mesh_d8(n, n, ng=c["ng"], radius=c.get("radius", 0.0))
     else:
@@ -168,7 +179,7 @@ def tangent_direction(g):
 
 TANGENT_CASES = ["gr_a_12x12x48_nse", "gr_b_16x16x96_nse_gaps", "gr_c_16x16x96_kge_se_log_mask", "gr_d_12x12x48_rmse_kge2_start",
                  "gr_b_24x24x120_norm_jreg", "gr_b_16x16x96_median2", "gr_c_32x32x240_d8_ragged",
-                 "vic_a_16x16x96_nse_gaps", "vic_a_24x24x240_d8_kge"]
+                 "vic_a_16x16x96_nse_gaps", "vic_a_24x24x240_d8_kge", "gr_a_cance_28x28x1440"]
 
 
 def main_tangent():

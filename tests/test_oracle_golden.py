@@ -105,3 +105,26 @@ def test_python_lbfgsb_loop_reproduces_reference_trajectory():
         x, f, d = fmin_l_bfgs_b(fg, x0, m=10, factr=10.0, pgtol=1e-12, bounds=[(0.0, 1.0)] * len(x0), maxiter=it, maxfun=100)
         r = pyoracle.run("gr-b", mesh, g.dt, g.prcp, g.pet, z["qobs"], unpack(x), Sn, **kw)
         assert np.float32(r["cost"]) == z["costs"][it], (it, r["cost"], z["costs"][it])
+
+
+def test_cance_fixture_is_pinned_by_the_values_the_reference_publishes():
+    """The reference's own test data is the Cance catchment (smash/tests/*, baseline.hdf5 unreadable here); what its
+    sources print about that case pins the fixture (read from the dataset files by tests/golden/cance_io.py and run
+    through the flang-built reference) and the oracle:
+      * mesh: 28 x 28, 383 active cells, gauge 0 at (20, 27)               (dataset/load.py:58, core/model.py:775-777)
+      * run with Model() defaults: qsim[0, :3]                             (core/model.py:475-477)
+      * run at the uniform SBS optimum (model.py:784): qsim[0, :3], qsim[0, -3:]   (core/model.py:767-769)
+    The last three values of the DEFAULT run printed there (20.9165, 20.7623, 20.6105) are 2.1 % above what the current
+    sources give on the current dataset (20.4842, 20.3349, 20.1874; flang -O2 and -O3 agree to 2e-7) while the optimum run
+    agrees to 4e-5: that docstring predates the defaults / forcing treatment of this revision and is not asserted."""
+    g = gu.load("gr_a_cance_28x28x1440")
+    assert (g.mesh.nrow, g.mesh.ncol, g.mesh.nac, g.nt) == (28, 28, 383, 1440)
+    assert tuple(np.asarray(g.mesh.gauge_pos)[0]) == (20, 27)
+    q = g.fwd["qsim"][0]
+    np.testing.assert_allclose(q[:3], [5.7140866e-04, 4.7018618e-04, 3.5345653e-04], rtol=2e-7)
+    np.testing.assert_allclose(q[-3:], [1.9017689e+01, 1.8781073e+01, 1.8549627e+01], rtol=1e-4)
+    # Model() defaults (mwd_parameters.f90:150-167, mwd_states.f90:117-126, lr = dt * 5 / 3600) through the oracle
+    pv = dict(ci=1e-6, cp=200.0, beta=1000.0, cft=500.0, cst=500.0, alpha=0.9, exc=0.0, lr=5.0)
+    P = {k: (np.full_like(v, pv[k]) if k in pv else v) for k, v in g.params.items()}
+    o = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, P, g.states, **g.opts)
+    np.testing.assert_allclose(o["qsim"][0][:3], [1.9826449e-03, 1.3466686e-07, 6.7618025e-12], rtol=2e-7)
