@@ -651,3 +651,76 @@ subroutine base_hyper_forward_b(setup, mesh, input_data, parameters, parameters_
     call hyper_parameters_to_parameters_b(hyper_parameters, hyper_parameters_b, parameters, parameters_b, setup, mesh, input_data)
 
 end subroutine base_hyper_forward_b
+
+!  Tangent of the hyper mappings: replaces BASE_HYPER_FORWARD_D (forward_db.f90:11079-11162) behind mw_forward::hyper_forward_d
+!  (mw_forward.f90:154-181).  The tangent of the descriptor -> parameter mapping is the reference's own host code
+!  (HYPER_PARAMETERS_TO_PARAMETERS_D, HYPER_STATES_TO_STATES_D); the tangent sweep and the cost tangent run on the GPU.
+subroutine base_hyper_forward_d(setup, mesh, input_data, parameters, parameters_d, hyper_parameters, hyper_parameters_d, &
+& hyper_parameters_bgd, states, states_d, hyper_states, hyper_states_d, hyper_states_bgd, output, output_d, cost, cost_d)
+
+    use iso_c_binding
+    use md_constant
+    use mwd_setup
+    use mwd_mesh
+    use mwd_input_data
+    use mwd_parameters_diff
+    use mwd_states_diff
+    use mwd_output_diff
+    use mwd_parameters_manipulation_diff, only: hyper_parameters_to_parameters_d
+    use mwd_states_manipulation_diff, only: hyper_states_to_states_d
+    use smashx_c
+    use smashx_glue, only: smashx_prepare, sx_plan, sx_check
+
+    implicit none
+
+    type(SetupDT), intent(in), target :: setup
+    type(MeshDT), intent(in), target :: mesh
+    type(Input_DataDT), intent(inout), target :: input_data
+    type(ParametersDT), intent(inout), target :: parameters, parameters_d
+    type(Hyper_ParametersDT), intent(in) :: hyper_parameters, hyper_parameters_d, hyper_parameters_bgd
+    type(StatesDT), intent(inout), target :: states, states_d
+    type(Hyper_StatesDT), intent(in) :: hyper_states, hyper_states_d, hyper_states_bgd
+    type(OutputDT), intent(inout), target :: output
+    type(OutputDT_diff), intent(inout), target :: output_d
+    real(sp), intent(inout) :: cost, cost_d
+
+    type(smashx_parameters) :: cp, cpd
+    type(smashx_states) :: cs, csd
+    type(smashx_costs) :: cc
+    type(c_ptr) :: qs, qd
+    real(c_float) :: cd
+
+    call hyper_parameters_to_parameters_d(hyper_parameters, hyper_parameters_d, parameters, parameters_d, setup, mesh, input_data)
+    call hyper_states_to_states_d(hyper_states, hyper_states_d, states, states_d, setup, mesh, input_data)
+    call smashx_prepare(setup, mesh, input_data, .true.)
+    cp%f(1) = c_loc(parameters%ci); cp%f(2) = c_loc(parameters%cp); cp%f(3) = c_loc(parameters%beta)
+    cp%f(4) = c_loc(parameters%cft); cp%f(5) = c_loc(parameters%cst); cp%f(6) = c_loc(parameters%alpha)
+    cp%f(7) = c_loc(parameters%exc); cp%f(8) = c_loc(parameters%b); cp%f(9) = c_loc(parameters%cusl1)
+    cp%f(10) = c_loc(parameters%cusl2); cp%f(11) = c_loc(parameters%clsl); cp%f(12) = c_loc(parameters%ks)
+    cp%f(13) = c_loc(parameters%ds); cp%f(14) = c_loc(parameters%dsm); cp%f(15) = c_loc(parameters%ws)
+    cp%f(16) = c_loc(parameters%lr)
+    cpd%f(1) = c_loc(parameters_d%ci); cpd%f(2) = c_loc(parameters_d%cp); cpd%f(3) = c_loc(parameters_d%beta)
+    cpd%f(4) = c_loc(parameters_d%cft); cpd%f(5) = c_loc(parameters_d%cst); cpd%f(6) = c_loc(parameters_d%alpha)
+    cpd%f(7) = c_loc(parameters_d%exc); cpd%f(8) = c_loc(parameters_d%b); cpd%f(9) = c_loc(parameters_d%cusl1)
+    cpd%f(10) = c_loc(parameters_d%cusl2); cpd%f(11) = c_loc(parameters_d%clsl); cpd%f(12) = c_loc(parameters_d%ks)
+    cpd%f(13) = c_loc(parameters_d%ds); cpd%f(14) = c_loc(parameters_d%dsm); cpd%f(15) = c_loc(parameters_d%ws)
+    cpd%f(16) = c_loc(parameters_d%lr)
+    cs%f(1) = c_loc(states%hi); cs%f(2) = c_loc(states%hp); cs%f(3) = c_loc(states%hft); cs%f(4) = c_loc(states%hst)
+    cs%f(5) = c_loc(states%husl1); cs%f(6) = c_loc(states%husl2); cs%f(7) = c_loc(states%hlsl); cs%f(8) = c_loc(states%hlr)
+    csd%f(1) = c_loc(states_d%hi); csd%f(2) = c_loc(states_d%hp); csd%f(3) = c_loc(states_d%hft); csd%f(4) = c_loc(states_d%hst)
+    csd%f(5) = c_loc(states_d%husl1); csd%f(6) = c_loc(states_d%husl2); csd%f(7) = c_loc(states_d%hlsl)
+    csd%f(8) = c_loc(states_d%hlr)
+    qs = c_null_ptr
+    qd = c_null_ptr
+    if (mesh%ng .gt. 0) then
+        qs = c_loc(output%qsim)
+        qd = c_loc(output_d%qsim)
+    end if
+    cd = 0._c_float
+    call sx_check(smashx_forward_d(sx_plan, cp, cpd, cp, cs, csd, cs, qs, qd, cc, cd), "hyper forward_d")
+    cost_d = cd
+    cost = cc%cost
+    output%cost = cc%cost
+    output%cost_jobs = cc%cost_jobs
+
+end subroutine base_hyper_forward_d

@@ -53,7 +53,7 @@ build_dropin () {
   cp "$src"/*.o "$src"/*.mod "$obj"/
   local OC=/opt/rocm/lib/llvm/bin/llvm-objcopy
   $OC --weaken-symbol=base_forward_ --weaken-symbol=base_hyper_forward_ "$obj/forward.o"
-  $OC --weaken-symbol=base_forward_b_ --weaken-symbol=base_forward_d_ --weaken-symbol=base_hyper_forward_b_ "$obj/forward_db.o"
+  $OC --weaken-symbol=base_forward_b_ --weaken-symbol=base_forward_d_ --weaken-symbol=base_hyper_forward_b_ --weaken-symbol=base_hyper_forward_d_ "$obj/forward_db.o"
   $FC -cpp -O2 -ffp-contract=off -fPIC -module-dir "$obj" -I"$obj" -c "$repo/fortran/smashx_dropin.f90" -o "$obj/smashx_dropin.o"
   $FC -shared -o "$OUT/libsmash_dropin.so" "$obj/smashx_dropin.o" $(ls "$obj"/*.o | grep -v smashx_dropin.o) \
       -L"$repo/smash_amd" -lsmashx -Wl,-rpath,'$ORIGIN/../../smash_amd'

@@ -22,7 +22,7 @@ module ref_capi
     use mwd_parameters_manipulation
     use mwd_states_manipulation
     use mw_sparse_storage
-    use mw_forward, only: forward, forward_b, forward_d, hyper_forward, hyper_forward_b
+    use mw_forward, only: forward, forward_b, forward_d, hyper_forward, hyper_forward_b, hyper_forward_d
     use mw_optimize, only: optimize_lbfgsb
 
     implicit none
@@ -60,7 +60,8 @@ contains
     !  icfg(8)  optimize_start_step (1-based) icfg(9)  njf      icfg(10) njr
     !  icfg(11) mode: 0 = forward, 1 = forward_b, 2 = optimize_lbfgsb (mw_optimize.f90:484-676),
     !           3 = forward_d (tangent model, mw_forward.f90:70-97; entry point ref_run_d only)
-    !           4 = hyper_forward, 5 = hyper_forward_b (mw_forward.f90:99-152; entry point ref_run_hyper only)
+    !           4 = hyper_forward, 5 = hyper_forward_b, 6 = hyper_forward_d (mw_forward.f90:99-181; entry point
+    !           ref_run_hyper only; mode 6 reads the direction from hyper_p_b / hyper_s_b)
     !  icfg(14) nd (descriptors)   icfg(15) mapping: 1 hyper-linear, 2 hyper-polynomial
     !  icfg(12) nrep (timing repetitions, >=1)     icfg(13) maxiter (mode 2)
     !  rcfg(1) dt  rcfg(2) dx  rcfg(3) wjreg  rcfg(4) cost_b
@@ -218,7 +219,7 @@ contains
             call system_clock(c0, crate)
             if (icfg(11) .eq. 0) then
                 call forward(setup, mesh, input_data, p, p_bgd, s, s_bgd, output, cost)
-            else if (icfg(11) .eq. 4 .or. icfg(11) .eq. 5) then
+            else if (icfg(11) .ge. 4 .and. icfg(11) .le. 6) then
                 call Hyper_ParametersDT_initialise(hp, setup)
                 call Hyper_ParametersDT_initialise(hp_b, setup)
                 call Hyper_ParametersDT_initialise(hp_bgd, setup)
@@ -231,6 +232,17 @@ contains
                 call set_hyper_states(setup, hs_bgd, hyper_s)
                 if (icfg(11) .eq. 4) then
                     call hyper_forward(setup, mesh, input_data, p, hp, hp_bgd, s, hs, hs_bgd, output, cost)
+                else if (icfg(11) .eq. 6) then
+                    call ParametersDT_initialise(p_d, mesh)
+                    call StatesDT_initialise(s_d, mesh)
+                    call OutputDT_initialise(output_d, setup, mesh)
+                    call set_hyper_parameters(setup, hp_b, hyper_p_b)
+                    call set_hyper_states(setup, hs_b, hyper_s_b)
+                    cost_d = 0._sp
+                    call hyper_forward_d(setup, mesh, input_data, p, p_d, hp, hp_b, hp_bgd, s, s_d, hs, hs_b, hs_bgd, &
+                    & output, output_d, cost, cost_d)
+                    cost_d_out = cost_d
+                    if (ng .gt. 0) qsim_d = output_d%qsim
                 else
                     call hyper_forward_b(setup, mesh, input_data, p, p_b, hp, hp_b, hp_bgd, s, s_b, hs, hs_b, hs_bgd, &
                     & output, output_b, cost, cost_b)
@@ -359,7 +371,7 @@ contains
     & prcp, pet, qobs, params, params_bgd, states, states_bgd, &
     & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
     & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed, &
-    & descriptor, hyper_p, hyper_s, hyper_p_b, hyper_s_b) bind(C, name="ref_run_hyper")
+    & descriptor, hyper_p, hyper_s, hyper_p_b, hyper_s_b, qsim_d, cost_d_out) bind(C, name="ref_run_hyper")
         integer(c_int), intent(in) :: icfg(16)
         real(c_float), intent(in) :: rcfg(4)
         integer(c_int), intent(in) :: flwdir(icfg(2), icfg(3)), flwacc(icfg(2), icfg(3))
@@ -386,10 +398,13 @@ contains
         real(c_float), intent(in) :: descriptor(icfg(2), icfg(3), *)
         real(c_float), intent(in) :: hyper_p(1 + icfg(15)*icfg(14), 1, GNP), hyper_s(1 + icfg(15)*icfg(14), 1, GNS)
         real(c_float), intent(inout) :: hyper_p_b(1 + icfg(15)*icfg(14), 1, GNP), hyper_s_b(1 + icfg(15)*icfg(14), 1, GNS)
+        real(c_float), intent(inout) :: qsim_d(icfg(5), icfg(4))
+        real(c_float), intent(inout) :: cost_d_out
         call ref_core(icfg, rcfg, flwdir, flwacc, path, active_cell, gauge_pos, area, &
         & prcp, pet, qobs, params, params_bgd, states, states_bgd, &
         & wgauge, jobs_codes, wjobs, jreg_codes, wjreg_fun, optim_p, optim_s, lbp, ubp, lbs, ubs, &
         & qsim, costs, fstates, params_out, states_out, params_b, states_b, elapsed, &
+        & qsim_d=qsim_d, cost_d_out=cost_d_out, &
         & descriptor=descriptor, hyper_p=hyper_p, hyper_s=hyper_s, hyper_p_b=hyper_p_b, hyper_s_b=hyper_s_b)
     end subroutine ref_run_hyper
 

@@ -69,7 +69,7 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         optim_parameters=None, optim_states=None, lb_parameters=None, ub_parameters=None,
         lb_states=None, ub_states=None, cost_b=1.0, nrep=1, fast=False, optimize_maxiter=None,
         params_d=None, states_d=None, params_bgd_d=None, states_bgd_d=None,
-        descriptor=None, hyper_params=None, hyper_states=None, mapping=None):
+        descriptor=None, hyper_params=None, hyper_states=None, mapping=None, hyper_params_d=None, hyper_states_d=None):
     """Call the reference forward / forward_b (mw_forward.f90:18-68) on flat arrays.
 
     mesh: object with nrow, ncol, dx, flwdir, flwacc, path (0-based), active_cell, gauge_pos (0-based),
@@ -78,7 +78,8 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
     instead; the result also holds cost_d and qsim_d.
     mapping ("hyper-linear" | "hyper-polynomial") with descriptor (nrow, ncol, nd), hyper_params / hyper_states
     (dict name -> (nhyper,)): mw_forward::hyper_forward / hyper_forward_b (mw_forward.f90:99-152); the result also holds
-    hyper_parameters_b / hyper_states_b."""
+    hyper_parameters_b / hyper_states_b; with hyper_params_d / hyper_states_d it is hyper_forward_d (mw_forward.f90:154-181)
+    along that direction (result: cost_d, qsim_d)."""
     from smash_amd.synth import PARAM_NAMES, STATE_NAMES
     lib = _lib(fast)
     nrow, ncol, ng = mesh.nrow, mesh.ncol, mesh.ng
@@ -89,7 +90,7 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
     mode = 3 if tangent else (2 if optimize_maxiter is not None else int(adjoint))
     nd = mcode = 0
     if hyper:
-        mode = 5 if adjoint else 4
+        mode = 6 if hyper_params_d is not None else 5 if adjoint else 4
         descriptor = np.asfortranarray(descriptor, dtype=np.float32)
         nd = descriptor.shape[2]
         mcode = {"hyper-linear": 1, "hyper-polynomial": 2}[mapping]
@@ -144,7 +145,15 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         for i, k in enumerate(STATE_NAMES):
             HS[:, 0, i] = hyper_states[k]
         HP_b, HS_b = np.zeros_like(HP, order="F"), np.zeros_like(HS, order="F")
-        cargs += [_ptr(descriptor), _ptr(HP), _ptr(HS), _ptr(HP_b), _ptr(HS_b)]
+        if mode == 6:
+            for i, k in enumerate(PARAM_NAMES):
+                HP_b[:, 0, i] = hyper_params_d[k]
+            for i, k in enumerate(STATE_NAMES):
+                HS_b[:, 0, i] = hyper_states_d[k]
+        qsim_d = np.zeros((max(ng, 1), nt), np.float32, order="F")
+        cost_d = C.c_float(0.0)
+        cargs += [_ptr(descriptor), _ptr(HP), _ptr(HS), _ptr(HP_b), _ptr(HS_b), _ptr(qsim_d), C.byref(cost_d)]
+        tangent = mode == 6
     err = []
 
     def call():

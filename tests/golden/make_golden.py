@@ -220,6 +220,12 @@ def hyper_inputs(g, mapping):
     return desc, mk(g.params, GLB_P, GUB_P, synth.PARAM_NAMES), mk(g.states, GLB_S, GUB_S, synth.STATE_NAMES)
 
 
+def hyper_direction(adj):
+    """Direction of the hyper tangent fixtures: 0.01 per coefficient, signed like the reference gradient (well-conditioned cost_d)."""
+    sg = lambda v: np.where(np.asarray(v) < 0, -0.01, 0.01).astype(np.float32)
+    return ({k: sg(v) for k, v in adj["hyper_parameters_b"].items()}, {k: sg(v) for k, v in adj["hyper_states_b"].items()})
+
+
 HYPER_CASES = [("gr_b_16x16x96_nse_gaps", "hyper-linear"), ("gr_c_32x32x240_d8_ragged", "hyper-polynomial"),
                ("vic_a_16x16x96_nse_gaps", "hyper-polynomial")]
 
@@ -247,8 +253,15 @@ def main_hyper():
             d["fwd_s_" + k] = f["states"][k]
             d["adj_hs_b_" + k] = b["hyper_states_b"][k]
             d["noise_hs_b_" + k] = np.float64(rel_l2(b3["hyper_states_b"][k], b["hyper_states_b"][k]))
+        # hyper_forward_d (mw_forward.f90:154-181) along hyper_direction()
+        hd, sd = hyper_direction(b)
+        t, t3 = run(hyper_params_d=hd, hyper_states_d=sd), run(hyper_params_d=hd, hyper_states_d=sd, fast=True)
+        d.update(tan_cost_d=np.float32(t["cost_d"]), tan_qsim_d=t["qsim_d"],
+                 noise_tan_cost_d=np.float64(abs(t3["cost_d"] - t["cost_d"]) / abs(t["cost_d"])),
+                 noise_tan_qsim_d=np.array([rel_l2(t3["qsim_d"][i], t["qsim_d"][i]) for i in range(g.mesh.ng)]))
         np.savez_compressed(os.path.join(OUT, "hyper", f"{name}__{mapping}.npz"), **d)
-        print(f"hyper {name} {mapping}: cost={f['cost']:.8g} |cp hyper_b|={np.abs(b['hyper_parameters_b']['cp']).max():.3g}")
+        print(f"hyper {name} {mapping}: cost={f['cost']:.8g} |cp hyper_b|={np.abs(b['hyper_parameters_b']['cp']).max():.3g} "
+              f"cost_d={t['cost_d']:.6g} noise={d['noise_tan_cost_d']:.2g}")
 
 
 def main_lbfgsb():

@@ -117,3 +117,27 @@ def test_reference_hyper_forward_through_dropin(name, mapping):
         assert gu.rel_l2(b["hyper_parameters_b"][k], z["adj_hp_b_" + k]) <= gu.tol(float(z["noise_hp_b_" + k]), base=5e-6), k
     for k in gu.STRUCT_STATES[g.structure]:
         assert gu.rel_l2(b["hyper_states_b"][k], z["adj_hs_b_" + k]) <= gu.tol(float(z["noise_hs_b_" + k]), base=5e-6), k
+
+
+@pytest.mark.parametrize("name,mapping", _hyper_cases())
+def test_reference_hyper_forward_d_through_dropin(name, mapping):
+    """mw_forward::hyper_forward_d (mw_forward.f90:154-181): tangent of the mapping in the reference's host code, tangent
+    sweep and cost tangent on the GPU (base_hyper_forward_d in fortran/smashx_dropin.f90).  Bars as in
+    test_gpu_tangent.py: qsim_d noise-aware 1e-6, cost_d 1e-5 (reference-order sums of cancelling terms)."""
+    import make_golden as mg
+    g = gu.load(name)
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "hyper", f"{name}__{mapping}.npz"))
+    desc, hp, hs = mg.hyper_inputs(g, mapping)
+    adj = dict(hyper_parameters_b={k: z["adj_hp_b_" + k] for k in hp}, hyper_states_b={k: z["adj_hs_b_" + k] for k in hs})
+    hd, sd = mg.hyper_direction(adj)
+    kw = dict(descriptor=desc, hyper_params=hp, hyper_states=hs, mapping=mapping, fast="dropin", hyper_params_d=hd, hyper_states_d=sd,
+              **{k: v for k, v in g.opts.items() if k in ("jobs_fun", "wjobs_fun", "optimize_start_step", "wgauge")})
+    t = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, **kw)
+    for i in range(g.mesh.ng):
+        assert gu.rel_l2(t["qsim_d"][i], z["tan_qsim_d"][i]) <= gu.tol(z["noise_tan_qsim_d"][i]), i
+    ref = float(z["tan_cost_d"])
+    assert abs(t["cost_d"] - ref) <= max(1e-5, 3 * float(z["noise_tan_cost_d"])) * abs(ref), (t["cost_d"], ref)
+    # and the adjoint / tangent pair of the whole chain agree: cost_d = <gradient, direction>
+    dot = sum(float(np.dot(z["adj_hp_b_" + k].astype(np.float64), hd[k])) for k in hp) + \
+          sum(float(np.dot(z["adj_hs_b_" + k].astype(np.float64), sd[k])) for k in hs)
+    assert abs(t["cost_d"] - dot) <= 2e-4 * abs(dot), (t["cost_d"], dot)
