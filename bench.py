@@ -64,13 +64,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=256)
     ap.add_argument("--cpu-nt", type=int, default=360)
+    ap.add_argument("--cpu-cores", type=int, default=0, help="replicas of the CPU baseline (default: the box's CPU share, at most 16)")
     return ap.parse_args()
 
 
-def cpu_baseline(structure, n, nt):
-    """The reference path timed on the host cores of this box, on a bounded sample of the same synthetic
-    workload: one forward_b (cost + gradient) on an n x n catchment over nt steps, single thread -- the only
-    mode the reference has for this path (mw_forward.f90:41-68; no OpenMP in forward_b)."""
+def _cpu_replica(structure, n, nt, barrier, q):
+    """One replica of the CPU baseline (its own process): the reference's forward_b on the bounded sample."""
     from oracle import pyoracle, refbind
     from smash_amd import synth
     m = synth.make_mesh(n, n, ng=4)
@@ -80,21 +79,55 @@ def cpu_baseline(structure, n, nt):
     kind = "reference" if refbind.available(fast=True) else "port"
     if kind == "reference":
         qobs = refbind.run(structure, m, 3600.0, prcp, pet, np.zeros((4, nt), np.float32), Pq, S, fast=True)["qsim"]
-        r = refbind.run(structure, m, 3600.0, prcp, pet, qobs, P, S, adjoint=True, fast=True)
-        secs = r["elapsed"]
-        what = "reference Fortran (flang -O3, libsmash_ref_fast.so) forward_b"
+        barrier.wait()
+        t0 = time.perf_counter()
+        refbind.run(structure, m, 3600.0, prcp, pet, qobs, P, S, adjoint=True, fast=True)
     else:
         qobs = pyoracle.run(structure, m, 3600.0, prcp, pet, np.zeros((4, nt), np.float32), Pq, S)["qsim"]
+        barrier.wait()
         t0 = time.perf_counter()
         pyoracle.run(structure, m, 3600.0, prcp, pet, qobs, P, S, adjoint=True)
-        secs = time.perf_counter() - t0
-        what = "plain-C oracle (gcc -O2) forward_b"
-    return {"value": m.nac * nt / secs, "unit": "cell-timesteps/s", "cores": 1, "kind": kind,
-            "sample": f"{what}, {structure}, {n}x{n} synthetic catchment x {nt} hourly steps, {secs:.1f} s"}
+    q.put((kind, m.nac * nt, time.perf_counter() - t0))
+
+
+def cpu_baseline(structure, n, nt, cores=0):
+    """The reference path timed on the host cores of this box, on a bounded sample of the same synthetic workload:
+    forward_b (cost + gradient) on an n x n catchment over nt steps.  forward_b is single-threaded
+    (mw_forward.f90:41-68; no OpenMP in it), so the host is filled the way the reference fills it
+    (mw_multiple_run.f90:96-107): one independent replica per core, started together; value = all replicas' work /
+    the slowest replica's time."""
+    import multiprocessing as mp
+    # the CPU share of a one-GPU box is 16 cores whatever the affinity mask says; a replica holds ~2 GB (the reference's
+    # tape is 40 B per cell-step), so the pool is sized to that share and never to the machine
+    cores = cores or max(1, min(len(os.sched_getaffinity(0)), 16))
+    ctx = mp.get_context("spawn")                       # no fork of a process that holds a HIP context
+    barrier, q = ctx.Barrier(cores), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_replica, args=(structure, n, nt, barrier, q)) for _ in range(cores)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join()
+    kind = res[0][0]
+    work, slow = sum(r[1] for r in res), max(r[2] for r in res)
+    what = ("reference Fortran (flang -O3, libsmash_ref_fast.so) forward_b" if kind == "reference"
+            else "plain-C oracle (gcc -O2) forward_b")
+    return {"value": work / slow, "unit": "cell-timesteps/s", "cores": cores, "kind": kind,
+            "per_core_value": float(np.mean([r[1] / r[2] for r in res])),
+            "sample": f"{what}, {structure}, {cores} independent replicas (one per core) of a {n}x{n} synthetic catchment x {nt} "
+                      f"hourly steps, slowest replica {slow:.1f} s"}
 
 
 def main():
     a = parse()
+    # the CPU baseline starts one process per core: it runs FIRST, before anything in this process touches the GPU
+    # (rank 0 at N = 1 only)
+    cpu = None
+    if not a.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        try:
+            cpu = cpu_baseline(a.structure, a.cpu_grid, a.cpu_nt, a.cpu_cores)
+        except Exception as e:  # pragma: no cover
+            cpu = {"value": None, "unit": "cell-timesteps/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     import torch
     import torch.distributed as dist
 
@@ -264,12 +297,8 @@ def main():
             "device_sweep_ms": tm["sweep_ms"], "cost": cost, "setup_s": t_setup,
             "hbm_plan_gb": tm["device_bytes"] / 1e9,
         }
-        if not a.no_cpu_baseline:
-            try:
-                line["cpu_baseline"] = cpu_baseline(a.structure, a.cpu_grid, a.cpu_nt)
-            except Exception as e:  # pragma: no cover
-                line["cpu_baseline"] = {"value": None, "unit": "cell-timesteps/s", "cores": 1, "kind": "port",
-                                        "sample": f"failed: {e}"}
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
