@@ -8,8 +8,9 @@ one message of (edges x steps) floats moves downstream in the forward sweep and 
 boundary discharge) in the reverse sweep: point-to-point send/recv over RCCL (torch.distributed backend "nccl"),
 no collective on the data path.  Gradients stay tile-local; the cost is the sum of per-tile partial costs.
 
-The flow network must make the tile graph acyclic (a river may not leave a tile and come back): true for the
-synthetic E/SE/S catchments; real catchments are cut along sub-catchment borders instead (not built here).
+The flow network must make the rank graph acyclic (a river may not leave a part and come back): true for
+rectangles on the synthetic E/SE/S catchments; real catchments (all eight D8 codes) are cut along the river tree
+instead -- partition_subcatchments() -- and a part is handed to the plan as an owner mask (Solver(owner_mask=...)).
 """
 from __future__ import annotations
 
