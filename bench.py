@@ -53,6 +53,12 @@ def parse():
     ap.add_argument("--tile-rows", type=int, default=0, help="per-GPU tile rows (default --grid); 2048 x 1024 tiles on 8 GPUs = the 4096^2 grid")
     ap.add_argument("--tile-cols", type=int, default=0)
     ap.add_argument("--pipe", type=int, default=0, help="pipeline sub-chunk (default: none on 1 GPU, 1104 on tiles)")
+    ap.add_argument("--partition", default="rect", choices=["rect", "sub", "trunk"],
+                    help="N > 1: rectangles (default), sub-catchments (tiles.partition_subcatchments) or the depth-2 trunk cut (tiles.partition_trunk)")
+    ap.add_argument("--trunk-share", type=float, default=1.0, help="--partition trunk: the trunk part's share of the cells relative to 1/N")
+    ap.add_argument("--as-rank", type=int, default=-1, help="diagnostics, one process: build rank R's part of an --of N decomposition and time it "
+                    "alone (no-op exchange, zero inflow): what that rank computes, without waiting for its neighbours")
+    ap.add_argument("--of", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo only for rehearsing the N>1 path without RCCL")
     ap.add_argument("--nt", type=int, default=8760)
     ap.add_argument("--structure", default="gr-b")
@@ -150,13 +156,23 @@ def main():
     from smash_amd import tiles
     n, nt = a.grid, a.nt
     trows, tcols = a.tile_rows or n, a.tile_cols or n
-    pr, pc = tiles.tile_grid(world)
-    nrow, ncol = pr * trows, pc * tcols            # the whole catchment; every rank owns one trows x tcols tile of it
+    solo = a.as_rank >= 0 and a.of > 1 and world == 1      # diagnostics: one rank of a decomposition, alone
+    parts, me = (a.of, a.as_rank) if solo else (world, rank)
+    pr, pc = tiles.tile_grid(parts)
+    nrow, ncol = pr * trows, pc * tcols            # the whole catchment; every rank owns 1/parts of it (weak scaling)
     t_setup = time.perf_counter()
     m = synth.make_mesh(nrow, ncol, ng=a.ng)
-    rect = tiles.tile_rect(rank, nrow, ncol, pr, pc) if world > 1 else None
+    rect, owner, mine = None, None, None
+    if parts > 1 and a.partition == "rect":
+        rect = tiles.tile_rect(me, nrow, ncol, pr, pc)
+    elif parts > 1:                                # every rank computes the same cut of the river tree
+        owner = tiles.partition_trunk(m, parts, a.trunk_share) if a.partition == "trunk" else tiles.partition_subcatchments(m, parts)
+        mine = np.asfortranarray((np.asarray(owner) == me).astype(np.int32))
     gp = np.asarray(m.gauge_pos)
-    loc = [i for i in range(m.ng) if rect is None or (rect[0] <= gp[i, 0] < rect[1] and rect[2] <= gp[i, 1] < rect[3])]
+    if mine is not None:
+        loc = [i for i in range(m.ng) if mine[gp[i, 0], gp[i, 1]]]
+    else:
+        loc = [i for i in range(m.ng) if rect is None or (rect[0] <= gp[i, 0] < rect[1] and rect[2] <= gp[i, 1] < rect[3])]
     setup = smash_amd.SetupDT(0, len(loc), structure=a.structure, dt=3600.0, ntime_step=nt)
     setup.optimize.jobs_fun, setup.optimize.wjobs_fun = ["nse"], [1.0]
     setup.optimize.wgauge = np.full(len(loc), 1.0 / m.ng, np.float32)      # weights of the global cost (mean over all gauges)
@@ -165,13 +181,13 @@ def main():
     mesh.gauge_pos = np.asfortranarray(gp[loc].reshape(-1, 2))
     mesh.area = np.asarray(m.area)[loc]
     chunk, pipe = a.chunk, a.pipe
-    if world > 1:
+    if parts > 1:
         # every rank must cut time identically (messages are per sub-chunk): fix the lengths instead of sizing from free HBM
         chunk = chunk or ((nt + 15) // 16 * 16 if trows * tcols <= 1100000 else ((nt + 3) // 4 + 15) // 16 * 16)
         pipe = pipe or 1104
     if a.trace_groups:
         os.environ["SMASHX_TRACE_GROUPS"] = "1"
-    sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=a.group, device=local, tile=rect)
+    sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=a.group, device=local, tile=rect, owner_mask=mine)
     n = None
     rows, cols = sol.cell_order()
     d_rows = torch.from_numpy(rows.astype(np.int64)).to(dev)
@@ -192,7 +208,9 @@ def main():
     # observations = forward run with parameters perturbed by +10 %
     parq = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(nrow, ncol, perturb=0.1))
     sol.set_options(setup.optimize)
-    exchange = tiles.TorchDistExchange(sol, nrow, ncol, pr, pc, dev) if world > 1 else None
+    exchange = tiles.TorchDistExchange(sol, nrow, ncol, pr, pc, dev, owner) if world > 1 else None
+    if solo:
+        exchange = tiles.NoExchange(sol, dev)
     sol.upload(parq, sta)
     sol.sweep(False)
     sol.download(False, parq, sta, out)
@@ -286,7 +304,9 @@ def main():
                        "grid": [nrow, ncol], "tile": [trows, tcols], "nt": nt, "structure": a.structure, "active_cells": int(cellsteps / nt),
                        "chunk_steps": int(tm["chunk_steps"]), "n_chunks": int(tm["n_chunks"]),
                        "routing_rounds": int(tm["n_rounds"]), "routing_groups": int(tm["n_groups"]),
-                       "parallelism": f"tiles {pr}x{pc}, halo exchange of boundary discharge series (send/recv)" if world > 1 else "single"},
+                       "parallelism": (f"rank {me} of {parts} alone ({a.partition}), no-op exchange" if solo else
+                                       (f"tiles {pr}x{pc}" if a.partition == "rect" else f"{parts} {a.partition} parts of the river tree") +
+                                       ", exchange of boundary discharge series (send/recv)" if world > 1 else "single")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, per_launch_steps) if a.structure == "gr-b" else None,
                          "avg_launch_ms": avg_ms, "launches_per_step": n_launch,

@@ -144,3 +144,72 @@ class TorchDistExchange:
                 view[ix] = tmps[p].to(self.dev)
         torch.cuda.current_stream().synchronize()
         return 0
+
+
+class NoExchange:
+    """Diagnostics: the halo hooks of one part run alone -- nothing moves, inflow stays zero."""
+
+    def __init__(self, solver, device):
+        import torch
+        n_out, n_in = solver.halo_counts()
+        _, tp = solver.chunking()
+        self.out_buf = torch.zeros(max(n_out, 1) * tp, dtype=torch.float32, device=device)
+        self.in_buf = torch.zeros(max(n_in, 1) * tp, dtype=torch.float32, device=device)
+        solver.set_halo(self.out_buf.data_ptr(), self.in_buf.data_ptr(), self)
+
+    def __call__(self, phase, t0, nsteps):
+        return 0
+
+
+def partition_trunk(mesh, nparts: int, trunk_share: float = 1.0):
+    """Depth-2 cut of the river tree: parts 0 .. nparts-2 are unions of WHOLE sub-catchments (subtrees no earlier cut has
+    touched), the last part is the trunk everything else drains through.  No leaf part receives anything, every leaf part
+    sends only to the trunk, so the rank graph has two levels whatever nparts is (partition_subcatchments tends to a chain
+    of nparts levels; rectangles on the E/SE/S catchment have Pr + Pc - 1).  Parts are balanced to the cell;
+    trunk_share scales the trunk's share of the cells (its routing is the deep, latency-bound part of the network).
+    Returns owner (nrow, ncol) int32, -1 on inactive cells."""
+    from . import synth
+    nrow, ncol = mesh.nrow, mesh.ncol
+    n = nrow * ncol
+    act = (np.asarray(mesh.active_cell) == 1).reshape(-1)
+    ds, _ = synth.downstream_index(np.asarray(mesh.flwdir), np.asarray(mesh.active_cell))     # C-order flat, -1 = outlet
+    acc = np.where(act, np.asarray(mesh.flwacc).reshape(-1).astype(np.int64), 0)              # subtree sizes
+    src = np.flatnonzero(ds >= 0)
+    order = src[np.argsort(ds[src], kind="stable")]                                           # children, grouped by parent
+    ptr = np.concatenate(([0], np.cumsum(np.bincount(ds[src], minlength=n))))
+
+    def subtree(root):
+        out, f = [np.array([root], np.int64)], np.array([root], np.int64)
+        while True:
+            c0 = ptr[f]
+            k = ptr[f + 1] - c0
+            tot = int(k.sum())
+            if tot == 0:
+                return np.concatenate(out)
+            first = np.cumsum(k) - k
+            f = order[np.repeat(c0 - first, k) + np.arange(tot)]
+            out.append(f)
+
+    nac = int(np.count_nonzero(act))
+    trunk = int(round(nac / nparts * trunk_share)) if nparts > 1 else nac
+    leaf_total = nac - trunk
+    owner = np.full(n, -1, np.int64)
+    avail = act.copy()                                   # may still become the root of a whole, untouched sub-catchment
+    for part in range(nparts - 1):
+        cap = (leaf_total * (part + 1)) // (nparts - 1) - (leaf_total * part) // (nparts - 1)
+        while cap > 0:
+            fits = np.where(avail & (acc <= cap), acc, 0)
+            root = int(np.argmax(fits))
+            size = int(fits[root])
+            if size == 0:
+                break
+            cells = subtree(root)
+            owner[cells] = part
+            avail[cells] = False
+            d = ds[root]
+            while d >= 0 and avail[d]:                   # everything downstream of a cut is trunk material from now on
+                avail[d] = False
+                d = ds[d]
+            cap -= size
+    owner[act & (owner < 0)] = nparts - 1
+    return np.asfortranarray(owner.reshape(nrow, ncol).astype(np.int32))

@@ -79,14 +79,15 @@ def test_tiled_sweep_equals_single_domain(world, chunk, pipe):
     _check_partitioned(_short("gr_b_64x64x720_nse", 96), world, chunk, pipe, None)
 
 
-@pytest.mark.parametrize("name,world,chunk,pipe", [("gr_c_32x32x240_d8_ragged", 3, 0, 16), ("gr_b_20x20x96_d8", 4, 32, 16),
-                                                   ("vic_a_24x24x240_d8_kge", 5, 0, 32)])
-def test_subcatchment_partition_equals_single_domain(name, world, chunk, pipe):
+@pytest.mark.parametrize("name,world,chunk,pipe,cut", [("gr_c_32x32x240_d8_ragged", 3, 0, 16, "sub"), ("gr_b_20x20x96_d8", 4, 32, 16, "sub"),
+                                                       ("vic_a_24x24x240_d8_kge", 5, 0, 32, "sub"),
+                                                       ("gr_c_32x32x240_d8_ragged", 4, 0, 16, "trunk"), ("gr_a_cance_28x28x1440", 3, 0, 32, "trunk")])
+def test_subcatchment_partition_equals_single_domain(name, world, chunk, pipe, cut):
     """A flow field with all eight D8 codes cut into sub-catchment parts (tiles.partition_subcatchments): each part is
     a plan with an owner mask, the boundary series travel between the plans as between ranks."""
     from smash_amd import tiles
     g = _short(name, 96)
-    owner = tiles.partition_subcatchments(g.mesh, world)
+    owner = tiles.partition_subcatchments(g.mesh, world) if cut == "sub" else tiles.partition_trunk(g.mesh, world)
     _check_partitioned(g, world, chunk, pipe, owner)
 
 

@@ -60,12 +60,13 @@ def test_tiles_partition_cells_and_agree_on_boundary_series(world, mask):
             assert np.all(tiles.owner_of(P[a]["out_dst"], m.nrow, m.ncol, pr, pc) > a)
 
 
-@pytest.mark.parametrize("kind,world", [("d8", 3), ("d8", 5), ("ese", 4), ("d8", 8)])
-def test_subcatchment_partition_is_balanced_acyclic_and_agrees_on_boundary_series(kind, world):
+@pytest.mark.parametrize("kind,world,cut", [("d8", 3, "sub"), ("d8", 5, "sub"), ("ese", 4, "sub"), ("d8", 8, "sub"),
+                                             ("d8", 4, "trunk"), ("ese", 8, "trunk")])
+def test_subcatchment_partition_is_balanced_acyclic_and_agrees_on_boundary_series(kind, world, cut):
     """Arbitrary partitions (real catchments drain in all 8 directions, rectangles would give a cyclic rank graph):
     partition_subcatchments cuts the river tree; each part is a plan with an owner mask."""
     m = synth.make_mesh_d8(40, 56, ng=1, seed=3) if kind == "d8" else synth.make_mesh(48, 64, ng=1, mask_corner=True)
-    owner = tiles.partition_subcatchments(m, world)
+    owner = tiles.partition_subcatchments(m, world) if cut == "sub" else tiles.partition_trunk(m, world)
     act = np.asarray(m.active_cell) == 1
     assert np.all(owner[act] >= 0) and np.all(owner[~act] == -1)
     sizes = np.bincount(owner[act], minlength=world)
@@ -78,10 +79,14 @@ def test_subcatchment_partition_is_balanced_acyclic_and_agrees_on_boundary_serie
     P = [probe(m, None, owner_mask=(owner == r)) for r in range(world)]
     assert [p["cells"] for p in P] == sizes.tolist()
     n_cross = int(np.count_nonzero(oc[ds[src]] != oc[src]))
+    if cut == "trunk":                                                              # two levels: leaves -> trunk
+        assert np.all(oc[ds[src]][oc[ds[src]] != oc[src]] == world - 1)
     assert sum(p["n_out"] for p in P) == sum(p["n_in"] for p in P) == n_cross > 0
     for a in range(world):
         own = of[P[a]["out_dst"]] if P[a]["n_out"] else np.zeros(0, int)
         assert np.all(own > a)
+        if cut == "trunk":
+            assert (P[a]["n_in"] == 0) == (a < world - 1) and np.all(own == world - 1)
         assert np.all(of[P[a]["out_src"]] == a) and np.all(of[P[a]["in_dst"]] == a)
         for b in np.unique(own):
             sel = own == b
