@@ -377,6 +377,7 @@ subroutine base_forward(setup, mesh, input_data, parameters, parameters_bgd, sta
     type(c_ptr) :: qs, qdom, pdom
     integer(c_int) :: sp_flag
 
+    !$omp critical (smashx_gpu)
     call smashx_prepare(setup, mesh, input_data)
     call smashx_pack_parameters(parameters, cp)
     call smashx_pack_parameters(parameters_bgd, cpb)
@@ -411,6 +412,7 @@ subroutine base_forward(setup, mesh, input_data, parameters, parameters_bgd, sta
     output%cost = cc%cost
     output%cost_jobs = cc%cost_jobs
     output%cost_jreg = cc%cost_jreg
+    !$omp end critical (smashx_gpu)
 
 end subroutine base_forward
 
@@ -448,6 +450,7 @@ subroutine base_forward_b(setup, mesh, input_data, parameters, parameters_b, par
     type(smashx_costs) :: cc
     type(c_ptr) :: qs
 
+    !$omp critical (smashx_gpu)
     call smashx_prepare(setup, mesh, input_data)
     call smashx_pack_parameters(parameters, cp)
     call smashx_pack_parameters(parameters_bgd, cpb)
@@ -462,6 +465,7 @@ subroutine base_forward_b(setup, mesh, input_data, parameters, parameters_b, par
     output%cost = cc%cost
     output%cost_jobs = cc%cost_jobs
     output%cost_jreg = cc%cost_jreg
+    !$omp end critical (smashx_gpu)
 
 end subroutine base_forward_b
 
@@ -502,6 +506,7 @@ subroutine base_forward_d(setup, mesh, input_data, parameters, parameters_d, par
     type(c_ptr) :: qs, qd
     real(c_float) :: cd
 
+    !$omp critical (smashx_gpu)
     call smashx_prepare(setup, mesh, input_data)
     call smashx_pack_parameters(parameters, cp)
     call smashx_pack_parameters(parameters_d, cpd)
@@ -523,6 +528,7 @@ subroutine base_forward_d(setup, mesh, input_data, parameters, parameters_d, par
     output%cost = cc%cost
     output%cost_jobs = cc%cost_jobs
     output%cost_jreg = cc%cost_jreg
+    !$omp end critical (smashx_gpu)
 
 end subroutine base_forward_d
 
@@ -564,6 +570,7 @@ subroutine base_hyper_forward(setup, mesh, input_data, parameters, hyper_paramet
     type(smashx_costs) :: cc
     type(c_ptr) :: qs
 
+    !$omp critical (smashx_gpu)
     call hyper_parameters_to_parameters(hyper_parameters, parameters, setup, mesh, input_data)
     call hyper_states_to_states(hyper_states, states, setup, mesh, input_data)
     call smashx_prepare(setup, mesh, input_data, .true.)
@@ -577,6 +584,7 @@ subroutine base_hyper_forward(setup, mesh, input_data, parameters, hyper_paramet
     cost = cc%cost
     output%cost = cc%cost
     output%cost_jobs = cc%cost_jobs
+    !$omp end critical (smashx_gpu)
 
 end subroutine base_hyper_forward
 
@@ -617,6 +625,7 @@ subroutine base_hyper_forward_b(setup, mesh, input_data, parameters, parameters_
     type(smashx_costs) :: cc
     type(c_ptr) :: qs
 
+    !$omp critical (smashx_gpu)
     call hyper_parameters_to_parameters(hyper_parameters, parameters, setup, mesh, input_data)
     call hyper_states_to_states(hyper_states, states, setup, mesh, input_data)
     call smashx_prepare(setup, mesh, input_data, .true.)
@@ -649,6 +658,7 @@ subroutine base_hyper_forward_b(setup, mesh, input_data, parameters, parameters_
     call set_hyper_states(setup, hyper_states_b, 0._sp)
     call hyper_states_to_states_b(hyper_states, hyper_states_b, states, states_b, setup, mesh, input_data)
     call hyper_parameters_to_parameters_b(hyper_parameters, hyper_parameters_b, parameters, parameters_b, setup, mesh, input_data)
+    !$omp end critical (smashx_gpu)
 
 end subroutine base_hyper_forward_b
 
@@ -690,6 +700,7 @@ subroutine base_hyper_forward_d(setup, mesh, input_data, parameters, parameters_
     type(c_ptr) :: qs, qd
     real(c_float) :: cd
 
+    !$omp critical (smashx_gpu)
     call hyper_parameters_to_parameters_d(hyper_parameters, hyper_parameters_d, parameters, parameters_d, setup, mesh, input_data)
     call hyper_states_to_states_d(hyper_states, hyper_states_d, states, states_d, setup, mesh, input_data)
     call smashx_prepare(setup, mesh, input_data, .true.)
@@ -722,5 +733,6 @@ subroutine base_hyper_forward_d(setup, mesh, input_data, parameters, parameters_
     cost = cc%cost
     output%cost = cc%cost
     output%cost_jobs = cc%cost_jobs
+    !$omp end critical (smashx_gpu)
 
 end subroutine base_hyper_forward_d
