@@ -290,10 +290,33 @@ def main_lbfgsb():
     print("lbfgsb costs:", costs)
 
 
+def main_lbfgsb_cance():
+    """The user guide's distributed calibration (doc/source/user_guide/quickstart/real_case_cance.rst:470-552) on the real
+    Cance data: optimize_lbfgsb over cp, cft, exc, lr from the uniform SBS optimum, nse at the downstream gauge; cost after
+    0..6 iterations of the all-CPU reference."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import golden_util as gu
+    g = gu.load("gr_a_cance_28x28x1440")
+    op = np.zeros(16, np.int32)
+    op[[1, 3, 6, 15]] = 1
+    d = dict(optim_parameters=op, maxiters=np.array([0, 1, 2, 4, 6]))
+    costs = []
+    for it in d["maxiters"]:
+        r = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, optimize_maxiter=int(it),
+                        optim_parameters=op, **g.opts)
+        costs.append(r["cost"])
+    d["costs"] = np.array(costs, np.float32)
+    for k in ("cp", "cft", "exc", "lr"):
+        d["final_" + k] = r["parameters"][k]
+    np.savez_compressed(os.path.join(OUT, "lbfgsb", "opt_gr_a_cance.npz"), **d)
+    print("lbfgsb cance costs:", costs)
+
+
 if __name__ == "__main__":
     main()                              # python make_golden.py [case names...]: only those cases
     if not [a for a in sys.argv[1:] if not a.startswith("-")]:
         os.makedirs(os.path.join(OUT, "lbfgsb"), exist_ok=True)
         main_lbfgsb()
+        main_lbfgsb_cance()
         main_tangent()
         main_hyper()

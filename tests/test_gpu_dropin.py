@@ -65,6 +65,23 @@ def test_reference_lbfgsb_loop_through_dropin():
     assert abs(costs[-1] - ref[-1]) <= 0.02 * abs(ref[0]), (costs, ref)
 
 
+def test_reference_lbfgsb_on_cance_through_dropin():
+    """The user guide's distributed calibration on the real Cance data (real_case_cance.rst:470-552): the reference's
+    optimize_lbfgsb over cp, cft, exc, lr from the uniform SBS optimum, GPU sweeps through the drop-in, against the
+    all-CPU reference's cost trajectory (tests/golden/lbfgsb/opt_gr_a_cance.npz)."""
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "opt_gr_a_cance.npz"))
+    g = gu.load("gr_a_cance_28x28x1440")
+    costs = []
+    for it in z["maxiters"]:
+        r = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, optimize_maxiter=int(it),
+                        optim_parameters=z["optim_parameters"], fast="dropin", **g.opts)
+        costs.append(r["cost"])
+    ref = z["costs"]
+    assert abs(costs[0] - ref[0]) <= 3e-7 + 1e-5 * abs(ref[0]), (costs, ref)
+    assert costs[-1] < costs[0]
+    assert abs(costs[-1] - ref[-1]) <= 0.02 * abs(ref[0]), (costs, ref)
+
+
 @pytest.mark.parametrize("name", ["gr_b_16x16x96_nse_gaps", "gr_b_24x24x120_norm_jreg"])
 def test_reference_forward_d_through_dropin(name):
     """mw_forward::forward_d of the reference (mw_forward.f90:70-97) on the GPU tangent sweep: base_forward_d replaced by

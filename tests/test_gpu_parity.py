@@ -261,6 +261,24 @@ def test_optimize_lbfgsb_python_host():
     assert np.all(par.cp > 1.0)          # calibrated fields come back denormalised
 
 
+def test_optimize_lbfgsb_python_host_on_cance():
+    """The same loop on the real Cance data (distributed calibration of the user guide, real_case_cance.rst:470-552)."""
+    import os
+    import smash_amd
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "opt_gr_a_cance.npz"))
+    g = gu.load("gr_a_cance_28x28x1440")
+    costs = []
+    for it in (1, 6):
+        setup, mesh, inp, par, sta, out = _types(g)
+        setup.optimize.optim_parameters = np.asarray(z["optim_parameters"], np.int32)
+        setup.optimize.maxiter = it
+        h = smash_amd.optimize_lbfgsb(setup, mesh, inp, par, sta, out)
+        costs.append(h["final_cost"])
+    ref = z["costs"]
+    assert abs(costs[0] - ref[1]) <= 3e-7 + 1e-5 * abs(ref[1]), (costs, ref)
+    assert abs(costs[1] - ref[4]) <= 0.02 * abs(ref[0]), (costs, ref)
+
+
 @pytest.mark.parametrize("case", ["nt5", "thin", "allgap", "one_cell", "no_gauge"])
 def test_edge_cases_vs_oracle(case):
     """Ragged sizes the kernels' blocking must survive (steps not a multiple of 4, a 1-row grid, a single active cell),
