@@ -327,3 +327,28 @@ def scalar_product_test(setup, mesh, input_data, parameters, states, output):
               states.copy(), states.copy(), output, out_b, 0.0, 1.0)
     sp2 = float(sum(np.sum(getattr(par_b, k).astype(np.float64) * getattr(par_d, k)) for k in PARAM_NAMES))
     return 1.0 * cost_d, sp2
+
+
+def gradient_test(setup, mesh, input_data, parameters, states, output, nstep=16):
+    """mw_adjoint_test::gradient_test (mw_adjoint_test.f90:108-189): Ia = (Y(k + a dk) - Y(k)) / (a dk* . dk) for dk = 1 on
+    every parameter field and a = 2^0 .. 2^-(nstep-1); Y = cost of a forward sweep, dk* = parameters_b of one adjoint sweep.
+    Returns [(a, |Ia - 1|), ...] (the reference prints them)."""
+    from .types import OutputDT
+    bgd_p, bgd_s = parameters.copy(), states.copy()
+    yk = np.float32(forward(setup, mesh, input_data, parameters.copy(), bgd_p, states.copy(), bgd_s, output))
+    par_b, sta_b = parameters.copy(), states.copy()
+    forward_b(setup, mesh, input_data, parameters.copy(), par_b, bgd_p, parameters.copy(), states.copy(), sta_b, bgd_s, states.copy(),
+              output, OutputDT(setup, mesh), 0.0, 1.0)
+    dot = np.float32(0.0)
+    for k in PARAM_NAMES:                      # sum(parameters_b_matrix * dk), fp32 like the reference
+        dot = np.float32(dot + np.sum(getattr(par_b, k), dtype=np.float32))
+    res = []
+    for n in range(nstep):
+        an = np.float32(2.0 ** (-n))
+        p = bgd_p.copy()
+        for k in PARAM_NAMES:
+            getattr(p, k)[...] = getattr(bgd_p, k) + an
+        yadk = np.float32(forward(setup, mesh, input_data, p, bgd_p, states.copy(), bgd_s, output))
+        ian = np.float32((yadk - yk) / (an * dot))
+        res.append((float(an), float(abs(ian - np.float32(1.0)))))
+    return res

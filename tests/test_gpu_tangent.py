@@ -67,3 +67,27 @@ def test_tangent_across_storage_chunks():
         _, cost_d = smash_amd.forward_d(setup, mesh, inp, par, par_d, inp._bgd[0], par.copy(), sta, sta_d, inp._bgd[1], sta.copy(), out, out_d)
         res.append((cost_d, out_d.qsim.copy(), out.qsim.copy()))
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+
+
+def test_gradient_test_api():
+    """smash_amd.gradient_test = mw_adjoint_test::gradient_test (mw_adjoint_test.f90:108-189): the finite-difference ratio
+    Ia of GPU forward sweeps against the GPU adjoint along dk = 1 goes to 1 in the mid range of a (large a: nonlinearity,
+    small a: fp32 cancellation), and agrees with the same ratios formed from the CPU oracle's costs and gradient."""
+    import smash_amd
+    from oracle import pyoracle
+    g = gu.load("gr_b_16x16x96_nse_gaps")
+    setup, mesh, inp, par, sta, out = _types(g)
+    res = smash_amd.gradient_test(setup, mesh, inp, par, sta, out, nstep=12)
+    assert [a for a, _ in res] == [2.0 ** -n for n in range(12)]
+    e = [x for _, x in res]
+    assert all(e[i + 1] < 0.6 * e[i] for i in range(5)), res          # first order in a
+    assert min(e) < 1e-2, res                                         # down to the fp32 floor of (Y(k + a dk) - Y(k))
+    P = {k: np.asarray(getattr(par, k)) for k in g.params}
+    S = {k: np.asarray(getattr(sta, k)) for k in g.states}
+    ob = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, P, S, adjoint=True, **g.opts)
+    dot = sum(float(np.sum(v.astype(np.float64))) for v in ob["parameters_b"].values())
+    for a, e in res[0:6]:
+        Pa = {k: (v + np.float32(a)).astype(np.float32) for k, v in P.items()}
+        oa = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, Pa, S, **g.opts)
+        ia = (oa["cost"] - ob["cost"]) / (a * dot)
+        assert abs(abs(ia - 1.0) - e) <= 3e-3, (a, e, ia)
