@@ -149,6 +149,23 @@ __global__ void sx_k_prep_routing(SxDeviceArrays A) {
     A.rt_denb[k] = 0.001f * (A.dx * A.dx) * f;
 }
 
+// load / store of one float at (wave-uniform row pointer) + (per-lane byte offset < 2^31): buffer instruction with the
+// row as its scalar resource, so the row advance is scalar-unit work and the vector unit sees no address arithmetic
+__device__ __forceinline__ float sx_row_load(const float* row, unsigned byte_off) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void sx_row_store4(float* row, unsigned byte_off, float a, float b, float c, float d) {
+    typedef int sx_v4i __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
+    sx_v4i v = {__builtin_bit_cast(int, a), __builtin_bit_cast(int, b), __builtin_bit_cast(int, c), __builtin_bit_cast(int, d)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void sx_row_store(float* row, unsigned byte_off, float v) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, byte_off, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // vertical forward: one thread per cell marches the time chunk [t0, t0+T)
 // ------------------------------------------------------------------------------------------------
@@ -173,11 +190,12 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
     hft = A.hft[k];
     if (ST == 3) hst = A.hst[k];
 
-    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
-    const float* pet_p = A.pet + (size_t)t0 * npad + k;
-    float4* qt4 = reinterpret_cast<float4*>(A.qtT) + k;
+    // rows are wave-uniform (sx_row_load / sx_row_store): the vector unit does no address arithmetic in the time loop
+    const unsigned kb = (unsigned)k * 4u;
+    const float* prcp_r = A.prcp + (size_t)t0 * npad;
+    const float* pet_r = A.pet + (size_t)t0 * npad;
     float prcp_n = 0.f, pet_n = 0.f;
-    if (T > 0) { prcp_n = prcp_p[0]; pet_n = pet_p[0]; }
+    if (T > 0) { prcp_n = sx_row_load(prcp_r, kb); pet_n = sx_row_load(pet_r, kb); }
     for (int tq = 0; tq * 4 < T; ++tq) {
         float q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -186,18 +204,20 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
             if (tt < T) {
                 float prcp = prcp_n, pet = pet_n;
                 sx_pin1(prcp); sx_pin1(pet);     // the wait for this step's forcing goes here, before the next loads
-                if (tt + 1 < T) { prcp_n = prcp_p[(size_t)(tt + 1) * npad]; pet_n = pet_p[(size_t)(tt + 1) * npad]; }
+                if (tt + 1 < T) {
+                    prcp_n = sx_row_load(prcp_r + (size_t)(tt + 1) * npad, kb); pet_n = sx_row_load(pet_r + (size_t)(tt + 1) * npad, kb);
+                }
                 if (TAPE) {
-                    const size_t o = (size_t)tt * npad + k;
-                    if (ST == 2 || ST == 3) A.tape_hi[o] = hi;
-                    A.tape_hp[o] = hp;
-                    A.tape_hft[o] = hft;
-                    if (ST == 3) A.tape_hst[o] = hst;
+                    const size_t o = (size_t)tt * npad;
+                    if (ST == 2 || ST == 3) sx_row_store(A.tape_hi + o, kb, hi);
+                    sx_row_store(A.tape_hp + o, kb, hp);
+                    sx_row_store(A.tape_hft + o, kb, hft);
+                    if (ST == 3) sx_row_store(A.tape_hst + o, kb, hst);
                 }
                 q[i] = sx_vertical_step<ST>(P, prcp, pet, hi, hp, hft, hst);
             }
         }
-        qt4[(size_t)tq * npad] = make_float4(q[0], q[1], q[2], q[3]);
+        sx_row_store4(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
     }
     if (ST == 2 || ST == 3) A.hi[k] = hi;
     A.hp[k] = hp;
@@ -762,17 +782,17 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDevi
     G.hft_b = A.hft_b[k];
     G.hst_b = (ST == 3) ? A.hst_b[k] : 0.f;
     // one-step-ahead software prefetch of everything a step reads (forcing, taped levels, qt_b)
-    const float* qtb = A.qtT + (size_t)k * 4;
-    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
-    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    // addresses = wave-uniform row (buffer descriptor in scalar registers, advanced by the scalar unit) + the cell's 32-bit
+    // byte offset: no vector address arithmetic in the time loop
+    const unsigned kb = (unsigned)k * 4u;
     float n_prcp = 0.f, n_pet = 0.f, n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
     auto fetch = [&](int tt) {
-        const size_t o = (size_t)tt * npad;
-        n_prcp = prcp_p[o]; n_pet = pet_p[o];
-        if (ST == 2 || ST == 3) n_hi = A.tape_hi[o + k];
-        n_hp = A.tape_hp[o + k]; n_hft = A.tape_hft[o + k];
-        if (ST == 3) n_hst = A.tape_hst[o + k];
-        n_q = qtb[(size_t)(tt >> 2) * npad * 4 + (tt & 3)];
+        const size_t o = (size_t)tt * npad, of = (size_t)(t0 + tt) * npad;
+        n_prcp = sx_row_load(A.prcp + of, kb); n_pet = sx_row_load(A.pet + of, kb);
+        if (ST == 2 || ST == 3) n_hi = sx_row_load(A.tape_hi + o, kb);
+        n_hp = sx_row_load(A.tape_hp + o, kb); n_hft = sx_row_load(A.tape_hft + o, kb);
+        if (ST == 3) n_hst = sx_row_load(A.tape_hst + o, kb);
+        n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
     };
     if (T > 0) fetch(T - 1);
     for (int tt = T - 1; tt >= 0; --tt) {
