@@ -154,6 +154,7 @@ struct smashx_plan {
     hipStream_t stream = nullptr;    // vertical kernels, uploads/downloads ("V stream")
     hipStream_t stream_r = nullptr;  // routing + cost kernels ("R stream"); overlaps the V stream chunk by chunk
     int Tp = 0;                      // pipeline sub-chunk length inside a storage chunk
+    int Tpa = 0;                     // ... of the reverse sweep (routing adjoint of sub-chunk j-1 under the vertical adjoint of j)
     int chain_from = 1;              // first chained round
     bool split_v = false;            // SMASHX_SPLIT_V=1: vertical kernels in two cell ranges so that routing round 0 overlaps the second.
                                      // Measured slower (185 vs 175 ms at 1024^2 x 8760: both kernels lose more than the overlap hides): off.
@@ -273,6 +274,11 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
             int want = p->cfg.pipe_steps > 0 ? p->cfg.pipe_steps : Tc;
             const int nsub = std::max(1, (Tc + want / 2) / want);
             p->Tp = std::min(Tc, ((Tc + nsub - 1) / nsub + 15) / 16 * 16);
+            p->Tpa = p->Tp;
+            if (const char* e = getenv("SMASHX_PIPE_ADJ")) {
+                const int wa = atoi(e);
+                if (wa > 0 && !p->tiled) { const int na = std::max(1, (Tc + wa / 2) / wa); p->Tpa = std::min(Tc, ((Tc + na - 1) / na + 15) / 16 * 16); }
+            }
         }
         int rc;
         if ((rc = p->dmalloc(&p->A.qtT, (size_t)p->npad * Tc))) return rc;
@@ -994,8 +1000,8 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
                 if ((rc = restore_states(p, src))) return rc;
                 if ((rc = forward_chunk(c, true))) return rc;
             }
-            for (int jb = nsub_of(Tcur) - 1; jb >= 0; --jb) {
-                const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
+            for (int jb = (Tcur + p->Tpa - 1) / p->Tpa - 1; jb >= 0; --jb) {
+                const int off = jb * p->Tpa, T = std::min(p->Tpa, Tcur - off);
                 if (halo && p->n_out > 0) {
                     if ((rc = hook(2, t0c + off, T))) return rc;  // out_buf now holds the downstream tiles' adjoint contributions
                     halo_move(false, true, off, T);
