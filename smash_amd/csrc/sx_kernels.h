@@ -46,6 +46,31 @@ __device__ __forceinline__ float4 sx_gload4(const float4* p) {
     return *p;
 #endif
 }
+// streaming variants (SX_R_NT: 1 = loads, 2 = stores, 3 = both) for the cell-indexed arrays of the routing kernels (qt, hr tape,
+// qt_b): read once / written once per pass.  Never for the exchange rows (xT), which neighbouring groups re-read through L2.
+// Measured at 1024^2 x 8760 (sweep 172.8 ms with 0): loads 175.3, stores 181.1 (route_fwd 24.8 -> 33.6 ms), both 180.9 -> off.
+#ifndef SX_R_NT
+#define SX_R_NT 0
+#endif
+__device__ __forceinline__ float4 sx_gload4s(const float4* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SX_R_NT & 1) {
+        const sx_f4v v = __builtin_nontemporal_load((const __attribute__((address_space(1))) sx_f4v*)p);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+#endif
+    return sx_gload4(p);
+}
+__device__ __forceinline__ void sx_gstore4s(float4* p, const float4& q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (SX_R_NT & 2) {
+        sx_f4v v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
+        __builtin_nontemporal_store(v, (__attribute__((address_space(1))) sx_f4v*)p);
+        return;
+    }
+#endif
+    *p = q;
+}
 __device__ __forceinline__ float sx_gload1(const float* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return *(const __attribute__((address_space(1))) float*)p;
@@ -151,19 +176,26 @@ __global__ void sx_k_prep_routing(SxDeviceArrays A) {
 
 // load / store of one float at (wave-uniform row pointer) + (per-lane byte offset < 2^31): buffer instruction with the
 // row as its scalar resource, so the row advance is scalar-unit work and the vector unit sees no address arithmetic
+// AUX = cache-policy bits (gfx94x/gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Measured at 1024^2 x 8760: nt on the forward kernel's
+// stream (forcing in, tapes and qt out) 42.0 -> 41.1 ms; nt on the reverse kernel's loads 76.4 -> 78.7 ms, so only the
+// forward kernel uses it.
+#define SX_NT 2
+template <int AUX = 0>
 __device__ __forceinline__ float sx_row_load(const float* row, unsigned byte_off) {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void sx_row_store4(float* row, unsigned byte_off, float a, float b, float c, float d) {
     typedef int sx_v4i __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
     sx_v4i v = {__builtin_bit_cast(int, a), __builtin_bit_cast(int, b), __builtin_bit_cast(int, c), __builtin_bit_cast(int, d)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void sx_row_store(float* row, unsigned byte_off, float v) {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, byte_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, byte_off, 0, AUX);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
     const float* prcp_r = A.prcp + (size_t)t0 * npad;
     const float* pet_r = A.pet + (size_t)t0 * npad;
     float prcp_n = 0.f, pet_n = 0.f;
-    if (T > 0) { prcp_n = sx_row_load(prcp_r, kb); pet_n = sx_row_load(pet_r, kb); }
+    if (T > 0) { prcp_n = sx_row_load<SX_NT>(prcp_r, kb); pet_n = sx_row_load<SX_NT>(pet_r, kb); }
     for (int tq = 0; tq * 4 < T; ++tq) {
         float q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -205,19 +237,19 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
                 float prcp = prcp_n, pet = pet_n;
                 sx_pin1(prcp); sx_pin1(pet);     // the wait for this step's forcing goes here, before the next loads
                 if (tt + 1 < T) {
-                    prcp_n = sx_row_load(prcp_r + (size_t)(tt + 1) * npad, kb); pet_n = sx_row_load(pet_r + (size_t)(tt + 1) * npad, kb);
+                    prcp_n = sx_row_load<SX_NT>(prcp_r + (size_t)(tt + 1) * npad, kb); pet_n = sx_row_load<SX_NT>(pet_r + (size_t)(tt + 1) * npad, kb);
                 }
                 if (TAPE) {
                     const size_t o = (size_t)tt * npad;
-                    if (ST == 2 || ST == 3) sx_row_store(A.tape_hi + o, kb, hi);
-                    sx_row_store(A.tape_hp + o, kb, hp);
-                    sx_row_store(A.tape_hft + o, kb, hft);
-                    if (ST == 3) sx_row_store(A.tape_hst + o, kb, hst);
+                    if (ST == 2 || ST == 3) sx_row_store<SX_NT>(A.tape_hi + o, kb, hi);
+                    sx_row_store<SX_NT>(A.tape_hp + o, kb, hp);
+                    sx_row_store<SX_NT>(A.tape_hft + o, kb, hft);
+                    if (ST == 3) sx_row_store<SX_NT>(A.tape_hst + o, kb, hst);
                 }
                 q[i] = sx_vertical_step<ST>(P, prcp, pet, hi, hp, hft, hst);
             }
         }
-        sx_row_store4(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
+        sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
     }
     if (ST == 2 || ST == 3) A.hi[k] = hi;
     A.hp[k] = hp;
@@ -437,7 +469,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
     const int* wprog = nullptr;
     int seen = 0;
     if (CHAIN && xin >= 0) { const int pg = A.x_prod[xin]; if (pg >= g0 && pg < gend) wprog = A.prog + pg; }
-    auto fetch = [&](int tb) -> float4 { return sx_gload4(src + (size_t)tb * sstride); };
+    auto fetch = [&](int tb) -> float4 { return cell >= 0 ? sx_gload4s(src + (size_t)tb * sstride) : sx_gload4(src + (size_t)tb * sstride); };
 
     float4 nxt[SX_MU], outq[SX_MU], outh[SX_MU], nhr[SX_MU];
     if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - stage, nb), seen, A.prog + A.ngroups);
@@ -463,7 +495,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
                 const int tb = SX_MU * (mw - 1) + u - stage;
                 if (tb >= 0 && tb < nb) {
                     if (xout >= 0) x4[(size_t)tb * A.nx + xout] = outq[u];
-                    if (TAPE) hr4[(size_t)tb * A.npad + cell] = outh[u];
+                    if (TAPE) sx_gstore4s(hr4 + (size_t)tb * A.npad + cell, outh[u]);
                     if (A.qdT) reinterpret_cast<float4*>(A.qdT)[(size_t)tb * A.npad + cell] = outq[u];
                     if (gid >= 0) {
                         const float qv[4] = {outq[u].x, outq[u].y, outq[u].z, outq[u].w};
@@ -642,7 +674,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
         const int tbr = u - rstage;
         const int tb = nb - 1 - tbr;
         const bool ok = valid && tbr >= 0 && tbr < nb;
-        nhr[u] = (ok && cell >= 0) ? sx_gload4(hr4p + (size_t)tb * A.npad + cell) : zero4;
+        nhr[u] = (ok && cell >= 0) ? sx_gload4s(hr4p + (size_t)tb * A.npad + cell) : zero4;
         nin[u] = (ok && root_in) ? fetch_in(tb) : zero4;
         nsd[u] = ok ? load_seed(tb) : zero4;
         outq[u] = zero4;
@@ -663,7 +695,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
                 const int tbr = SX_MU * (mw - 1) + u - rstage;
                 if (tbr >= 0 && tbr < nb) {
                     const int tb = nb - 1 - tbr;
-                    if (cell >= 0) qt4[(size_t)tb * A.npad + cell] = outq[u];
+                    if (cell >= 0) sx_gstore4s(qt4 + (size_t)tb * A.npad + cell, outq[u]);
                     else x4[(size_t)tb * A.nx + xin] = outq[u];
                 }
             }
@@ -675,7 +707,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, 
             const int tbr = SX_MU * (mw + 1) + u - rstage;
             const int tb = nb - 1 - tbr;
             const bool ok = valid && tbr >= 0 && tbr < nb;
-            nhr[u] = (ok && cell >= 0) ? sx_gload4(hr4p + (size_t)tb * A.npad + cell) : zero4;
+            nhr[u] = (ok && cell >= 0) ? sx_gload4s(hr4p + (size_t)tb * A.npad + cell) : zero4;
             nin[u] = (ok && root_in) ? fetch_in(tb) : zero4;
             nsd[u] = ok ? load_seed(tb) : zero4;
         }
