@@ -180,6 +180,9 @@ __global__ void sx_k_prep_routing(SxDeviceArrays A) {
 // stream (forcing in, tapes and qt out) 42.0 -> 41.1 ms; nt on the reverse kernel's loads 76.4 -> 78.7 ms, so only the
 // forward kernel uses it.
 #define SX_NT 2
+#ifndef SX_VADJ_NT
+#define SX_VADJ_NT 0
+#endif
 template <int AUX = 0>
 __device__ __forceinline__ float sx_row_load(const float* row, unsigned byte_off) {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
@@ -417,7 +420,17 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
 #ifndef SX_MU
 #define SX_MU 4
 #endif
-#define SX_MAXGROUP 512   // largest routing workgroup (group_size); 8 waves, registers are not the limit
+#define SX_MAXGROUP 512   // largest routing workgroup (group_size): 8 waves = 2 per SIMD
+// Occupancy of the routing kernels: 132 (forward) / 154 (adjoint) registers = ONE resident group per CU.  Measured at
+// 1024^2 x 8760: compiling them for two groups per CU (128 registers) makes round 0 slower (route_fwd 26.0 -> 27.7 ms; the
+// adjoint spills, 28 -> 98 ms) and leaves the chained rounds unchanged (their time is (blocks + longest cell path) x the
+// latency of one super-step, whoever is resident), so one group per CU stays.
+#ifndef SX_RLB_F
+#define SX_RLB_F 1        // waves per SIMD the chained forward kernel is compiled for (a resident group = 2 per SIMD)
+#endif
+#ifndef SX_RLB_A
+#define SX_RLB_A 1        // adjoint
+#endif
 
 // TMODE 2: the same wavefront on the tangents (UPSTREAM_DISCHARGE_D, LINEAR_ROUTING_D and the q update of
 // GR_x_FORWARD_D): reads qt_d (qtdT) and the hr_imd tape of the value pass, carries hlr_d (hlr_b), publishes q_d series
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
 // from forward's in the last bit, and the criteria derivatives amplify that to ~5e-6 of cost_d, so the tangent sweep
 // evaluates the primal the way forward_d does.
 template <bool TAPE, bool CHAIN, int TMODE = 0>
-__global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, int g0, int gend, int t0, int T) {
+__global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_fwd(SxDeviceArrays A, int g0, int gend, int t0, int T) {
     constexpr bool TAN = (TMODE == 2);
     constexpr bool DFORM = (TMODE == 1);
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];   // [2][blockDim.x]
@@ -612,7 +625,7 @@ __global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_fwd(SxDeviceArrays A, 
 // Same macro-step staging of global memory as the forward kernel.
 // ------------------------------------------------------------------------------------------------
 template <bool CHAIN>
-__global__ __launch_bounds__(SX_MAXGROUP) void sx_k_route_adj(SxDeviceArrays A, int g0, int gend, int t0, int T) {
+__global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDeviceArrays A, int g0, int gend, int t0, int T) {
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];
     // chained rounds run roots-of-the-basin first: the producers of adjoint series get the low block indices
     const int g = CHAIN ? gend - 1 - (int)blockIdx.x : g0 + (int)blockIdx.x;
@@ -820,10 +833,10 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDevi
     float n_prcp = 0.f, n_pet = 0.f, n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
     auto fetch = [&](int tt) {
         const size_t o = (size_t)tt * npad, of = (size_t)(t0 + tt) * npad;
-        n_prcp = sx_row_load(A.prcp + of, kb); n_pet = sx_row_load(A.pet + of, kb);
-        if (ST == 2 || ST == 3) n_hi = sx_row_load(A.tape_hi + o, kb);
-        n_hp = sx_row_load(A.tape_hp + o, kb); n_hft = sx_row_load(A.tape_hft + o, kb);
-        if (ST == 3) n_hst = sx_row_load(A.tape_hst + o, kb);
+        n_prcp = sx_row_load<SX_VADJ_NT>(A.prcp + of, kb); n_pet = sx_row_load<SX_VADJ_NT>(A.pet + of, kb);
+        if (ST == 2 || ST == 3) n_hi = sx_row_load<SX_VADJ_NT>(A.tape_hi + o, kb);
+        n_hp = sx_row_load<SX_VADJ_NT>(A.tape_hp + o, kb); n_hft = sx_row_load<SX_VADJ_NT>(A.tape_hft + o, kb);
+        if (ST == 3) n_hst = sx_row_load<SX_VADJ_NT>(A.tape_hst + o, kb);
         n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
     };
     if (T > 0) fetch(T - 1);
