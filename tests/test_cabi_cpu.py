@@ -42,5 +42,4 @@ def test_product_does_not_import_the_oracle():
         for f in fs:
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
-                assert "oracle" not in txt.replace("the oracle", "").lower() or f == "synth.py" or True
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
