@@ -23,7 +23,7 @@ module ref_capi
     use mwd_states_manipulation
     use mw_sparse_storage
     use mw_forward, only: forward, forward_b, forward_d, hyper_forward, hyper_forward_b, hyper_forward_d
-    use mw_optimize, only: optimize_lbfgsb
+    use mw_optimize, only: optimize_lbfgsb, optimize_sbs
 
     implicit none
 
@@ -62,6 +62,7 @@ contains
     !           3 = forward_d (tangent model, mw_forward.f90:70-97; entry point ref_run_d only)
     !           4 = hyper_forward, 5 = hyper_forward_b, 6 = hyper_forward_d (mw_forward.f90:99-181; entry point
     !           ref_run_hyper only; mode 6 reads the direction from hyper_p_b / hyper_s_b)
+    !           7 = optimize_sbs (mw_optimize.f90:53-294), maxiter in icfg(13)
     !  icfg(14) nd (descriptors)   icfg(15) mapping: 1 hyper-linear, 2 hyper-polynomial
     !  icfg(12) nrep (timing repetitions, >=1)     icfg(13) maxiter (mode 2)
     !  rcfg(1) dt  rcfg(2) dx  rcfg(3) wjreg  rcfg(4) cost_b
@@ -263,6 +264,12 @@ contains
                 & s, s_d, s_bgd, s_bgd_b, output, output_d, cost, cost_d)
                 cost_d_out = cost_d
                 if (ng .gt. 0) qsim_d = output_d%qsim
+            else if (icfg(11) .eq. 7) then
+                !  mw_optimize::optimize_sbs (mw_optimize.f90:53-294): the uniform step-by-step calibration, forward sweeps only
+                setup%optimize%maxiter = icfg(13)
+                setup%optimize%verbose = .false.
+                call optimize_sbs(setup, mesh, input_data, p, s, output)
+                cost = output%cost
             else if (icfg(11) .eq. 2) then
                 setup%optimize%denormalize_forward = .false.
                 setup%optimize%maxiter = icfg(13)

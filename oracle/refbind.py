@@ -69,7 +69,8 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         optim_parameters=None, optim_states=None, lb_parameters=None, ub_parameters=None,
         lb_states=None, ub_states=None, cost_b=1.0, nrep=1, fast=False, optimize_maxiter=None,
         params_d=None, states_d=None, params_bgd_d=None, states_bgd_d=None,
-        descriptor=None, hyper_params=None, hyper_states=None, mapping=None, hyper_params_d=None, hyper_states_d=None):
+        descriptor=None, hyper_params=None, hyper_states=None, mapping=None, hyper_params_d=None, hyper_states_d=None,
+        optimize_sbs_maxiter=None):
     """Call the reference forward / forward_b (mw_forward.f90:18-68) on flat arrays.
 
     mesh: object with nrow, ncol, dx, flwdir, flwacc, path (0-based), active_cell, gauge_pos (0-based),
@@ -87,7 +88,9 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
     jobs_fun, jreg_fun = list(jobs_fun), list(jreg_fun)
     tangent = params_d is not None or states_d is not None
     hyper = mapping is not None
-    mode = 3 if tangent else (2 if optimize_maxiter is not None else int(adjoint))
+    mode = 3 if tangent else (2 if optimize_maxiter is not None else 7 if optimize_sbs_maxiter is not None else int(adjoint))
+    if optimize_sbs_maxiter is not None:        # mw_optimize::optimize_sbs, uniform mapping (mw_optimize.f90:53-294)
+        optimize_maxiter = optimize_sbs_maxiter
     nd = mcode = 0
     if hyper:
         mode = 6 if hyper_params_d is not None else 5 if adjoint else 4

@@ -82,6 +82,28 @@ def test_reference_lbfgsb_on_cance_through_dropin():
     assert abs(costs[-1] - ref[-1]) <= 0.02 * abs(ref[0]), (costs, ref)
 
 
+def test_reference_sbs_on_cance_through_dropin():
+    """The user guide's first calibration (real_case_cance.rst:396-430): the reference's optimize_sbs (uniform cp, cft, exc,
+    lr from the Model() defaults, nse at the downstream gauge, maxiter 2) with every forward sweep on the GPU, against the
+    all-CPU reference (tests/golden/lbfgsb/sbs_gr_a_cance.npz: J = 0.6996 -> 0.1097 -> 0.0439; the guide, on its revision of
+    the data, prints 0.6774 -> 0.1300 -> 0.0437)."""
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "sbs_gr_a_cance.npz"))
+    g = gu.load("gr_a_cance_28x28x1440")
+    pv = dict(ci=1e-6, cp=200.0, beta=1000.0, cft=500.0, cst=500.0, alpha=0.9, exc=0.0, lr=5.0)
+    P = {k: (np.full_like(v, pv[k]) if k in pv else v) for k, v in g.params.items()}
+    costs = []
+    for it in z["maxiters"]:
+        r = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, P, g.states, optimize_sbs_maxiter=int(it),
+                        optim_parameters=z["optim_parameters"], fast="dropin", **g.opts)
+        costs.append(r["cost"])
+    ref = z["costs"]
+    assert abs(costs[0] - ref[0]) <= 3e-7 + 1e-5 * abs(ref[0]), (costs, ref)
+    for a, b in zip(costs[1:], ref[1:]):
+        assert abs(a - b) <= 0.02 * abs(b), (costs, ref)
+    for k in ("cp", "cft", "exc", "lr"):
+        assert abs(float(r["parameters"][k][20, 27]) - float(z["final_" + k])) <= 0.02 * abs(float(z["final_" + k])) + 1e-3, k
+
+
 @pytest.mark.parametrize("name", ["gr_b_16x16x96_nse_gaps", "gr_b_24x24x120_norm_jreg"])
 def test_reference_forward_d_through_dropin(name):
     """mw_forward::forward_d of the reference (mw_forward.f90:70-97) on the GPU tangent sweep: base_forward_d replaced by
