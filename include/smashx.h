@@ -152,8 +152,12 @@ int smashx_forward_b(smashx_plan* plan, smashx_parameters* params, const smashx_
                      smashx_states* states, const smashx_states* states_bgd, float cost_b, float* qsim,
                      smashx_costs* costs, smashx_parameters* params_b, smashx_states* states_b);
 
-/* split-phase form of the two calls above, for measurement with inputs resident in HBM:
- * upload -> (sweep)* -> download.  adjoint = 0: forward sweep; 1: forward + cost + adjoint sweep. */
+/* split-phase form of the two calls above, for measurement with inputs resident in HBM and for calibration loops:
+ * upload -> (sweep)* -> download.  adjoint = 0: forward sweep; 1: forward + cost + adjoint sweep.
+ * After a first complete upload, a NULL field in params / states means "unchanged": only the fields the optimiser moved
+ * travel (var_to_control / control_to_var of mw_optimize.f90:679-777 touch only the optimised fields).  download skips NULL
+ * fields likewise; downloading parameters / states under denormalize_forward hands the caller denormalised fields and a
+ * complete upload is required again. */
 int smashx_upload(smashx_plan* plan, const smashx_parameters* params, const smashx_parameters* params_bgd,
                   const smashx_states* states, const smashx_states* states_bgd);
 int smashx_sweep(smashx_plan* plan, int adjoint, float cost_b);

@@ -795,7 +795,10 @@ int smashx_upload(smashx_plan* p, const smashx_parameters* params, const smashx_
     for (int i = 0; i < NPS; ++i) {
         const int f = param_field(st, i);
         if (f < 0) continue;
-        if (!params->f[f]) return fail(SMASHX_E_ARG, "a parameter field the structure uses is NULL");
+        if (!params->f[f]) {     // NULL = unchanged since the last upload (calibration loops move only the optimised fields)
+            if (!p->uploaded) return fail(SMASHX_E_ARG, "a parameter field the structure uses is NULL");
+            continue;
+        }
         HIPCHK(hipMemcpyAsync(p->d_fullP[f], params->f[f], (size_t)p->n2 * 4, hipMemcpyHostToDevice, p->stream));
         if (p->opt.denormalize_forward)
             hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullP[f], p->n2, p->opt.lb_parameters[f], p->opt.ub_parameters[f]);
@@ -804,7 +807,10 @@ int smashx_upload(smashx_plan* p, const smashx_parameters* params, const smashx_
     for (int i = 0; i < NSS; ++i) {
         const int f = state_field(st, i);
         if (f < 0) continue;
-        if (!states->f[f]) return fail(SMASHX_E_ARG, "a state field the structure uses is NULL");
+        if (!states->f[f]) {
+            if (!p->uploaded) return fail(SMASHX_E_ARG, "a state field the structure uses is NULL");
+            continue;
+        }
         HIPCHK(hipMemcpyAsync(p->d_fullS[f], states->f[f], (size_t)p->n2 * 4, hipMemcpyHostToDevice, p->stream));
         if (p->opt.denormalize_forward)
             hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullS[f], p->n2, p->opt.lb_states[f], p->opt.ub_states[f]);
@@ -1204,9 +1210,11 @@ int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smas
     // parameters / states as the reference leaves them (forward.f90:33-38,72; mwd_cost.f90:284-298):
     // denormalised; base_forward additionally sends them through normalise -> denormalise inside compute_cost.
     if (p->opt.denormalize_forward) {
+        bool touched = false;
         for (int i = 0; i < NPS; ++i) {
             const int f = param_field(st, i);
             if (f < 0 || !params || !params->f[f]) continue;
+            touched = true;
             if (!adjoint) {
                 hipLaunchKernelGGL(k_normalize, gfull, b, 0, p->stream, p->d_fullP[f], p->n2, p->opt.lb_parameters[f], p->opt.ub_parameters[f]);
                 hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullP[f], p->n2, p->opt.lb_parameters[f], p->opt.ub_parameters[f]);
@@ -1216,6 +1224,7 @@ int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smas
         for (int i = 0; i < NSS; ++i) {
             const int f = state_field(st, i);
             if (f < 0 || !states || !states->f[f]) continue;
+            touched = true;
             if (!adjoint) {
                 hipLaunchKernelGGL(k_normalize, gfull, b, 0, p->stream, p->d_fullS[f], p->n2, p->opt.lb_states[f], p->opt.ub_states[f]);
                 hipLaunchKernelGGL(k_denormalize, gfull, b, 0, p->stream, p->d_fullS[f], p->n2, p->opt.lb_states[f], p->opt.ub_states[f]);
@@ -1223,7 +1232,7 @@ int smashx_download(smashx_plan* p, int adjoint, smashx_parameters* params, smas
             HIPCHK(hipMemcpyAsync(states->f[f], p->d_fullS[f], (size_t)p->n2 * 4, hipMemcpyDeviceToHost, p->stream));
         }
         HIPCHK(hipStreamSynchronize(p->stream));
-        p->uploaded = false;   // the full-field copies were transformed: a new upload is required
+        if (touched) p->uploaded = false;   // the caller now holds denormalised fields: a full upload is required before the next sweep
     }
     if (adjoint) {
         if (!p->adj_ready) return fail(SMASHX_E_STATE, "no adjoint sweep has run");

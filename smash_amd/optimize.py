@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .solver import forward, forward_b
+from .solver import _solver_for, forward
 from .synth import PARAM_NAMES, STATE_NAMES
 
 
@@ -27,18 +27,63 @@ class _Stop(Exception):
     pass
 
 
+def _lbfgsb_box(fg, x0, m, factr, pgtol, maxiter, maxfun, callback):
+    """L-BFGS-B (Zhu-Byrd-Lu-Nocedal 3.0, scipy's build of the code the reference carries as lbfgsb.f) on the box [0, 1]^n.
+    scipy's fmin_l_bfgs_b walks the bounds in two Python loops over n before it starts -- tens of seconds for the 1.7e7 control
+    variables of a 2048 x 2048 grid -- so its driver loop (scipy/optimize/_lbfgsb_py.py::_minimize_lbfgsb, 1.15) is restated
+    here around the same setulb with the bound arrays built in one go.  Same iterates, bit for bit
+    (tests/test_cabi_cpu.py).  Other scipy versions go through fmin_l_bfgs_b itself.  Returns (x, f, info)."""
+    import scipy
+    from scipy.optimize import fmin_l_bfgs_b
+    n = x0.size
+    try:
+        from scipy.optimize import _lbfgsb
+        direct = tuple(int(v) for v in scipy.__version__.split(".")[:2]) == (1, 15) and hasattr(_lbfgsb, "setulb")
+    except Exception:  # pragma: no cover
+        direct = False
+    if not direct:  # pragma: no cover
+        return fmin_l_bfgs_b(fg, x0, m=m, factr=factr, pgtol=pgtol, bounds=[(0.0, 1.0)] * n, maxiter=maxiter, maxfun=maxfun,
+                             callback=callback)
+    x = np.clip(np.array(x0, dtype=np.float64), 0.0, 1.0)
+    nbd = np.full(n, 2, np.int32)                       # both bounds present
+    low, up = np.zeros(n, np.float64), np.ones(n, np.float64)
+    f = np.array(0.0, dtype=np.int32)
+    g = np.zeros(n, np.float64)
+    wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+    iwa = np.zeros(3 * n, np.int32)
+    task, ln_task, lsave = np.zeros(2, np.int32), np.zeros(2, np.int32), np.zeros(4, np.int32)
+    isave, dsave = np.zeros(44, np.int32), np.zeros(29, np.float64)
+    nit = nfev = 0
+    while True:
+        g = np.asarray(g, np.float64)
+        _lbfgsb.setulb(m, x, low, up, nbd, f, g, factr, pgtol, wa, iwa, task, lsave, isave, dsave, 20, ln_task)
+        if task[0] == 3:                                # f and g wanted at x
+            f, g = fg(np.copy(x))
+            nfev += 1
+        elif task[0] == 1:                              # new iterate
+            nit += 1
+            if callback is not None:
+                callback(np.copy(x))
+            if nit >= maxiter:
+                task[0], task[1] = 5, 504
+            elif nfev > maxfun:
+                task[0], task[1] = 5, 502
+        else:
+            break
+    msg = {4: "CONVERGENCE", 5: "STOP", 6: "WARNING", 7: "ERROR", 8: "ABNORMAL"}.get(int(task[0]), str(int(task[0])))
+    return x, float(f), {"task": f"{msg} ({int(task[1])})", "nit": nit, "funcalls": nfev, "grad": g}
+
+
 def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose=False):
     """In-place like the reference: parameters / states come back calibrated (denormalised), output holds the final run.
     Returns a dict with the cost trajectory.  setup.optimize.maxiter bounds the iterations (default 100)."""
-    from scipy.optimize import fmin_l_bfgs_b
     o = setup.optimize
     maxiter = int(getattr(o, "maxiter", 100))
     act = np.asarray(mesh.active_cell) == 1
-    cr = np.argwhere(act.T)                                # column outer, row inner
-    cols, rows = cr[:, 0], cr[:, 1]
+    mask_f = act.reshape(-1, order="F")                    # column outer, row inner = the reference's control-vector order
     pf = [k for i, k in enumerate(PARAM_NAMES) if o.optim_parameters[i] > 0]
     sf = [k for i, k in enumerate(STATE_NAMES) if o.optim_states[i] > 0]
-    m = len(rows)
+    m = int(np.count_nonzero(mask_f))
     n = m * (len(pf) + len(sf))
     if n == 0:
         raise ValueError("nothing to optimise: optim_parameters / optim_states are all zero")
@@ -47,19 +92,24 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
     _normalize(states, STATE_NAMES, o.lb_states, o.ub_states)
     par_bgd, sta_bgd = parameters.copy(), states.copy()
     par_b, sta_b = parameters.copy(), states.copy()
-    out_b = output.copy()
     was = o.denormalize_forward
     o.denormalize_forward = True
 
+    def flat(obj, k):
+        a = getattr(obj, k)
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.f_contiguous):
+            a = np.asfortranarray(a, dtype=np.float32)
+            setattr(obj, k, a)
+        return a.reshape(-1, order="F")                   # a view of the Fortran-ordered field
+
     def to_control(p, s):
-        return np.concatenate([getattr(p, k)[rows, cols].astype(np.float64) for k in pf] +
-                              [getattr(s, k)[rows, cols].astype(np.float64) for k in sf])
+        return np.concatenate([flat(p, k)[mask_f].astype(np.float64) for k in pf] + [flat(s, k)[mask_f].astype(np.float64) for k in sf])
 
     def to_var(x):
         for j, k in enumerate(pf):
-            a = getattr(parameters, k); a[rows, cols] = x[j * m:(j + 1) * m].astype(np.float32)
+            flat(parameters, k)[mask_f] = x[j * m:(j + 1) * m]
         for j, k in enumerate(sf):
-            a = getattr(states, k); a[rows, cols] = x[(len(pf) + j) * m:(len(pf) + j + 1) * m].astype(np.float32)
+            flat(states, k)[mask_f] = x[(len(pf) + j) * m:(len(pf) + j + 1) * m]
 
     def renormalize():
         _normalize(parameters, PARAM_NAMES, o.lb_parameters, o.ub_parameters)
@@ -67,17 +117,23 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
 
     hist = {"cost": [], "nfg": 0}
     x = to_control(parameters, states)
+    moved = set(pf + sf)
     try:
         forward(setup, mesh, input_data, parameters, par_bgd, states, sta_bgd, output, np.float32(0))
         renormalize()
         hist["cost_jobs_initial"], hist["cost_jreg_initial"] = output.cost_jobs, output.cost_jreg
         last = {}
+        # every evaluation is one forward_b with denormalize_forward on (mw_optimize.f90:590-606).  The plan keeps the fields
+        # that do not move on the device: an evaluation uploads the optimised fields only and brings back cost, discharge
+        # and the gradient of those fields -- nothing is denormalised and renormalised on the host in between.
+        sol = _solver_for(setup, mesh, input_data)
+        sol.upload(parameters, states, par_bgd, sta_bgd)
 
         def fg(xc):
             to_var(xc)
-            forward_b(setup, mesh, input_data, parameters, par_b, par_bgd, par_bgd.copy(), states, sta_b, sta_bgd, sta_bgd.copy(),
-                      output, out_b, np.float32(0), np.float32(1))
-            renormalize()
+            sol.upload(parameters, states, par_bgd, sta_bgd, only=moved)
+            sol.sweep(True, 1.0)
+            sol.download(True, None, None, output, par_b, sta_b, only_b=moved)
             hist["nfg"] += 1
             g = to_control(par_b, sta_b)
             last["f"], last["g"] = float(np.float32(output.cost)), g
@@ -93,8 +149,7 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
                 raise _Stop
 
         try:
-            x, f, info = fmin_l_bfgs_b(fg, x, m=10, factr=10.0, pgtol=1e-12, bounds=[(0.0, 1.0)] * n, maxiter=maxiter,
-                                       maxfun=10 * maxiter + 20, callback=cb)
+            x, f, info = _lbfgsb_box(fg, x, 10, 10.0, 1e-12, maxiter, 10 * maxiter + 20, cb)
             hist["task"] = str(info.get("task", ""))
         except _Stop:
             x = last["x"]

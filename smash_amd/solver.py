@@ -181,11 +181,11 @@ class Solver:
 
     # -- calls ---------------------------------------------------------------------------------
     @staticmethod
-    def _pack(obj, names, struct_cls):
+    def _pack(obj, names, struct_cls, only=None):
         s = struct_cls()
         keep = []
         for i, k in enumerate(names):
-            a = getattr(obj, k, None) if obj is not None else None
+            a = getattr(obj, k, None) if obj is not None and (only is None or k in only) else None
             if a is None:
                 s.f[i] = None
                 continue
@@ -196,9 +196,10 @@ class Solver:
             s.f[i] = a.ctypes.data
         return s, keep
 
-    def upload(self, parameters, states, parameters_bgd=None, states_bgd=None):
-        P, k1 = self._pack(parameters, PARAM_NAMES, _lib.Parameters)
-        S, k2 = self._pack(states, STATE_NAMES, _lib.States)
+    def upload(self, parameters, states, parameters_bgd=None, states_bgd=None, only=None):
+        """only = names of the fields that changed since the last upload (the others keep their device copies)."""
+        P, k1 = self._pack(parameters, PARAM_NAMES, _lib.Parameters, only)
+        S, k2 = self._pack(states, STATE_NAMES, _lib.States, only)
         PB, k3 = self._pack(parameters_bgd, PARAM_NAMES, _lib.Parameters) if parameters_bgd is not None else (None, None)
         SB, k4 = self._pack(states_bgd, STATE_NAMES, _lib.States) if states_bgd is not None else (None, None)
         _lib.check(_lib.lib().smashx_upload(self._h, C.byref(P), C.byref(PB) if PB is not None else None, C.byref(S),
@@ -212,10 +213,10 @@ class Solver:
         _lib.check(_lib.lib().smashx_get_timing(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _lib.Timing._fields_}
 
-    def download(self, adjoint, parameters, states, output, parameters_b=None, states_b=None):
+    def download(self, adjoint, parameters, states, output, parameters_b=None, states_b=None, only_b=None):
+        """parameters / states None: nothing but cost, discharge and gradients comes back; only_b = the gradient fields wanted."""
         P, k1 = self._pack(parameters, PARAM_NAMES, _lib.Parameters)
         S, k2 = self._pack(states, STATE_NAMES, _lib.States)
-        qsim = np.zeros((max(self.ng, 1), self.nt), np.float32, order="F")[: self.ng] if self.ng else None
         qs = np.zeros((self.ng, self.nt), np.float32, order="F") if self.ng else None
         costs = _lib.Costs()
         F = PB = SB = None
@@ -223,8 +224,8 @@ class Solver:
         if not adjoint and output is not None:
             F, kf = self._pack(output.fstates, STATE_NAMES, _lib.States)
         if adjoint:
-            PB, kp = self._pack(parameters_b, PARAM_NAMES, _lib.Parameters)
-            SB, ks = self._pack(states_b, STATE_NAMES, _lib.States)
+            PB, kp = self._pack(parameters_b, PARAM_NAMES, _lib.Parameters, only_b)
+            SB, ks = self._pack(states_b, STATE_NAMES, _lib.States, only_b)
         _lib.check(_lib.lib().smashx_download(self._h, int(bool(adjoint)), C.byref(P), C.byref(S), _ptr(qs), C.byref(costs),
                                               C.byref(F) if F is not None else None,
                                               C.byref(PB) if PB is not None else None,

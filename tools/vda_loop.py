@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[3]: the VDA L-BFGS-B loop (distributed mapping) on a 2048 x 2048 grid on one MI355X, timed.
+A year of hourly fp32 forcing on 2048^2 cells (294 GB) cannot be resident on one card: the loop runs on --nt steps
+(default 2190 = one quarter, 9.2e9 cell-steps per sweep).   python tools/vda_loop.py [--grid 2048 --nt 2190 --maxiter 3]"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=2048)
+    ap.add_argument("--nt", type=int, default=2190)
+    ap.add_argument("--maxiter", type=int, default=3)
+    a = ap.parse_args()
+    import smash_amd
+    import test_gpu_fullsize as tf
+    t0 = time.perf_counter()
+    sol, setup, mesh, par, sta = tf._problem(0, a.grid, a.nt)
+    out = smash_amd.OutputDT(setup, mesh)
+    inp = types.SimpleNamespace(qobs=np.asfortranarray(tf.sol_qobs(sol, setup, mesh, par, sta)), _smashx_solver=sol)
+    t_setup = time.perf_counter() - t0
+    op = np.zeros(16, np.int32)
+    op[[1, 3, 6, 15]] = 1
+    setup.optimize.optim_parameters = op
+    setup.optimize.maxiter = a.maxiter
+    sweeps = {"n": 0, "ms": 0.0}
+    orig = sol.sweep
+
+    def timed(adjoint=False, cost_b=1.0):
+        r = orig(adjoint, cost_b)
+        sweeps["n"] += 1
+        sweeps["ms"] += sol.timing()["sweep_ms"]
+        return r
+    sol.sweep = timed
+    t0 = time.perf_counter()
+    h = smash_amd.optimize_lbfgsb(setup, mesh, inp, par, sta, out)
+    wall = time.perf_counter() - t0
+    print(json.dumps({"grid": a.grid, "nt": a.nt, "control_variables": int(4 * sol.ncells), "iterations": len(h["cost"]),
+                      "nfg": h["nfg"], "cost": h["cost"], "final_cost": h["final_cost"], "loop_s": wall, "setup_s": t_setup,
+                      "gpu_sweeps": sweeps["n"], "gpu_sweep_s": sweeps["ms"] * 1e-3,
+                      "host_s": wall - sweeps["ms"] * 1e-3}))
+
+
+if __name__ == "__main__":
+    main()
