@@ -95,15 +95,20 @@ def test_subcatchment_partition_is_balanced_acyclic_and_agrees_on_boundary_serie
             assert np.array_equal(P[a]["out_dst"][sel], P[b]["in_dst"][src_b])
 
 
-def _gloo_worker(rank, world, port, q):
+def _gloo_worker(rank, world, port, q, cut="rect"):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         pr, pc = tiles.tile_grid(world)
-        m = synth.make_mesh(40, 56, ng=1)
-        me = probe(m, tiles.tile_rect(rank, m.nrow, m.ncol, pr, pc))
+        if cut == "rect":
+            m = synth.make_mesh(40, 56, ng=1)
+            me = probe(m, tiles.tile_rect(rank, m.nrow, m.ncol, pr, pc))
+        else:            # full-D8 flow field: every rank cuts the river tree the same way and owns one part
+            m = synth.make_mesh_d8(40, 56, ng=1, seed=3)
+            owner = tiles.partition_trunk(m, world)
+            me = probe(m, None, owner_mask=(owner == rank))
         if rank == 0:    # upstream tile: tell the peer which series it will send, in its own order
             assert me["n_in"] == 0 and me["n_out"] > 0
             dist.send(torch.tensor([me["n_out"]]), 1)
@@ -123,12 +128,13 @@ def _gloo_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_agree_over_gloo():
+@pytest.mark.parametrize("cut", ["rect", "trunk"])
+def test_two_ranks_agree_over_gloo(cut):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + (7 if cut == "trunk" else 0)
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q, cut)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(2))
