@@ -150,11 +150,69 @@ SX_HD void sx_pow_3p5_2p5(float h, float* p35, float* p25) {
     *p35 = (float)((d2 * d) * s); *p25 = (float)(d2 * s);
 }
 
-// expf / logf: fp64 evaluation, one rounding (glibc's float versions are correctly rounded in 99.94 %)
+// expf: fp64 evaluation, one rounding (glibc's float version is correctly rounded in 99.94 %)
 SX_HD float sx_expf(float x) { return (float)exp((double)x); }
-SX_HD float sx_logf(float x) { return (float)log((double)x); }
-// powf for the rare general call sites (gap branch) -- fp64 pow, one rounding
-SX_HD float sx_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+
+// logf / powf with run-time arguments (vic-a exponents 1/(b+1), b+1, ...; the logarithmic criterion; the gap branch of
+// gr_transfer).  Same contract as above -- an fp64 value within ~2^-45 of the true one, rounded once to fp32, i.e. the
+// correctly rounded result except when the true value lies within 2^-45 of a rounding boundary (glibc's own powf / logf
+// miss 6e-4 of the time) -- but evaluated by ~45 fp64 FMAs instead of the ~200 instructions of the double-precision
+// library pow:  log2 x = e + 2 atanh(s) / ln 2 with x = m 2^e, m in [sqrt(1/2), sqrt 2), s = (m-1)/(m+1);
+// x^y = 2^(y log2 x) with 2^t = 2^n exp(r ln 2), r = t - n in [-1/2, 1/2].   tests/test_sx_math.py checks both against the
+// double-precision library on a few million arguments (|error| < 2^-44 relative) and the fp32 results against glibc's.
+struct SxLog2 { double l2; int special; };   // special: 0 = finite x > 0, 1 = x == 0, 2 = x < 0 or NaN, 3 = +inf
+SX_HD SxLog2 sx_log2_d(float x) {
+    SxLog2 R; R.special = 0; R.l2 = 0.0;
+    if (!(x > 0.f)) { R.special = (x == 0.f) ? 1 : 2; return R; }
+    uint32_t u = sx_f2u(x);
+    if (u >= 0x7f800000u) { R.special = 3; return R; }
+    int e = 0;
+    if (u < 0x00800000u) { u = sx_f2u(x * 16777216.0f); e = -24; }      // subnormal
+    e += (int)(u >> 23) - 127;
+    float m = sx_u2f((u & 0x007fffffu) | 0x3f800000u);                  // [1, 2)
+    if (m > 1.41421356f) { m *= 0.5f; e += 1; }                          // [sqrt(1/2), sqrt 2)
+    const double f = (double)m - 1.0;                                    // exact
+    const double d = 2.0 + f;
+    double r = (double)sx_seed_rcp((float)d);
+    double t = fma(-d, r, 1.0); r = fma(r, t, r);
+    t = fma(-d, r, 1.0); r = fma(r, t, r);
+    const double s2 = f * r, z = s2 * s2;                                // s = f / (2 + f), |s| <= 0.1716
+    double p = 1.0 / 17.0;
+    p = fma(p, z, 1.0 / 15.0); p = fma(p, z, 1.0 / 13.0); p = fma(p, z, 1.0 / 11.0); p = fma(p, z, 1.0 / 9.0);
+    p = fma(p, z, 1.0 / 7.0); p = fma(p, z, 1.0 / 5.0); p = fma(p, z, 1.0 / 3.0);
+    const double lm = fma(s2 * z, p, s2);                                // atanh(s) = s + s^3 (1/3 + s^2/5 + ...)
+    R.l2 = fma(lm, 2.8853900817779268, (double)e);                      // 2 / ln 2
+    return R;
+}
+// 2^t for |t| < 1100 (beyond: the ldexp saturates to 0 / inf)
+SX_HD double sx_exp2_d(double t) {
+    if (!(t > -1100.0)) t = -1100.0;
+    if (!(t < 1100.0)) t = 1100.0;
+    const double n = rint(t);
+    const double u = (t - n) * 0.6931471805599453;                        // r ln 2, |u| <= 0.3466
+    double p = 2.505210838544172e-08;                                     // 1/11!
+    p = fma(p, u, 2.755731922398589e-07); p = fma(p, u, 2.755731922398589e-06); p = fma(p, u, 2.48015873015873e-05);
+    p = fma(p, u, 1.984126984126984e-04); p = fma(p, u, 1.388888888888889e-03); p = fma(p, u, 8.333333333333333e-03);
+    p = fma(p, u, 4.166666666666666e-02); p = fma(p, u, 1.666666666666667e-01); p = fma(p, u, 0.5);
+    p = fma(p, u, 1.0); p = fma(p, u, 1.0);
+    return ldexp(p, (int)n);
+}
+SX_HD float sx_nanf() { return sx_u2f(0x7fc00000u); }
+SX_HD float sx_inff() { return sx_u2f(0x7f800000u); }
+SX_HD float sx_logf(float x) {
+    const SxLog2 L = sx_log2_d(x);
+    if (L.special) return L.special == 1 ? -sx_inff() : L.special == 3 ? sx_inff() : sx_nanf();
+    return (float)(L.l2 * 0.6931471805599453);
+}
+// x^y given log2 x (several powers of one base share the logarithm: the vic-a adjoints need x^y, x^(y-1) and ln x)
+SX_HD float sx_pow_from(const SxLog2& L, float x, float y) {
+    if (y == 0.f || x == 1.f) return 1.f;
+    if (L.special == 1) return y > 0.f ? 0.f : sx_inff();
+    if (L.special == 3) return y > 0.f ? sx_inff() : 0.f;
+    if (L.special == 2) return sx_nanf();         // negative base: the model never raises one (the reference would give NaN or +-|x|^y)
+    return (float)sx_exp2_d((double)y * L.l2);
+}
+SX_HD float sx_powf(float x, float y) { return sx_pow_from(sx_log2_d(x), x, y); }
 
 // ---- fdlibm float expm1 / tanh (Sun Microsystems 1993, public algorithm; the float port is what
 // ---- glibc 2.35 ships as expm1f/tanhf).  Restated for arguments the model can produce:

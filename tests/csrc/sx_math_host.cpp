@@ -54,4 +54,40 @@ long sxt_div_mismatches(long n) {
 
 float sxt_expf(float x) { return sx_expf(x); }
 
+/* sx_powf / sx_logf (fp64 log2 / exp2 evaluation) on n random arguments of the vic-a kind: out[0] = fp32 mismatches against
+ * glibc powf, out[1] = against the correctly rounded logarithm (float)log((double)x), dout[0] / dout[1] = largest relative error of the fp64 values against the
+ * double-precision library pow / log */
+void sxt_powlog_check(long n, long* out, double* dout) {
+    srand(4242);
+    out[0] = out[1] = 0; dout[0] = dout[1] = 0.0;
+    for (long i = 0; i < n; ++i) {
+        float x, y;
+        switch (i & 3) {
+            case 0: x = rnd(1e-7f, 1.f); y = rnd(0.05f, 3.f); break;         /* 1 - w/c in (0,1), exponents 1/(b+1), b+1, b */
+            case 1: x = rnd(1e-3f, 50.f); y = rnd(-5.f, 5.f); break;
+            case 2: x = sx_u2f(0x3f800000u + (uint32_t)(rand() % 2000000) - 1000000u); y = rnd(-3.f, 3.f); break;   /* x ~ 1 */
+            default: x = sx_u2f((uint32_t)rand() % 0x7f000000u + 0x00100000u); y = rnd(-1.5f, 1.5f); break;        /* any magnitude */
+        }
+        const SxLog2 L = sx_log2_d(x);
+        const double pd = sx_exp2_d((double)y * L.l2), pr = pow((double)x, (double)y);
+        if (pr > 1e-300 && pr < 1e300) { const double e = fabs(pd - pr) / pr; if (e > dout[0]) dout[0] = e; }
+        const double ld = L.l2 * 0.6931471805599453, lr = log((double)x);
+        if (fabs(lr) > 1e-300) { const double e = fabs(ld - lr) / fabs(lr); if (e > dout[1]) dout[1] = e; }
+        if (sx_f2u(sx_powf(x, y)) != sx_f2u(powf(x, y))) out[0]++;
+        if (sx_f2u(sx_logf(x)) != sx_f2u((float)log((double)x))) out[1]++;   /* glibc's logf itself is ~1.7 % away from correct rounding */
+    }
+}
+/* special values: returns the number of disagreements with glibc */
+long sxt_pow_specials(void) {
+    const float xs[] = {0.f, 1.f, 2.f, 1e-45f, 1e-40f, 3.4e38f, 0.5f}, ys[] = {0.f, 1.f, -1.f, 0.5f, 2.f, -2.5f, 30.f, -30.f};
+    long bad = 0;
+    for (float x : xs) for (float y : ys) {
+        const float a = sx_powf(x, y), b = powf(x, y);
+        if (!(a == b || (a != a && b != b))) bad++;
+    }
+    if (sx_logf(0.f) != logf(0.f)) bad++;
+    if (sx_logf(-1.f) == sx_logf(-1.f)) bad++;
+    return bad;
+}
+
 }  /* extern "C" */

@@ -44,5 +44,20 @@ def test_fixed_powers_match_glibc_up_to_its_own_misrounding(lib):
         assert out[i] / n < 1.5e-3, (name, out[i] / n)       # glibc powf itself misrounds 6e-4 of the time
 
 
+def test_runtime_pow_and_log(lib):
+    """sx_powf / sx_logf (vic-a's run-time exponents, the logarithmic criterion): the fp64 values are within 2^-44 of the
+    double-precision library's; the fp32 power equals glibc's powf except where a rounding boundary is that close (glibc's own
+    powf misrounds 6e-4 of the time), the fp32 logarithm is the correctly rounded one (what the kernels used before, through
+    the library's double log; glibc's logf is 1.7 % away from it); special values as glibc."""
+    n = 4_000_000
+    out, dout = (C.c_long * 2)(), (C.c_double * 2)()
+    lib.sxt_powlog_check.argtypes = [C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_double)]
+    lib.sxt_powlog_check(n, out, dout)
+    assert dout[0] < 2.0 ** -44 and dout[1] < 2.0 ** -44, (dout[0], dout[1])
+    assert out[0] / n < 1.5e-3 and out[1] / n < 1e-4, (out[0] / n, out[1] / n)
+    lib.sxt_pow_specials.restype = C.c_long
+    assert lib.sxt_pow_specials() == 0
+
+
 def test_reciprocal_fma_division_is_ieee_division(lib):
     assert lib.sxt_div_mismatches(20_000_000) == 0
