@@ -974,7 +974,9 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
                 if (c > 0 && (rc = v_waits_r())) return rc;
                 if ((rc = copy_states(p, dst, cur))) return rc;
             }
-            if ((rc = forward_chunk(c, C == 1))) return rc;
+            // the last storage chunk is the first one the reverse sweep needs: it runs with the tape on straight away and
+            // is not recomputed
+            if ((rc = forward_chunk(c, c == C - 1))) return rc;
         }
         if ((rc = run_cost(p, 1, cost_b))) return rc;
         {   // gradient accumulators start from what COMPUTE_COST_B left in parameters_b / states_b: zero, or the
@@ -999,7 +1001,7 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
         if (p->ng == 0) HIPCHK(hipMemsetAsync(p->A.qgb, 0, (size_t)std::max(p->ngc, 1) * p->nt * 4, sR));
         for (int c = C - 1; c >= 0; --c) {
             const int t0c = c * p->Tc, Tcur = chunk_len(p, c);
-            if (C > 1) {   // recompute this storage chunk with the tape on
+            if (C > 1 && c < C - 1) {   // recompute this storage chunk with the tape on
                 float* src[5];
                 for (int i = 0; i < 5; ++i) src[i] = p->ckpt + ((size_t)c * 5 + i) * p->npad;
                 if ((rc = v_waits_r())) return rc;
