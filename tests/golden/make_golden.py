@@ -312,11 +312,34 @@ def main_lbfgsb_cance():
     print("lbfgsb cance costs:", costs)
 
 
+def main_sbs_cance():
+    """The user guide's first calibration (real_case_cance.rst:396-430): mw_optimize::optimize_sbs, uniform cp, cft, exc, lr from
+    the Model() defaults on the real Cance data, nse at the downstream gauge: cost after 0, 1, 2 iterations of the all-CPU
+    reference and the calibrated values at the outlet cell."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import golden_util as gu
+    g = gu.load("gr_a_cance_28x28x1440")
+    pv = dict(ci=1e-6, cp=200.0, beta=1000.0, cft=500.0, cst=500.0, alpha=0.9, exc=0.0, lr=5.0)
+    P = {k: (np.full_like(v, pv[k]) if k in pv else v) for k, v in g.params.items()}
+    op = np.zeros(16, np.int32)
+    op[[1, 3, 6, 15]] = 1
+    costs = []
+    for it in (0, 1, 2):
+        r = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, P, g.states, optimize_sbs_maxiter=it, optim_parameters=op, **g.opts)
+        costs.append(r["cost"])
+    d = dict(optim_parameters=op, maxiters=np.array([0, 1, 2]), costs=np.array(costs, np.float32))
+    for k in ("cp", "cft", "exc", "lr"):
+        d["final_" + k] = np.float32(r["parameters"][k][20, 27])
+    np.savez_compressed(os.path.join(OUT, "lbfgsb", "sbs_gr_a_cance.npz"), **d)
+    print("sbs cance costs:", costs)
+
+
 if __name__ == "__main__":
     main()                              # python make_golden.py [case names...]: only those cases
     if not [a for a in sys.argv[1:] if not a.startswith("-")]:
         os.makedirs(os.path.join(OUT, "lbfgsb"), exist_ok=True)
         main_lbfgsb()
         main_lbfgsb_cance()
+        main_sbs_cance()
         main_tangent()
         main_hyper()
