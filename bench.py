@@ -217,6 +217,8 @@ def main():
     if len(loc):
         sol.set_qobs(out.qsim)
     sol.upload(par, sta)
+    if not a.forward_only:
+        sol.chunking()                               # allocates the tapes of the reverse sweep now (set-up, ~4 s for 180 GB), not in the first sweep
     t_setup = time.perf_counter() - t_setup
 
     adjoint = not a.forward_only

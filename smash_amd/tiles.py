@@ -113,6 +113,20 @@ class TorchDistExchange:
         self.idx_out = {p: torch.from_numpy(ix).to(device) for p, ix in self.peers.out_peers.items()}
         self.idx_in = {p: torch.from_numpy(ix).to(device) for p, ix in self.peers.in_peers.items()}
         solver.set_halo(self.out_buf.data_ptr(), self.in_buf.data_ptr(), self)
+        # one handshake per neighbour now: RCCL creates its point-to-point channels on first use, which belongs to the set-up
+        # and not to the first sweep
+        mdev = "cpu" if self.host_staged else device
+        hello = {p: torch.zeros(1, dtype=torch.float32, device=mdev) for p in set(self.idx_out) | set(self.idx_in)}
+        ops = [dist.P2POp(dist.isend, torch.ones(1, dtype=torch.float32, device=mdev), p) for p in self.idx_out] + \
+              [dist.P2POp(dist.irecv, hello[p], p) for p in self.idx_in]
+        if ops:
+            if self.host_staged:
+                for r in [op.op(op.tensor, op.peer) for op in ops]:
+                    r.wait()
+            else:
+                for r in dist.batch_isend_irecv(ops):
+                    r.wait()
+                torch.cuda.current_stream().synchronize()
 
     def __call__(self, phase, t0, nsteps):
         torch, dist = self.torch, self.dist
