@@ -154,6 +154,7 @@ struct smashx_plan {
     hipStream_t stream = nullptr;    // vertical kernels, uploads/downloads ("V stream")
     hipStream_t stream_r = nullptr;  // routing + cost kernels ("R stream"); overlaps the V stream chunk by chunk
     int Tp = 0;                      // pipeline sub-chunk length inside a storage chunk
+    bool hi_tape = true;             // gr-b / gr-c: full tape of the interception level (false: sparse checkpoints, rebuilt in the reverse kernel)
     int Tpa = 0;                     // ... of the reverse sweep (routing adjoint of sub-chunk j-1 under the vertical adjoint of j)
     int chain_from = 1;              // first chained round
     bool split_v = false;            // SMASHX_SPLIT_V=1: vertical kernels in two cell ranges so that routing round 0 overlaps the second.
@@ -247,18 +248,30 @@ int chunk_len(const smashx_plan* p, int c) { return std::min(p->Tc, p->nt - c * 
 // allocate the time-chunk buffers; Tc from cfg or from free HBM
 int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
     const int st = p->st;
-    const int ntape = ((st == 2 || st == 5) ? 3 : st == 3 ? 4 : 2);
+    // taped levels per cell-step: hp, hft (+ hst in gr-c, + husl1 in vic-a) and, for gr-b / gr-c, the interception level hi.
+    // hi depends on the forcing only: when its tape is what keeps the period from fitting in one storage chunk, the plan
+    // keeps one checkpoint per SX_HIK steps instead and the reverse kernel rebuilds the levels block by block
+    // (slower per step, but no recomputation of whole chunks: gr-c at 1024^2 x 8760 230 -> 204 ms).  SMASHX_HI_TAPE=0/1 forces it.
+    const bool has_hi = (st == 2 || st == 3);
+    const double ntape_full = (st == 5 ? 3.0 : st == 3 ? 4.0 : st == 2 ? 3.0 : 2.0);
+    const double ntape_lean = has_hi ? ntape_full - 1.0 + 1.0 / SX_HIK : ntape_full;
+    double ntape = ntape_full;
     if (!p->chunk_ready) {
         const int nt16 = (p->nt + 15) / 16 * 16;
         int Tc = p->cfg.chunk_steps > 0 ? (p->cfg.chunk_steps + 15) / 16 * 16 : 0;
         if (Tc == 0) {
             size_t fr = 0, tot = 0;
             HIPCHK(hipMemGetInfo(&fr, &tot));
-            const double per_step = 4.0 * ((double)p->npad * (2 + ntape) + (double)std::max(p->sch.nxslots, 1));
             const double avail = (double)fr * 0.85 - 1.0e9;
-            long t = (long)(avail / per_step) / 16 * 16;
+            auto fit = [&](double nt_) { return (long)(avail / (4.0 * ((double)p->npad * (2 + nt_) + (double)std::max(p->sch.nxslots, 1)))) / 16 * 16; };
+            long t = fit(ntape_full);
+            if (has_hi && t < nt16) { p->hi_tape = false; t = fit(ntape_lean); }
             Tc = (int)std::max<long>(16, std::min<long>(nt16, t));
         }
+        if (const char* e = getenv("SMASHX_HI_TAPE")) p->hi_tape = atoi(e) != 0;
+        if (!has_hi) p->hi_tape = true;
+        ntape = p->hi_tape ? ntape_full : ntape_lean;
+        (void)ntape;
         Tc = std::min(Tc, nt16);
         {   // balance the chunks: same count, equal lengths
             const int nch = (p->nt + Tc - 1) / Tc;
@@ -297,7 +310,8 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
         if ((rc = p->dmalloc(&p->A.hrT, cs))) return rc;
         if ((rc = p->dmalloc(&p->A.tape_hp, cs))) return rc;
         if ((rc = p->dmalloc(&p->A.tape_hft, cs))) return rc;
-        if (st == 2 || st == 3 || st == 5) { if ((rc = p->dmalloc(&p->A.tape_hi, cs))) return rc; }
+        if (st == 5 || ((st == 2 || st == 3) && p->hi_tape)) { if ((rc = p->dmalloc(&p->A.tape_hi, cs))) return rc; }
+        else if (st == 2 || st == 3) { if ((rc = p->dmalloc(&p->A.ckpt_hi, cs / SX_HIK))) return rc; }
         if (st == 3) { if ((rc = p->dmalloc(&p->A.tape_hst, cs))) return rc; }
         if (p->nchunks > 1) { if ((rc = p->dmalloc(&p->ckpt, (size_t)p->nchunks * 5 * p->npad))) return rc; }
         float** g[14] = {&p->A.ci_b, &p->A.cp_b, &p->A.cft_b, &p->A.cst_b, &p->A.exc_b, &p->A.lr_b,
@@ -322,6 +336,7 @@ SxDeviceArrays view_at(const smashx_plan* p, int off) {
     if (p->A.tape_hp) B.tape_hp = p->A.tape_hp + (size_t)off * p->npad;
     if (p->A.tape_hft) B.tape_hft = p->A.tape_hft + (size_t)off * p->npad;
     if (p->A.tape_hi) B.tape_hi = p->A.tape_hi + (size_t)off * p->npad;
+    if (p->A.ckpt_hi) B.ckpt_hi = p->A.ckpt_hi + (size_t)(off / SX_HIK) * p->npad;
     if (p->A.tape_hst) B.tape_hst = p->A.tape_hst + (size_t)off * p->npad;
     return B;
 }

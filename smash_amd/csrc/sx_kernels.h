@@ -146,6 +146,7 @@ struct SxDeviceArrays {
     float *qtdT, *xdT, *qgd;
     float* qdT;                   // optional: discharge of every cell (setup%save_qsim_domain), T4 like qtT; null = off
     float *tape_hi, *tape_hp, *tape_hft, *tape_hst;
+    float* ckpt_hi;               // gr-b / gr-c: hi at every SX_HIK-th step of the chunk, [Tc / SX_HIK][npad] (tape_hi: vic-a only)
     float* xT;                    // exchange series
     // gauges
     float *qg, *qgb;              // [ngc][nt] discharge at gauge cells / adjoint seeds
@@ -180,6 +181,7 @@ __global__ void sx_k_prep_routing(SxDeviceArrays A) {
 // stream (forcing in, tapes and qt out) 42.0 -> 41.1 ms; nt on the reverse kernel's loads 76.4 -> 78.7 ms, so only the
 // forward kernel uses it.
 #define SX_NT 2
+#define SX_HIK 8             // steps per block of the interception level's checkpoint / rebuild (chunk offsets are multiples of 16)
 #ifndef SX_VADJ_NT
 #define SX_VADJ_NT 0
 #endif
@@ -244,7 +246,10 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
                 }
                 if (TAPE) {
                     const size_t o = (size_t)tt * npad;
-                    if (ST == 2 || ST == 3) sx_row_store<SX_NT>(A.tape_hi + o, kb, hi);
+                    if (ST == 2 || ST == 3) {     // the interception level: a full tape when it fits, else one checkpoint per SX_HIK steps
+                        if (A.tape_hi) sx_row_store<SX_NT>(A.tape_hi + o, kb, hi);
+                        else if ((tt % SX_HIK) == 0) sx_row_store<SX_NT>(A.ckpt_hi + (size_t)(tt / SX_HIK) * npad, kb, hi);
+                    }
                     sx_row_store<SX_NT>(A.tape_hp + o, kb, hp);
                     sx_row_store<SX_NT>(A.tape_hft + o, kb, hft);
                     if (ST == 3) sx_row_store<SX_NT>(A.tape_hst + o, kb, hst);
@@ -831,22 +836,46 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDevi
     // byte offset: no vector address arithmetic in the time loop
     const unsigned kb = (unsigned)k * 4u;
     float n_prcp = 0.f, n_pet = 0.f, n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
+    const bool hi_taped = (ST == 2 || ST == 3) && A.tape_hi != nullptr;       // wave-uniform
     auto fetch = [&](int tt) {
         const size_t o = (size_t)tt * npad, of = (size_t)(t0 + tt) * npad;
         n_prcp = sx_row_load<SX_VADJ_NT>(A.prcp + of, kb); n_pet = sx_row_load<SX_VADJ_NT>(A.pet + of, kb);
-        if (ST == 2 || ST == 3) n_hi = sx_row_load<SX_VADJ_NT>(A.tape_hi + o, kb);
+        if (hi_taped) n_hi = sx_row_load<SX_VADJ_NT>(A.tape_hi + o, kb);
         n_hp = sx_row_load<SX_VADJ_NT>(A.tape_hp + o, kb); n_hft = sx_row_load<SX_VADJ_NT>(A.tape_hft + o, kb);
         if (ST == 3) n_hst = sx_row_load<SX_VADJ_NT>(A.tape_hst + o, kb);
         n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
     };
+    // When the interception level is not taped (it depends on the forcing and ci only; the plan drops its tape when that is what
+    // lets the whole period fit): each block of SX_HIK steps is marched forward once more from its checkpoint -- the same
+    // sx_interception on the same operands, hence the same bits -- and the pre-step levels wait in this thread's LDS
+    // column for the reverse steps of the block.
+    __shared__ float s_hi[(ST == 2 || ST == 3) ? SX_HIK : 1][SX_VBLOCK];
     if (T > 0) fetch(T - 1);
-    for (int tt = T - 1; tt >= 0; --tt) {
-        float prcp = n_prcp, pet = n_pet, hi = n_hi, hp = n_hp, hft = n_hft, hst = n_hst, q = n_q;
-        sx_pin1(prcp); sx_pin1(pet); sx_pin1(hp); sx_pin1(hft); sx_pin1(q);
-        if (ST == 2 || ST == 3) sx_pin1(hi);
-        if (ST == 3) sx_pin1(hst);
-        if (tt > 0) fetch(tt - 1);
-        sx_vertical_step_b<ST>(P, Q, prcp, pet, hi, hp, hft, hst, q, G);
+    for (int tb = (T - 1) / SX_HIK; tb >= 0; --tb) {
+        const int tt0 = tb * SX_HIK, len = min(SX_HIK, T - tt0);
+        if ((ST == 2 || ST == 3) && !hi_taped) {
+            float fp[SX_HIK], fe[SX_HIK];
+#pragma unroll
+            for (int j = 0; j < SX_HIK; ++j) {
+                const size_t of = (size_t)(t0 + tt0 + (j < len ? j : 0)) * npad;
+                fp[j] = sx_row_load<SX_VADJ_NT>(A.prcp + of, kb); fe[j] = sx_row_load<SX_VADJ_NT>(A.pet + of, kb);
+            }
+            float h = sx_row_load(A.ckpt_hi + (size_t)tb * npad, kb);
+#pragma unroll
+            for (int j = 0; j < SX_HIK; ++j) {
+                s_hi[j][threadIdx.x] = h;
+                if (j < len && fp[j] >= 0.f && fe[j] >= 0.f) { float pn, ei; sx_interception(fp[j], fe[j], P.ci, P.dci, h, pn, ei); }
+            }
+        }
+        for (int tt = tt0 + len - 1; tt >= tt0; --tt) {
+            float prcp = n_prcp, pet = n_pet, hit = n_hi, hp = n_hp, hft = n_hft, hst = n_hst, q = n_q;
+            sx_pin1(prcp); sx_pin1(pet); sx_pin1(hp); sx_pin1(hft); sx_pin1(q);
+            if (ST == 2 || ST == 3) sx_pin1(hit);
+            if (ST == 3) sx_pin1(hst);
+            if (tt > 0) fetch(tt - 1);
+            const float hi = (ST == 2 || ST == 3) ? (hi_taped ? hit : s_hi[tt - tt0][threadIdx.x]) : 0.f;
+            sx_vertical_step_b<ST>(P, Q, prcp, pet, hi, hp, hft, hst, q, G);
+        }
     }
     if (ST == 2 || ST == 3) { A.ci_b[k] = G.ci_b; A.hi_b[k] = G.hi_b; }
     A.cp_b[k] = G.cp_b;

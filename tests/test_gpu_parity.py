@@ -125,6 +125,25 @@ def test_chunking_and_grouping_do_not_change_results(name, chunk, pipe, group):
         assert np.array_equal(getattr(ref[4], k), getattr(alt[4], k)), k
 
 
+@pytest.mark.parametrize("name,chunk", [("gr_b_16x16x96_nse_gaps", 0), ("gr_c_16x16x96_kge_se_log_mask", 32), ("gr_b_24x24x120_norm_jreg", 48),
+                                        ("gr_c_32x32x240_d8_ragged", 0)])
+def test_interception_level_rebuilt_from_checkpoints_equals_tape(name, chunk, monkeypatch):
+    """gr-b / gr-c: the reverse kernel either reads a tape of the interception level or rebuilds it block by block from
+    sparse checkpoints (chosen by the plan when the full tape would force a second storage chunk; SMASHX_HI_TAPE forces it):
+    the same sx_interception on the same operands, so every output is bit-identical -- also with gaps, with a step count
+    that is not a multiple of the block (120, 240 vs 8) and across storage chunks."""
+    g = gu.load(name)
+    monkeypatch.setenv("SMASHX_HI_TAPE", "1")
+    ref = _run_adjoint(g, chunk_steps=chunk)
+    monkeypatch.setenv("SMASHX_HI_TAPE", "0")
+    alt = _run_adjoint(g, chunk_steps=chunk)
+    assert np.array_equal(ref[2].qsim, alt[2].qsim) and ref[2].cost == alt[2].cost
+    for k in gu.STRUCT_PARAMS[g.structure]:
+        assert np.array_equal(getattr(ref[3], k), getattr(alt[3], k)), k
+    for k in gu.STRUCT_STATES[g.structure]:
+        assert np.array_equal(getattr(ref[4], k), getattr(alt[4], k)), k
+
+
 def test_sparse_forcing_layout_matches_dense():
     """Input_DataDT%sparse_prcp/pet (nac,nt) numbered along path (mw_sparse_storage.f90:12-49)."""
     import smash_amd
