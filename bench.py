@@ -5,9 +5,17 @@ hourly x 1 yr forcing resident in HBM (BASELINE.json metric; SURVEY.md section 8
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one forward+adjoint sweep of the hot path over the whole (grid x nt) batch.  At N = 1 the
-workload is BASELINE.json configs[2]: 1024 x 1024 grid, 8760 steps, gr-b (4096^2, the grid the metric is
-quoted on, needs 1.18 TB of forcing and only fits 8 GPUs).  Prints ONE JSON line on rank 0.
+A "step" is one forward+adjoint sweep of the hot path over the whole (grid x nt) batch.
+  N = 1   BASELINE.json configs[2]: 1024 x 1024 grid, 8760 steps, gr-b, store-all adjoint.  The same line carries a
+          "secondary" object: the 2048 x 2048 grid of configs[3] on the one GPU (checkpointed adjoint).
+  N > 1   one process per GPU, every GPU owns a 2048 x 1024 tile: 1x2, 2x2, 2x4 tiles = 2048x2048, 4096x2048 and, at
+          N = 8, the 4096 x 4096 grid the metric is quoted on (configs[4]).  Boundary discharge series move between the
+          tiles with grouped ncclSend / ncclRecv posted by the library itself on its routing stream (RCCL over xGMI);
+          torch.distributed (backend nccl = RCCL) carries the set-up handshake, the barriers and the max-over-ranks time.
+          Under a launcher (torchrun: RANK / WORLD_SIZE in the environment) the process is one rank; without one,
+          --gpus N starts the N ranks itself as fresh child processes before anything here touches the GPU.
+          --tile-rows / --tile-cols (or --grid) choose another per-GPU tile, e.g. --grid 1024 for the 1024^2-per-GPU series.
+Prints ONE JSON line on rank 0.
 
 PyTorch is plumbing here (device memory for building the forcing in HBM, streams, torch.distributed);
 all solver arithmetic is in libsmashx (HIP) behind the C ABI.
@@ -26,31 +34,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+N_SIMD, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD for 4 cycles
+KERNELS = ("vert_fwd", "route_fwd", "route_adj", "vert_adj")
 
 
-def pmc_traffic(kernel, cellsteps_per_launch):
-    """HBM bytes per launch of `kernel` from the PMC counters.  bench.py cannot collect PMC itself: the values
-    come from the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command
-    (tools/profile_round.sh), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950), stored per
-    cell-step in profiles/r*_pmc_traffic.json and scaled to this run's launch size.  None if never measured."""
+def pmc_profile():
+    """Counters of the committed rocprofv3 --pmc passes over this very command (tools/profile_round.sh): bench.py cannot
+    collect PMC itself.  Per kernel: HBM bytes per cell-step (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md)
+    and VALU wave-instructions per cell-step (SQ_INSTS_VALU).  The newest profiles/r*_pmc_traffic.json wins."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, {}
     try:
-        d = json.load(open(files[-1])).get(kernel)
-        return d["hbm_bytes_per_cellstep_corrected"] * cellsteps_per_launch if d else None
+        return os.path.relpath(files[-1], ROOT), json.load(open(files[-1]))
     except Exception:
-        return None
+        return None, {}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", type=int, default=1024, help="cells per side of the per-GPU tile (weak scaling: fixed per GPU)")
-    ap.add_argument("--tile-rows", type=int, default=0, help="per-GPU tile rows (default --grid); 2048 x 1024 tiles on 8 GPUs = the 4096^2 grid")
+    ap.add_argument("--grid", type=int, default=0, help="square per-GPU tile (default: 1024 at N = 1)")
+    ap.add_argument("--tile-rows", type=int, default=0, help="per-GPU tile rows (default at N > 1: 2048 x 1024, so 8 GPUs hold the 4096^2 grid)")
     ap.add_argument("--tile-cols", type=int, default=0)
     ap.add_argument("--pipe", type=int, default=0, help="pipeline sub-chunk (default: none on 1 GPU, 1104 on tiles)")
     ap.add_argument("--partition", default="rect", choices=["rect", "sub", "trunk"],
@@ -60,18 +68,24 @@ def parse():
                     "alone (no-op exchange, zero inflow): what that rank computes, without waiting for its neighbours")
     ap.add_argument("--of", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; gloo only for rehearsing the N>1 path without RCCL")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
+                    help="boundary series: rccl = grouped ncclSend/ncclRecv posted by libsmashx on its routing stream (default); "
+                         "torch = host callback + torch.distributed point-to-point (always used with --backend gloo)")
     ap.add_argument("--nt", type=int, default=8760)
     ap.add_argument("--structure", default="gr-b")
-    ap.add_argument("--chunk", type=int, default=0, help="time-chunk length (0 = from free HBM)")
+    ap.add_argument("--chunk", type=int, default=0, help="time-chunk length (0 = from HBM size)")
     ap.add_argument("--group", type=int, default=0, help="routing group size (0 = default)")
     ap.add_argument("--ng", type=int, default=8)
     ap.add_argument("--forward-only", action="store_true")
+    ap.add_argument("--raw-forcing", action="store_true", help="keep the forcing as fp32 (no lossless compaction)")
     ap.add_argument("--trace-groups", default="", help="diagnostics: write per-round start/end times of the routing groups (JSON) here")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the 2048 x 2048 measurement attached to the line")
+    ap.add_argument("--secondary-grid", type=int, default=2048)
     ap.add_argument("--cpu-grid", type=int, default=256)
     ap.add_argument("--cpu-nt", type=int, default=360)
     ap.add_argument("--cpu-cores", type=int, default=0, help="replicas of the CPU baseline (default: the box's CPU share, at most 16)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def _cpu_replica(structure, n, nt, barrier, q):
@@ -124,123 +138,270 @@ def cpu_baseline(structure, n, nt, cores=0):
                       f"hourly steps, slowest replica {slow:.1f} s"}
 
 
+def self_launch(a, argv):
+    """--gpus N without a launcher: start the N ranks as fresh children -- nothing in this parent has imported torch or
+    touched the GPU, and no process that has is ever re-executed.  Rank 0's stdout (the JSON line) is ours."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, t_fail = 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+        if bad and t_fail is None:
+            rc, t_fail = bad[0], time.time()
+        if t_fail is not None and time.time() - t_fail > 20:      # a rank died: the others would wait for it forever
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for p in procs:
+        rc = rc or p.returncode
+    return rc
+
+
+def chunk_plan(nt, cells, hbm_bytes, forcing_bytes, structure, forced=0):
+    """Storage-chunk length for a tile, from quantities every rank agrees on (the GPU's total HBM, not this rank's free
+    memory): the ranks of a decomposition must cut time identically."""
+    nt16 = (nt + 15) // 16 * 16
+    if forced:
+        return forced
+    per_step = 4.0 * cells * ({"gr-a": 4, "gr-b": 5, "gr-c": 6, "gr-d": 4, "vic-a": 5}[structure])   # qt, hr_imd + taped levels
+    avail = 0.80 * hbm_bytes - forcing_bytes - 2.0e9
+    tc = int(max(16, min(nt16, int(avail / per_step) // 16 * 16)))
+    nch = (nt + tc - 1) // tc
+    return min(tc, ((nt + nch - 1) // nch + 15) // 16 * 16)
+
+
+class Case:
+    """One benchmark workload: plan + forcing resident in HBM + observations, ready to sweep."""
+
+    def __init__(self, a, torch, dev, local, parts, me, world, trows, tcols, solo, raw_forcing):
+        import smash_amd
+        from smash_amd import synth, tiles
+        from smash_amd.solver import Solver
+        self.a, self.torch, self.dev = a, torch, dev
+        nt = a.nt
+        pr, pc = tiles.tile_grid(parts)
+        nrow, ncol = pr * trows, pc * tcols            # the whole catchment; every rank owns 1/parts of it
+        self.pr, self.pc, self.nrow, self.ncol, self.parts, self.me = pr, pc, nrow, ncol, parts, me
+        t_setup = time.perf_counter()
+        m = synth.make_mesh(nrow, ncol, ng=a.ng)
+        rect, owner, mine = None, None, None
+        if parts > 1 and a.partition == "rect":
+            rect = tiles.tile_rect(me, nrow, ncol, pr, pc)
+        elif parts > 1:                                # every rank computes the same cut of the river tree
+            owner = tiles.partition_trunk(m, parts, a.trunk_share) if a.partition == "trunk" else tiles.partition_subcatchments(m, parts)
+            mine = np.asfortranarray((np.asarray(owner) == me).astype(np.int32))
+        self.owner = owner
+        gp = np.asarray(m.gauge_pos)
+        if mine is not None:
+            loc = [i for i in range(m.ng) if mine[gp[i, 0], gp[i, 1]]]
+        else:
+            loc = [i for i in range(m.ng) if rect is None or (rect[0] <= gp[i, 0] < rect[1] and rect[2] <= gp[i, 1] < rect[3])]
+        setup = smash_amd.SetupDT(0, len(loc), structure=a.structure, dt=3600.0, ntime_step=nt)
+        setup.optimize.jobs_fun, setup.optimize.wjobs_fun = ["nse"], [1.0]
+        setup.optimize.wgauge = np.full(len(loc), 1.0 / m.ng, np.float32)      # weights of the global cost (mean over all gauges)
+        mesh = smash_amd.MeshDT(setup, nrow, ncol, len(loc))
+        mesh.dx, mesh.flwdir, mesh.flwacc, mesh.path, mesh.active_cell = m.dx, m.flwdir, m.flwacc, m.path, m.active_cell
+        mesh.gauge_pos = np.asfortranarray(gp[loc].reshape(-1, 2))
+        mesh.area = np.asarray(m.area)[loc]
+        self.setup, self.mesh, self.loc = setup, mesh, loc
+        chunk, pipe = a.chunk, a.pipe
+        compact = not raw_forcing
+        if parts > 1:
+            # every rank must cut time identically (messages are per sub-chunk): lengths from sizes all ranks share
+            cells = -(-nrow * ncol // parts)
+            hbm = torch.cuda.get_device_properties(dev).total_memory
+            fbytes = cells * nt * (2.0 + 4.0 / 24.0 if compact else 8.0)
+            chunk = chunk_plan(nt, cells, hbm, fbytes, a.structure, chunk)
+            pipe = pipe or 1104
+        if a.trace_groups:
+            os.environ["SMASHX_TRACE_GROUPS"] = "1"
+        sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=a.group, device=local, tile=rect, owner_mask=mine)
+        self.sol = sol
+        if compact:
+            daily, w = synth._pet_tables()
+            sol.set_forcing_layout(compact=True, prcp_factor=0.1, pet_ratio=w, pet_hour0=0)
+        rows, cols = sol.cell_order()
+        d_rows = torch.from_numpy(rows.astype(np.int64)).to(dev)
+        d_cols = torch.from_numpy(cols.astype(np.int64)).to(dev)
+        tb = max(24, (1 << 26) // max(sol.ncells, 1) // 24 * 24)     # whole days; ~64 M cell-steps of int64 temporaries per block
+        for t0 in range(0, nt, tb):
+            t1 = min(nt, t0 + tb)
+            prcp, pet = synth.forcing_block(d_rows, d_cols, t0, t1, xp=torch, device=dev)
+            torch.cuda.synchronize()
+            sol.set_forcing_device_block(t0, t1, prcp.data_ptr(), pet.data_ptr())
+            del prcp, pet
+        del d_rows, d_cols
+        torch.cuda.empty_cache()
+        self.forcing = sol.forcing_info()
+
+        P, S = synth.make_parameters(nrow, ncol), synth.make_states(nrow, ncol, warm=True)
+        self.par, self.sta = smash_amd.ParametersDT.from_dict(mesh, P), smash_amd.StatesDT.from_dict(mesh, S)
+        self.out = smash_amd.OutputDT(setup, mesh)
+        # observations = forward run with parameters perturbed by +10 % (SURVEY 8d)
+        parq = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(nrow, ncol, perturb=0.1))
+        sol.set_options(setup.optimize)
+        self.comm, self.exchange = None, None
+        if world > 1:
+            import torch.distributed as dist
+            if a.exchange == "rccl" and a.backend == "nccl":
+                from smash_amd.solver import Comm
+                uid = [Comm.unique_id() if me == 0 else None]
+                dist.broadcast_object_list(uid, src=0, device=dev)
+                self.comm = Comm(uid[0], me, world, local)
+                self.exchange = tiles.RcclExchange(sol, self.comm, nrow, ncol, pr, pc, owner)
+            else:
+                self.exchange = tiles.TorchDistExchange(sol, nrow, ncol, pr, pc, dev, owner)
+        elif solo:
+            self.exchange = tiles.NoExchange(sol, dev)
+        sol.upload(parq, self.sta)
+        sol.sweep(False)
+        sol.download(False, parq, self.sta, self.out)
+        if len(loc):
+            sol.set_qobs(self.out.qsim)
+        sol.upload(self.par, self.sta)
+        if not a.forward_only:
+            sol.chunking()                               # allocates the tapes of the reverse sweep now (set-up), not in the first sweep
+        self.setup_s = time.perf_counter() - t_setup
+
+    def close(self):
+        self.sol.close()
+        if self.comm is not None:
+            self.comm.close()
+        self.torch.cuda.empty_cache()
+
+
+def timed_sweeps(case, steps, warmup, adjoint, barrier):
+    """W untimed sweeps, then exactly K sweeps between two barrier + synchronize brackets.  Returns (seconds, kernel times)."""
+    sol = case.sol
+    for _ in range(warmup):
+        sol.sweep(adjoint)
+    tm_acc = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sol.sweep(adjoint)          # smashx_sweep synchronises its streams before returning
+        for k, v in sol.timing().items():
+            tm_acc[k] = tm_acc.get(k, 0.0) + v
+    barrier()
+    secs = time.perf_counter() - t0
+    return secs, {k: v / steps for k, v in tm_acc.items()}
+
+
+def inclusive_call_ms(case, adjoint, reps=3):
+    """One call through the boundary the way the reference's host makes it: parameters and states uploaded from host arrays,
+    the sweep, cost + discharge + all gradient planes downloaded (smashx_forward_b).  Not the metric's value (inputs resident)."""
+    sol = case.sol
+    par_b, sta_b = case.par.copy(), case.sta.copy()
+    case.torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sol.upload(case.par, case.sta)
+        sol.sweep(adjoint)
+        sol.download(adjoint, case.par, case.sta, case.out, par_b, sta_b)
+    case.torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / reps
+
+
+def roofline(tm, adjoint, structure):
+    """Dominant kernel against both ceilings: HBM (algorithmic bytes: prcp + pet = 8 B per cell-step per vertical pass,
+    SURVEY.md 8d) and VALU issue (wave-instructions per cell-step from the committed PMC pass x 4 cycles on 1024 SIMDs)."""
+    ms = {k: tm[k + "_ms"] for k in KERNELS}
+    dom = max(ms, key=ms.get)
+    n_launch = max(tm[dom + "_launches"], 1.0)
+    avg_ms = ms[dom] / n_launch
+    cs_launch = tm[dom + "_cellsteps"] / n_launch                 # cell-steps ONE launch processes (sub-chunked launches are shorter)
+    per_cs = 8.0 if dom.startswith("vert") else 4.0               # routing reads qt once: it is not a streaming kernel of the forcing
+    alg_bytes = per_cs * cs_launch
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    src, prof = pmc_profile()
+    pk = prof.get("sx_k_" + dom) if structure == "gr-b" else None
+    traffic = pk["hbm_bytes_per_cellstep_corrected"] * cs_launch if pk and "hbm_bytes_per_cellstep_corrected" in pk else None
+    r = {"bound": "hbm", "kernel": "sx_k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+         "traffic_source": (f"{src}: rocprofv3 --pmc passes of this command, bytes per cell-step scaled to this run's launch" if traffic else None),
+         "avg_launch_ms": avg_ms, "launches_per_step": n_launch, "cellsteps_per_launch": cs_launch,
+         "algorithmic_bytes_per_launch": alg_bytes,
+         "sweep_frac": (16.0 if adjoint else 8.0) * tm["vert_adj_cellsteps" if adjoint else "vert_fwd_cellsteps"] / (tm["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if pk and "valu_per_cellstep" in pk:
+        issue_ms = pk["valu_per_cellstep"] * cs_launch / 64.0 * 4.0 / (N_SIMD * CLOCK_HZ) * 1e3
+        r["valu"] = {"instr_per_cellstep": pk["valu_per_cellstep"], "issue_bound_ms": issue_ms, "frac": issue_ms / avg_ms,
+                     "note": "SQ_INSTS_VALU per cell-step x 4 cycles per wave64 instruction on 1024 SIMDs at 2.4 GHz; frac = share of the "
+                             "launch time the VALU is issuing: this ceiling, not HBM, binds the reverse kernel"}
+    return r
+
+
 def main():
-    a = parse()
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and a.as_rank < 0:
+        sys.exit(self_launch(a, argv))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     # the CPU baseline starts one process per core: it runs FIRST, before anything in this process touches the GPU
     # (rank 0 at N = 1 only)
     cpu = None
-    if not a.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    if not a.no_cpu_baseline and world == 1:
         try:
             cpu = cpu_baseline(a.structure, a.cpu_grid, a.cpu_nt, a.cpu_cores)
         except Exception as e:  # pragma: no cover
             cpu = {"value": None, "unit": "cell-timesteps/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     import torch
     import torch.distributed as dist
+    from smash_amd import tiles
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    local = local % max(torch.cuda.device_count(), 1)
-    if world > 1:
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(a.backend)
+    ndev = max(torch.cuda.device_count(), 1)       # counting devices does not initialise the GPU
+    shared = world > 1 and ndev < int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if shared and a.backend == "nccl":
+        tiles.share_one_gpu_env(rank)              # rehearsal on a box with fewer GPUs than ranks
+    local = local % ndev
+    if world > 1 and a.backend != "nccl":          # host-side rendezvous first: it needs no device
+        dist.init_process_group(a.backend)
+        dist.barrier()
+        print(f"bench.py: rank {rank}/{world} handshake ok ({a.backend})", file=sys.stderr, flush=True)
+    if not torch.cuda.is_available():
+        print("bench.py: no HIP device -- libsmashx has no CPU path, nothing to measure", file=sys.stderr, flush=True)
+        sys.exit(3)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1 and a.backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()                             # every rank has completed the RCCL handshake past this point
+        print(f"bench.py: rank {rank}/{world} handshake ok (nccl)", file=sys.stderr, flush=True)
 
-    import smash_amd
-    from smash_amd import synth
-    from smash_amd.solver import Solver
-
-    from smash_amd import tiles
-    n, nt = a.grid, a.nt
-    trows, tcols = a.tile_rows or n, a.tile_cols or n
     solo = a.as_rank >= 0 and a.of > 1 and world == 1      # diagnostics: one rank of a decomposition, alone
     parts, me = (a.of, a.as_rank) if solo else (world, rank)
-    pr, pc = tiles.tile_grid(parts)
-    nrow, ncol = pr * trows, pc * tcols            # the whole catchment; every rank owns 1/parts of it (weak scaling)
-    t_setup = time.perf_counter()
-    m = synth.make_mesh(nrow, ncol, ng=a.ng)
-    rect, owner, mine = None, None, None
-    if parts > 1 and a.partition == "rect":
-        rect = tiles.tile_rect(me, nrow, ncol, pr, pc)
-    elif parts > 1:                                # every rank computes the same cut of the river tree
-        owner = tiles.partition_trunk(m, parts, a.trunk_share) if a.partition == "trunk" else tiles.partition_subcatchments(m, parts)
-        mine = np.asfortranarray((np.asarray(owner) == me).astype(np.int32))
-    gp = np.asarray(m.gauge_pos)
-    if mine is not None:
-        loc = [i for i in range(m.ng) if mine[gp[i, 0], gp[i, 1]]]
+    if a.tile_rows or a.tile_cols:
+        trows, tcols = a.tile_rows or a.tile_cols, a.tile_cols or a.tile_rows
+    elif a.grid:
+        trows = tcols = a.grid
     else:
-        loc = [i for i in range(m.ng) if rect is None or (rect[0] <= gp[i, 0] < rect[1] and rect[2] <= gp[i, 1] < rect[3])]
-    setup = smash_amd.SetupDT(0, len(loc), structure=a.structure, dt=3600.0, ntime_step=nt)
-    setup.optimize.jobs_fun, setup.optimize.wjobs_fun = ["nse"], [1.0]
-    setup.optimize.wgauge = np.full(len(loc), 1.0 / m.ng, np.float32)      # weights of the global cost (mean over all gauges)
-    mesh = smash_amd.MeshDT(setup, nrow, ncol, len(loc))
-    mesh.dx, mesh.flwdir, mesh.flwacc, mesh.path, mesh.active_cell = m.dx, m.flwdir, m.flwacc, m.path, m.active_cell
-    mesh.gauge_pos = np.asfortranarray(gp[loc].reshape(-1, 2))
-    mesh.area = np.asarray(m.area)[loc]
-    chunk, pipe = a.chunk, a.pipe
-    if parts > 1:
-        # every rank must cut time identically (messages are per sub-chunk): fix the lengths instead of sizing from free HBM
-        chunk = chunk or ((nt + 15) // 16 * 16 if trows * tcols <= 1100000 else ((nt + 3) // 4 + 15) // 16 * 16)
-        pipe = pipe or 1104
-    if a.trace_groups:
-        os.environ["SMASHX_TRACE_GROUPS"] = "1"
-    sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=a.group, device=local, tile=rect, owner_mask=mine)
-    n = None
-    rows, cols = sol.cell_order()
-    d_rows = torch.from_numpy(rows.astype(np.int64)).to(dev)
-    d_cols = torch.from_numpy(cols.astype(np.int64)).to(dev)
-    tb = max(1, min(nt, (1 << 26) // max(sol.ncells, 1)))     # ~64 M cell-steps of int64 temporaries per block
-    for t0 in range(0, nt, tb):
-        t1 = min(nt, t0 + tb)
-        prcp, pet = synth.forcing_block(d_rows, d_cols, t0, t1, xp=torch, device=dev)
-        torch.cuda.synchronize()
-        sol.set_forcing_device_block(t0, t1, prcp.data_ptr(), pet.data_ptr())
-        del prcp, pet
-    del d_rows, d_cols
-    torch.cuda.empty_cache()
-
-    P, S = synth.make_parameters(nrow, ncol), synth.make_states(nrow, ncol, warm=True)
-    par, sta = smash_amd.ParametersDT.from_dict(mesh, P), smash_amd.StatesDT.from_dict(mesh, S)
-    out = smash_amd.OutputDT(setup, mesh)
-    # observations = forward run with parameters perturbed by +10 %
-    parq = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(nrow, ncol, perturb=0.1))
-    sol.set_options(setup.optimize)
-    exchange = tiles.TorchDistExchange(sol, nrow, ncol, pr, pc, dev, owner) if world > 1 else None
-    if solo:
-        exchange = tiles.NoExchange(sol, dev)
-    sol.upload(parq, sta)
-    sol.sweep(False)
-    sol.download(False, parq, sta, out)
-    if len(loc):
-        sol.set_qobs(out.qsim)
-    sol.upload(par, sta)
-    if not a.forward_only:
-        sol.chunking()                               # allocates the tapes of the reverse sweep now (set-up, ~4 s for 180 GB), not in the first sweep
-    t_setup = time.perf_counter() - t_setup
-
+        trows, tcols = (1024, 1024) if parts == 1 else (2048, 1024)
     adjoint = not a.forward_only
-    for _ in range(a.warmup):
-        sol.sweep(adjoint)
+    nt = a.nt
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    tm_acc = {}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        sol.sweep(adjoint)          # smashx_sweep synchronises its stream before returning
-        for k, v in sol.timing().items():
-            tm_acc[k] = tm_acc.get(k, 0.0) + v
-    barrier()
-    secs = time.perf_counter() - t0
+    case = Case(a, torch, dev, local, parts, me, world, trows, tcols, solo, a.raw_forcing)
+    sol = case.sol
+    secs, tm = timed_sweeps(case, a.steps, a.warmup, adjoint, barrier)
+    cdev = dev if a.backend == "nccl" else "cpu"
     if world > 1:
-        cdev = dev if a.backend == "nccl" else "cpu"
         t = torch.tensor([secs], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         secs = float(t.item())
@@ -249,12 +410,16 @@ def main():
         cellsteps = float(cs.item())
     else:
         cellsteps = float(sol.ncells) * nt
-    par_b, sta_b = par.copy(), sta.copy()
-    cost = sol.download(adjoint, par, sta, out, par_b, sta_b)
+    par_b, sta_b = case.par.copy(), case.sta.copy()
+    cost = sol.download(adjoint, case.par, case.sta, case.out, par_b, sta_b)
     if world > 1:                                   # global cost = sum of the per-tile partial costs
-        ct = torch.tensor([cost], dtype=torch.float64, device=dev if a.backend == "nccl" else "cpu")
-        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
-        cost = float(ct.item())
+        if case.comm is not None:
+            cost = float(case.comm.allreduce_sum([cost])[0])
+        else:
+            ct = torch.tensor([cost], dtype=torch.float64, device=cdev)
+            dist.all_reduce(ct, op=dist.ReduceOp.SUM)
+            cost = float(ct.item())
+    inclusive = inclusive_call_ms(case, adjoint) if world == 1 and not solo else None
 
     if rank == 0 and a.trace_groups:
         ticks, rnd = sol.group_times()
@@ -271,59 +436,67 @@ def main():
                  "mean_run_ms": float((t[rnd == r, 1] - t[rnd == r, 0]).mean())} for r in np.unique(rnd)]}
         with open(a.trace_groups, "w") as f:
             json.dump(rep, f, indent=1)
+
+    line = None
     if rank == 0:
         K = a.steps
-        ms_per_step = secs * 1e3 / K
-        value = cellsteps * K / secs
-        tm = {k: v / K for k, v in tm_acc.items()}
-        # dominant kernel and its roofline: algorithmic bytes = 8 B per cell-step per vertical pass
-        # (prcp + pet read once forward, once in the reverse pass: SURVEY 8d, 16 B per forward+adjoint cell-step)
-        kern = {"sx_k_vert_fwd": (tm["vert_fwd_ms"], tm["vert_fwd_launches"]),
-                "sx_k_vert_adj": (tm["vert_adj_ms"], tm["vert_adj_launches"]),
-                "sx_k_route_fwd": (tm["route_fwd_ms"], tm["route_fwd_launches"]),
-                "sx_k_route_adj": (tm["route_adj_ms"], tm["route_adj_launches"])}
-        dom = max(kern, key=lambda k: kern[k][0])
-        dom_ms, dom_n = kern[dom]
-        per_launch_steps = float(sol.ncells) * nt / max(tm["n_chunks"], 1)       # cell-steps one launch processes
-        if dom.startswith("sx_k_vert"):
-            alg_bytes = 8.0 * per_launch_steps
-            n_launch = max(dom_n, 1.0)
-            avg_ms = dom_ms / n_launch
-        else:
-            alg_bytes = 4.0 * per_launch_steps       # routing reads qt once; it is not the streaming kernel
-            n_launch = max(tm["n_chunks"], 1)
-            avg_ms = dom_ms / n_launch
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        sweep_bytes = (16.0 if adjoint else 8.0) * float(sol.ncells) * nt
+        pr, pc, nrow, ncol = case.pr, case.pc, case.nrow, case.ncol
+        xch = ("grouped ncclSend/ncclRecv on the routing stream (libsmashx, RCCL)" if case.comm is not None
+               else f"host callback + torch.distributed point-to-point ({a.backend})")
         line = {
             "metric": "cell-timesteps/s, forward+adjoint sweep" if adjoint else "cell-timesteps/s, forward sweep",
-            "value": value, "unit": "cell-timesteps/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": cellsteps * K / secs, "unit": "cell-timesteps/s", "n_gpus": world, "steps": K, "warmup": a.warmup,
+            "ms_per_step": secs * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{nrow}x{ncol} synthetic catchment ({trows}x{tcols} cells per GPU, D8 E/SE/S, all cells active), "
                                    f"hourly x {nt} steps, {a.structure}, nse cost at {a.ng} gauges, one forward+adjoint sweep = cost + "
-                                   "gradient of all distributed parameters and initial states (BASELINE.json configs[2]; tiled: configs[4])",
+                                   "gradient of all distributed parameters and initial states "
+                                   + ("(BASELINE.json configs[2])" if world == 1 else
+                                      "(BASELINE.json configs[4]: the metric's 4096^2 grid)" if (nrow, ncol) == (4096, 4096) else
+                                      "(the per-GPU tile of BASELINE.json configs[4], fewer tiles)"),
                        "grid": [nrow, ncol], "tile": [trows, tcols], "nt": nt, "structure": a.structure, "active_cells": int(cellsteps / nt),
-                       "chunk_steps": int(tm["chunk_steps"]), "n_chunks": int(tm["n_chunks"]),
+                       "chunk_steps": int(tm["chunk_steps"]), "n_chunks": int(tm["n_chunks"]), "pipe_steps": int(tm["pipe_steps"]),
                        "routing_rounds": int(tm["n_rounds"]), "routing_groups": int(tm["n_groups"]),
+                       "forcing": case.forcing,
                        "parallelism": (f"rank {me} of {parts} alone ({a.partition}), no-op exchange" if solo else
-                                       (f"tiles {pr}x{pc}" if a.partition == "rect" else f"{parts} {a.partition} parts of the river tree") +
-                                       ", exchange of boundary discharge series (send/recv)" if world > 1 else "single")},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, per_launch_steps) if a.structure == "gr-b" else None,
-                         "avg_launch_ms": avg_ms, "launches_per_step": n_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "sweep_frac": sweep_bytes / (tm["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "note": "pointwise transcendental-heavy path: the VALU ceiling binds before HBM (DESIGN.md)"},
-            "kernel_ms_per_step": {k: round(v[0], 3) for k, v in kern.items()},
-            "device_sweep_ms": tm["sweep_ms"], "cost": cost, "setup_s": t_setup,
+                                       ((f"tiles {pr}x{pc}" if a.partition == "rect" else f"{parts} {a.partition} parts of the river tree") +
+                                        f", boundary discharge series by {xch}" + (", ranks share GPUs (rehearsal)" if shared else ""))
+                                       if world > 1 else "single")},
+            "roofline": roofline(tm, adjoint, a.structure),
+            "kernel_ms_per_step": {"sx_k_" + k: round(tm[k + "_ms"], 3) for k in KERNELS},
+            "device_sweep_ms": tm["sweep_ms"], "cost": cost, "setup_s": case.setup_s,
             "hbm_plan_gb": tm["device_bytes"] / 1e9,
         }
+        if inclusive is not None:
+            line["inclusive_ms_per_step"] = inclusive
+            line["inclusive_note"] = ("one smashx_forward_b-style call: host parameter/state planes uploaded, sweep, cost + discharge + every "
+                                      "gradient plane downloaded; `value` is the resident-input rate (forcing upload is one-off set-up)")
         if cpu is not None:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line))
+    # N = 1: the 2048 x 2048 grid of configs[3] on the same GPU, attached to the line (checkpointed adjoint; needs the compact forcing)
+    if world == 1 and not solo and not a.no_secondary and not a.raw_forcing and (trows, tcols) == (1024, 1024) and nt == 8760 and a.secondary_grid > 0:
+        case.close()
+        del case, sol
+        g = a.secondary_grid
+        try:
+            c2 = Case(a, torch, dev, local, 1, 0, 1, g, g, False, False)
+            s2, tm2 = timed_sweeps(c2, 2, 1, adjoint, barrier)
+            line["secondary"] = {
+                "workload": f"{g}x{g} synthetic catchment on ONE GPU (the grid of BASELINE.json configs[3]), hourly x {nt} steps, {a.structure}, "
+                            "one forward+adjoint sweep; forcing compact and resident, adjoint checkpointed in storage chunks",
+                "value": float(c2.sol.ncells) * nt * 2 / s2, "unit": "cell-timesteps/s", "steps": 2, "warmup": 1, "ms_per_step": s2 * 1e3 / 2,
+                "n_chunks": int(tm2["n_chunks"]), "chunk_steps": int(tm2["chunk_steps"]), "hbm_plan_gb": tm2["device_bytes"] / 1e9,
+                "forcing": c2.forcing, "kernel_ms_per_step": {"sx_k_" + k: round(tm2[k + "_ms"], 3) for k in KERNELS},
+                "roofline": roofline(tm2, adjoint, a.structure), "setup_s": c2.setup_s}
+            c2.close()
+        except Exception as e:  # pragma: no cover
+            line["secondary"] = {"workload": f"{g}x{g}", "value": None, "error": str(e)}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+        if 'case' in locals():
+            case.close()
         dist.destroy_process_group()
 
 

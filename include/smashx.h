@@ -110,6 +110,8 @@ typedef struct {
     int   vert_fwd_launches, route_fwd_launches, route_adj_launches, vert_adj_launches;
     int   n_chunks, chunk_steps, pipe_steps, n_rounds, n_groups;
     double device_bytes;     /* HBM held by the plan */
+    double cellsteps[4];     /* cell-steps the launches of the last sweep processed: vert_fwd, route_fwd, route_adj, vert_adj
+                                (a checkpointed adjoint runs the forward kernels over most of the period twice) */
 } smashx_timing;
 
 typedef struct smashx_plan smashx_plan;
@@ -119,7 +121,7 @@ int smashx_device_count(void);
 /* ABI guard for bindings that mirror the structs by hand (the Fortran shim, ctypes): sizes in bytes of
  * {smashx_config, smashx_mesh, smashx_options, smashx_parameters, smashx_states, smashx_costs, smashx_timing};
  * returns SMASHX_ABI_VERSION. */
-#define SMASHX_ABI_VERSION 5
+#define SMASHX_ABI_VERSION 6
 int smashx_abi_sizes(int sizes[7]);
 
 /* builds the routing schedule from the mesh and allocates device storage */
@@ -137,6 +139,26 @@ int smashx_set_forcing(smashx_plan* plan, const float* prcp, const float* pet, i
 /* device-resident block: d_prcp/d_pet are DEVICE pointers to (t1-t0, ncells) arrays, cell index in
  * plan order (smashx_plan_cell_order) fastest.  Used by bench.py to build the forcing in HBM. */
 int smashx_set_forcing_device_block(smashx_plan* plan, int t0, int t1, const float* d_prcp, const float* d_pet);
+/* Lossless compact residency of the forcing.  The reference's reader forms every value it stores from far fewer bits:
+ *   prcp(cell, t) = real(k) * prcp_conversion_factor, k the raster's integer depth (0.1 mm units in its datasets), or -99
+ *                   for a missing file            smash/core/_read_input_data.py:176-196, mwd_setup.f90:128
+ *   pet(cell, t)  = daily(cell, day) * ratio(hour) with the 24-entry RATIO_PET_HOURLY table when
+ *                   setup%daily_interannual_pet   _read_input_data.py:223-283, smash/core/_constant.py:47-75
+ * With compact = 1 the plan stores k as uint16 (65535 = the gap marker) and the daily PET field, and the kernels form the fp32
+ * values with the reader's own single fp32 multiply: 2.17 B per cell-step resident instead of 8 (a year of hourly forcing
+ * for 2048^2 cells: 80 GB instead of 294 GB).  Every value handed in is checked BIT FOR BIT against what the kernels will
+ * reconstruct; data that is not of this form is never approximated: smashx_set_forcing falls back to fp32 rows by itself,
+ * smashx_set_forcing_device_block returns SMASHX_E_UNSUPPORTED for the offending block (the caller resets the layout and
+ * sends the blocks again).  Requires dt = 3600 s for the PET form.  Call before the forcing is set; smashx_forcing_info
+ * reports what the plan holds (compact 0/1, resident bytes per cell-step). */
+typedef struct {
+    int compact;           /* 0 = fp32 rows (default), 1 = compact, verified */
+    float prcp_factor;     /* setup%prcp_conversion_factor */
+    float pet_ratio[24];   /* hourly share of the daily PET; hour index = (time step + pet_hour0) mod 24 */
+    int pet_hour0;         /* ratio index of time step 0 (the reference's first step is start_time + dt: 1 for a run starting at midnight) */
+} smashx_forcing_layout;
+int smashx_set_forcing_layout(smashx_plan* plan, const smashx_forcing_layout* layout);
+int smashx_forcing_info(const smashx_plan* plan, int* compact, double* bytes_per_cellstep);
 int smashx_set_qobs(smashx_plan* plan, const float* qobs /* (ng,nt) */);
 int smashx_set_options(smashx_plan* plan, const smashx_options* opt);
 
@@ -204,6 +226,27 @@ int smashx_halo_counts(const smashx_plan* plan, int* n_out, int* n_in);
 int smashx_halo_edges(const smashx_plan* plan, int* out_src, int* out_dst, int* in_src, int* in_dst);
 int smashx_plan_chunking(smashx_plan* plan, int* chunk_steps, int* pipe_steps);   /* fixes and returns the chunk lengths */
 int smashx_set_halo(smashx_plan* plan, float* d_out_buf, float* d_in_buf, smashx_halo_fn fn, void* user);
+
+/* ---- native exchange: grouped ncclSend / ncclRecv on the plan's routing stream ----------------------
+ * The reference has no counterpart (its only parallel code is the OpenMP replica loop, mw_multiple_run.f90:96-117).
+ * One RCCL communicator per process (= per GPU); rank 0 draws the id, every rank calls smashx_comm_create with it (the
+ * launcher moves the 128 bytes: bench.py broadcasts them through torch.distributed).  RCCL is resolved at run time
+ * (dlopen of librccl.so.1: the copy the host process already holds, e.g. PyTorch's, else ROCm's), so single-GPU users
+ * never load it.  With an exchange set, a sweep moves the boundary series of every pipeline sub-chunk itself:
+ *   forward   recv(in edges, grouped by upstream peer) -> unpack -> routing -> pack -> send(out edges, by downstream peer)
+ *   reverse   recv(out edges)                          -> unpack -> routing adjoint -> pack -> send(in edges)
+ * all stream-ordered on the routing stream: no host synchronisation, no callback.  out_peer[n_out] / in_peer[n_in] give
+ * the rank that owns the other end of each boundary edge (edge order of smashx_halo_edges).  Every rank of the
+ * decomposition must cut time identically: smashx_set_exchange checks (all-reduce of chunk_steps / pipe_steps / nt) and
+ * fails with SMASHX_E_ARG on disagreement; a plan with boundary series refuses chunk_steps = 0 (sized from each rank's
+ * own free HBM) with SMASHX_E_ARG.  smashx_comm_allreduce_sum: sum over ranks of n doubles (the global cost =
+ * sum of the per-tile partial costs), host in / host out. */
+#define SMASHX_COMM_ID_BYTES 128
+int smashx_comm_unique_id(unsigned char id[SMASHX_COMM_ID_BYTES]);
+int smashx_comm_create(const unsigned char id[SMASHX_COMM_ID_BYTES], int rank, int nranks, int device, void** comm);
+int smashx_comm_destroy(void* comm);
+int smashx_comm_allreduce_sum(void* comm, double* values, int n);
+int smashx_set_exchange(smashx_plan* plan, void* comm, const int* out_peer, const int* in_peer);
 
 /* ---- diagnostics ---------------------------------------------------------------------------------------
  * Start / end ticks (100 MHz device wall clock) of every routing group in the last forward (pass 0) and adjoint

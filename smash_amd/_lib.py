@@ -6,7 +6,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SMASHX_LIB", os.path.join(_HERE, "libsmashx.so"))   # override only for A/B experiments
+# SMASHX_EXACT_LIBM=1 selects the exact-libm build (glibc's float functions restated, IEEE divisions: csrc/sx_libm.h) -- the
+# slower library that reproduces the reference bit for bit; SMASHX_LIB overrides the path for A/B experiments.
+EXACT = os.environ.get("SMASHX_EXACT_LIBM", "0") not in ("", "0")
+LIB_PATH = os.environ.get("SMASHX_LIB", os.path.join(_HERE, "libsmashx_exact.so" if EXACT else "libsmashx.so"))
 
 GNP, GNS = 16, 8
 
@@ -17,6 +20,8 @@ SYMBOLS = [
     "smashx_plan_cell_order", "smashx_set_forcing", "smashx_set_forcing_device_block", "smashx_set_qobs",
     "smashx_set_options", "smashx_forward", "smashx_forward_b", "smashx_upload", "smashx_sweep", "smashx_download",
     "smashx_get_timing", "smashx_halo_counts", "smashx_halo_edges", "smashx_plan_chunking", "smashx_set_halo", "smashx_tile_probe", "smashx_debug_group_times", "smashx_set_domain_outputs", "smashx_forward_d", "smashx_selftest_math",
+    "smashx_set_forcing_layout", "smashx_forcing_info",
+    "smashx_comm_unique_id", "smashx_comm_create", "smashx_comm_destroy", "smashx_comm_allreduce_sum", "smashx_set_exchange",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
@@ -41,6 +46,10 @@ class Options(C.Structure):
                 ("lb_states", C.c_float * GNS), ("ub_states", C.c_float * GNS), ("wgauge", C.c_void_p)]
 
 
+class ForcingLayout(C.Structure):
+    _fields_ = [("compact", C.c_int), ("prcp_factor", C.c_float), ("pet_ratio", C.c_float * 24), ("pet_hour0", C.c_int)]
+
+
 class Parameters(C.Structure):
     _fields_ = [("f", C.c_void_p * GNP)]
 
@@ -58,7 +67,7 @@ class Timing(C.Structure):
                 ("route_adj_ms", C.c_float), ("vert_adj_ms", C.c_float), ("vert_fwd_launches", C.c_int),
                 ("route_fwd_launches", C.c_int), ("route_adj_launches", C.c_int), ("vert_adj_launches", C.c_int),
                 ("n_chunks", C.c_int), ("chunk_steps", C.c_int), ("pipe_steps", C.c_int), ("n_rounds", C.c_int), ("n_groups", C.c_int),
-                ("device_bytes", C.c_double)]
+                ("device_bytes", C.c_double), ("cellsteps", C.c_double * 4)]
 
 
 class SmashxError(RuntimeError):

@@ -3,6 +3,9 @@
 #include "../../include/smashx.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and prototypes only: the functions are resolved at run time (rccl() below)
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -85,6 +88,72 @@ __global__ void k_scatter(float* dst, const float* src, const int* idx, int n, f
     if (k < n) dst[idx[k]] = scaled ? scale * src[k] : src[k];
 }
 
+// ---- compact forcing: encode + verify (smashx_set_forcing_layout) ---------------------------------------------
+// src: fp32 rows, row r = time step t0 + r, cell k at src[r * ld + (idx ? idx[k] : k)].  A value is accepted only if the kernels'
+// decode reproduces its bits; status[0] counts rejects, status[1] holds the bits of the one gap value (0 = none seen yet).
+__global__ void k_encode_prcp(unsigned short* dst, const float* src, const int* idx, int n, int npad, long ld, int rows, float c,
+                              unsigned* status) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (k >= n || r >= rows) return;
+    const float v = src[(size_t)r * ld + (idx ? idx[k] : k)];
+    unsigned code = 65535u;
+    if (v < 0.f) {
+        const unsigned bits = __float_as_uint(v);
+        const unsigned old = atomicCAS(status + 1, 0u, bits);
+        if (old != 0u && old != bits) atomicAdd(status, 1u);             // a second kind of negative value: not representable
+    } else {
+        const float kf = rintf(v / c);
+        code = (kf >= 0.f && kf < 65535.f) ? (unsigned)kf : 65535u;
+        if (code == 65535u || __float_as_uint((float)code * c) != __float_as_uint(v)) atomicAdd(status, 1u);
+    }
+    dst[(size_t)r * npad + k] = (unsigned short)code;
+}
+// one thread per (cell, day touched by the block): finds the daily value D with D * ratio(h) == pet bit for bit for every hour
+// of the day inside the block (or D < 0 == every hour: a gap day); a day already set by an earlier block is only verified.
+// petd holds NaN while a day is undetermined (only night hours seen so far).
+__global__ void k_encode_pet(float* petd, const float* src, const int* idx, int n, int npad, long ld, int t0, int rows, int hour0,
+                             const float* ratio, unsigned* status) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d0 = (t0 + hour0) / 24, d = d0 + blockIdx.y;
+    if (k >= n) return;
+    const int ta = max(t0, d * 24 - hour0), tb = min(t0 + rows, (d + 1) * 24 - hour0);     // steps of day d in this block
+    if (ta >= tb) return;
+    const size_t col = idx ? idx[k] : k;
+    float* slot = petd + (size_t)d * npad + k;
+    float D = *slot;
+    auto fits = [&](float Dc) {
+        for (int t = ta; t < tb; ++t) {
+            const float v = src[(size_t)(t - t0) * ld + col];
+            const float w = Dc < 0.f ? Dc : Dc * ratio[(t + hour0) % 24];
+            if (__float_as_uint(w) != __float_as_uint(v)) return false;
+        }
+        return true;
+    };
+    if (D == D) { if (!fits(D)) atomicAdd(status, 1u); return; }
+    // the hour with the largest share pins D to within two ulps; a negative value must be the whole day's
+    int tbest = -1; float rbest = 0.f;
+    bool allzero = true;
+    for (int t = ta; t < tb; ++t) {
+        const float v = src[(size_t)(t - t0) * ld + col], r = ratio[(t + hour0) % 24];
+        if (__float_as_uint(v) != 0u) allzero = false;
+        if (v < 0.f) { if (fits(v)) *slot = v; else atomicAdd(status, 1u); return; }
+        if (r > rbest) { rbest = r; tbest = t; }
+    }
+    if (tbest < 0) { if (!allzero) atomicAdd(status, 1u); return; }           // night hours only: any D >= 0 fits, stays open
+    const float v = src[(size_t)(tbest - t0) * ld + col];
+    const unsigned b0 = __float_as_uint(v / rbest);
+    for (int j = 0; j <= 6; ++j) {
+        const int off = (j & 1) ? (j + 1) / 2 : -(j / 2);                       // 0, +1, -1, +2, -2, +3, -3 ulps
+        const float Dc = __uint_as_float(b0 + (unsigned)off);
+        if (Dc >= 0.f && Dc == Dc && fits(Dc)) { *slot = Dc; return; }
+    }
+    atomicAdd(status, 1u);
+}
+__global__ void k_close_petd(float* petd, size_t n) {      // days that only ever showed night hours: any value works, take 0
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i < n && !(petd[i] == petd[i])) petd[i] = 0.f;
+}
+
 // boundary series <-> dense message buffer [edge][Tq] float4
 __global__ void k_halo_pack(float4* buf, const float4* x4, const int* slots, int nedge, int nx, int Tq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,7 +205,58 @@ __global__ void k_gauge_rows(float* dst, const float* src, const int* gid, int n
     if (t < nt && g < ng) dst[(size_t)g * nt + t] = src[(size_t)gid[g] * nt + t];
 }
 
-struct Launch { hipEvent_t a, b; int kind; };
+
+// ---- RCCL, resolved at run time ------------------------------------------------------------------------------
+// The library is not linked: a single-GPU host never loads it, and a host process that already holds an RCCL (PyTorch
+// ships its own librccl.so.1) must not get a second copy -- dlopen by soname returns the copy already mapped.
+struct RcclApi {
+    void* h = nullptr;
+    std::string err;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok() const { return h != nullptr && err.empty(); }
+};
+RcclApi& rccl() {
+    static RcclApi R;
+    static bool tried = false;
+    if (tried) return R;
+    tried = true;
+    const char* names[] = {getenv("SMASHX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        if (!n || !n[0]) continue;
+        R.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (R.h) break;
+    }
+    if (!R.h) { R.err = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return R; }
+#define SX_SYM(f) do { R.f = (decltype(R.f))dlsym(R.h, "nccl" #f); if (!R.f) R.err = "librccl lacks nccl" #f; } while (0)
+    SX_SYM(GetUniqueId); SX_SYM(CommInitRank); SX_SYM(CommDestroy); SX_SYM(Send); SX_SYM(Recv); SX_SYM(AllReduce);
+    SX_SYM(GroupStart); SX_SYM(GroupEnd); SX_SYM(GetErrorString);
+#undef SX_SYM
+    return R;
+}
+#define NCCLCHK(expr)                                                                                   \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess)                                                                          \
+            return fail(SMASHX_E_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+struct SxComm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1, device = -1;
+    hipStream_t stream = nullptr;    // collectives outside the sweeps (agreement check, cost sum)
+    double* d_buf = nullptr;         // 64 doubles
+};
+struct PeerSeg { int rank, first, count; };   // a run of boundary edges that share the peer rank
+
+struct Launch { hipEvent_t a, b; int kind; double cellsteps; };
 
 }  // namespace
 
@@ -160,6 +280,7 @@ struct smashx_plan {
     bool split_v = false;            // SMASHX_SPLIT_V=1: vertical kernels in two cell ranges so that routing round 0 overlaps the second.
                                      // Measured slower (185 vs 175 ms at 1024^2 x 8760: both kernels lose more than the overlap hides): off.
     int n0 = 0;                      // cells of the round-0 groups = [0, n0) in device order
+    std::vector<double> round_ncells;  // cells per routing round
     bool chain_used = false;         // a chained launch ran in the current sweep: check the stall flag afterwards
     bool chain = true;               // all routing rounds in one launch (progress counters), see sx_kernels.h
     // tile boundary exchange
@@ -167,7 +288,12 @@ struct smashx_plan {
     int *d_out_x = nullptr, *d_in_x = nullptr;
     float *halo_out = nullptr, *halo_in = nullptr;   // caller-owned device buffers
     smashx_halo_fn halo_fn = nullptr; void* halo_user = nullptr;
-    std::vector<void*> allocs;
+    // native exchange (smashx_set_exchange): edges regrouped by peer rank, plan-owned message buffers
+    SxComm* xcomm = nullptr;
+    std::vector<PeerSeg> out_segs, in_segs;
+    int *d_out_xp = nullptr, *d_in_xp = nullptr;     // exchange slots of the out / in edges in peer-grouped order
+    float *x_out = nullptr, *x_in = nullptr;         // [edge][Tp/4] float4
+    std::vector<void*> allocs; std::vector<size_t> alloc_bytes;
     double bytes = 0;
     SxDeviceArrays A{};
     // extra device storage
@@ -180,6 +306,10 @@ struct smashx_plan {
     float* st0[5] = {nullptr};       // initial (denormalised) states in cell order
     float* ckpt = nullptr;           // [nchunks][5][npad]
     float* d_prcp = nullptr; float* d_pet = nullptr;
+    // compact forcing (smashx_set_forcing_layout)
+    smashx_forcing_layout flay{};
+    unsigned short* d_prcp16 = nullptr; float* d_petd = nullptr; float* d_ratio = nullptr; unsigned* d_fstatus = nullptr;
+    int ndays = 0; bool petd_open = false;
     // cost
     int ngc = 0;
     std::vector<int> gauge_gid;
@@ -219,8 +349,14 @@ struct smashx_plan {
         const size_t b = std::max<size_t>(count, 1) * sizeof(T);
         hipError_t e = hipMalloc(&q, b);
         if (e != hipSuccess) return fail(SMASHX_E_HIP, std::string("hipMalloc(") + std::to_string(b) + " B): " + hipGetErrorString(e));
-        allocs.push_back(q); bytes += (double)b; *p = (T*)q;
+        allocs.push_back(q); alloc_bytes.push_back(b); bytes += (double)b; *p = (T*)q;
         return 0;
+    }
+    void dfree(void* q) {
+        if (!q) return;
+        for (size_t i = 0; i < allocs.size(); ++i)
+            if (allocs[i] == q) { bytes -= (double)alloc_bytes[i]; allocs.erase(allocs.begin() + i); alloc_bytes.erase(alloc_bytes.begin() + i); break; }
+        (void)hipFree(q);
     }
     template <class T> int upload_vec(T** p, const std::vector<T>& v) {
         int rc = dmalloc(p, v.size()); if (rc) return rc;
@@ -232,7 +368,11 @@ struct smashx_plan {
         return pool[pool_used++];
     }
     hipStream_t cur = nullptr;       // stream of the launch being marked
-    void mark_begin(int kind, hipStream_t st) { cur = st; Launch l; l.a = event(); l.b = nullptr; l.kind = kind; if (l.a) (void)hipEventRecord(l.a, st); launches.push_back(l); }
+    void mark_begin(int kind, hipStream_t st, double cellsteps = 0.0) {
+        cur = st; Launch l; l.a = event(); l.b = nullptr; l.kind = kind; l.cellsteps = cellsteps;
+        if (l.a) (void)hipEventRecord(l.a, st);
+        launches.push_back(l);
+    }
     void mark_end() { Launch& l = launches.back(); l.b = event(); if (l.b) (void)hipEventRecord(l.b, cur); }
 };
 
@@ -257,6 +397,10 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
     const double ntape_lean = has_hi ? ntape_full - 1.0 + 1.0 / SX_HIK : ntape_full;
     double ntape = ntape_full;
     if (!p->chunk_ready) {
+        // a tile's neighbours must cut time exactly like it does (one message per sub-chunk): lengths sized from this
+        // rank's own free HBM would differ between ranks and end in mismatched send/recv sizes
+        if ((p->n_out > 0 || p->n_in > 0) && p->cfg.chunk_steps <= 0)
+            return fail(SMASHX_E_ARG, "a tile with boundary series needs an explicit chunk_steps (identical on every rank; pipe_steps = 0 then means no sub-chunks)");
         const int nt16 = (p->nt + 15) / 16 * 16;
         int Tc = p->cfg.chunk_steps > 0 ? (p->cfg.chunk_steps + 15) / 16 * 16 : 0;
         if (Tc == 0) {
@@ -345,7 +489,7 @@ SxDeviceArrays view_at(const smashx_plan* p, int off) {
 template <int ST>
 void launch_vert_fwd(smashx_plan* p, const SxDeviceArrays& B, bool tape, int t0, int T) {
     const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
-    p->mark_begin(0, p->stream);
+    p->mark_begin(0, p->stream, (double)(B.k1 - B.k0) * T);
     if (tape) hipLaunchKernelGGL((sx_k_vert_fwd<ST, true>), grid, block, 0, p->stream, B, t0, T);
     else      hipLaunchKernelGGL((sx_k_vert_fwd<ST, false>), grid, block, 0, p->stream, B, t0, T);
     p->mark_end();
@@ -360,7 +504,7 @@ void vert_fwd(smashx_plan* p, int off, bool tape, int t0, int T, int k0 = 0, int
         case 3: launch_vert_fwd<3>(p, B, tape, t0, T); break;
         case 5: {
             const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
-            p->mark_begin(0, p->stream);
+            p->mark_begin(0, p->stream, (double)(B.k1 - B.k0) * T);
             if (tape) hipLaunchKernelGGL((sx_k_vert_fwd_vic<true>), grid, block, 0, p->stream, B, t0, T);
             else      hipLaunchKernelGGL((sx_k_vert_fwd_vic<false>), grid, block, 0, p->stream, B, t0, T);
             p->mark_end();
@@ -373,7 +517,7 @@ void vert_adj(smashx_plan* p, int off, int t0, int T, int k0 = 0, int k1 = -1) {
     B.k0 = k0; B.k1 = k1 < 0 ? p->n : k1;
     if (B.k1 <= B.k0) return;
     const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
-    p->mark_begin(3, p->stream);
+    p->mark_begin(3, p->stream, (double)(B.k1 - B.k0) * T);
     switch (p->st) {
         case 1: hipLaunchKernelGGL((sx_k_vert_adj<1>), grid, block, 0, p->stream, B, t0, T); break;
         case 2: hipLaunchKernelGGL((sx_k_vert_adj<2>), grid, block, 0, p->stream, B, t0, T); break;
@@ -387,6 +531,11 @@ void vert_adj(smashx_plan* p, int off, int t0, int T, int k0 = 0, int k1 = -1) {
 // HBM-bound); the narrow, latency-bound rounds from chain_from on run chained inside a single launch
 // (sx_kernels.h "rounds chained inside one launch"), which turns their sum into roughly the longest of them.
 // wait_rest: event the launches after round 0 have to wait for (the vertical kernel of the cells outside round 0)
+double round_cells(const smashx_plan* p, int r0, int r1) {   // cells (inlets excluded) of the groups of rounds [r0, r1)
+    double c = 0.0;
+    for (int r = r0; r < r1; ++r) c += p->round_ncells[r];
+    return c;
+}
 void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T, hipEvent_t wait_rest = nullptr) {
     SxDeviceArrays B = view_at(p, off);
     if (!p->dom_q_active) B.qdT = nullptr;
@@ -396,7 +545,7 @@ void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T, hipEvent_t wai
     for (int r = 0; r < cf; ++r) {
         if (r == 1 && wait_rest) (void)hipStreamWaitEvent(p->stream_r, wait_rest, 0);
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
-        p->mark_begin(1, p->stream_r);
+        p->mark_begin(1, p->stream_r, round_cells(p, r, r + 1) * T);
         if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
         else      hipLaunchKernelGGL((sx_k_route_fwd<false, false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
         p->mark_end();
@@ -405,7 +554,7 @@ void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T, hipEvent_t wai
         const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
         if (cf <= 1 && wait_rest) (void)hipStreamWaitEvent(p->stream_r, wait_rest, 0);
         (void)hipMemsetAsync(p->A.prog, 0, (size_t)p->sch.ngroups * sizeof(int), p->stream_r);
-        p->mark_begin(1, p->stream_r);
+        p->mark_begin(1, p->stream_r, round_cells(p, cf, nr) * T);
         if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(g1 - g0), dim3(p->M), lds, p->stream_r, B, g0, g1, t0, T);
         else      hipLaunchKernelGGL((sx_k_route_fwd<false, true>), dim3(g1 - g0), dim3(p->M), lds, p->stream_r, B, g0, g1, t0, T);
         p->mark_end();
@@ -421,7 +570,7 @@ void route_adj(smashx_plan* p, int off, int t0, int T, hipEvent_t after_rest = n
     if (cf < nr) {
         const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
         (void)hipMemsetAsync(p->A.prog, 0, (size_t)p->sch.ngroups * sizeof(int), p->stream_r);
-        p->mark_begin(2, p->stream_r);
+        p->mark_begin(2, p->stream_r, round_cells(p, cf, nr) * T);
         hipLaunchKernelGGL((sx_k_route_adj<true>), dim3(g1 - g0), dim3(p->M), lds, p->stream_r, B, g0, g1, t0, T);
         p->mark_end();
         p->chain_used = true;
@@ -430,7 +579,7 @@ void route_adj(smashx_plan* p, int off, int t0, int T, hipEvent_t after_rest = n
     for (int r = cf - 1; r >= 0; --r) {
         if (r == 0 && cf > 1 && after_rest) (void)hipEventRecord(after_rest, p->stream_r);
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
-        p->mark_begin(2, p->stream_r);
+        p->mark_begin(2, p->stream_r, round_cells(p, r, r + 1) * T);
         hipLaunchKernelGGL((sx_k_route_adj<false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
         p->mark_end();
     }
@@ -549,10 +698,17 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         p->chain = !(e && e[0] == '0');
         const char* sv = getenv("SMASHX_SPLIT_V");
         p->split_v = sv && sv[0] == '1';
-        for (int g = p->sch.round_group_begin[0]; g < p->sch.round_group_begin[1]; ++g)
-            for (int q = p->sch.g_slot_begin[g]; q < p->sch.g_slot_begin[g + 1]; ++q) p->n0 += p->sch.s_cell[q] >= 0;
+        p->round_ncells.assign(p->sch.nrounds, 0.0);
+        for (int r = 0; r < p->sch.nrounds; ++r)
+            for (int g = p->sch.round_group_begin[r]; g < p->sch.round_group_begin[r + 1]; ++g)
+                for (int q = p->sch.g_slot_begin[g]; q < p->sch.g_slot_begin[g + 1]; ++q) p->round_ncells[r] += p->sch.s_cell[q] >= 0;
+        p->n0 = (int)p->round_ncells[0];
         const char* cfm = getenv("SMASHX_CHAIN_FROM");
         p->chain_from = cfm ? std::max(0, atoi(cfm)) : 1;
+        A.spin_limit = SX_SPIN_LIMIT; A.mute_group = -1;
+        if (const char* sl = getenv("SMASHX_SPIN_LIMIT")) A.spin_limit = std::max(1, atoi(sl));
+        if (const char* mg = getenv("SMASHX_DEBUG_MUTE_GROUP")) A.mute_group = atoi(mg);     // tests of the stall path only
+        if (A.mute_group < -1) A.mute_group = p->sch.round_group_begin[std::min(p->chain_from, p->sch.nrounds - 1)];   // "the first chained group"
         A.gtime = nullptr;
         const char* tr = getenv("SMASHX_TRACE_GROUPS");
         if (tr && tr[0] == '1') {
@@ -657,11 +813,84 @@ int smashx_plan_cell_order(const smashx_plan* p, int* rows, int* cols) {
 }
 
 static int alloc_forcing(smashx_plan* p) {
-    if (p->d_prcp) return 0;
+    if (p->d_prcp || p->d_prcp16) return 0;
     int rc;
+    if (p->flay.compact) {
+        p->ndays = (p->nt + p->flay.pet_hour0 + 23) / 24;
+        if ((rc = p->dmalloc(&p->d_prcp16, (size_t)p->nt * p->npad))) return rc;
+        if ((rc = p->dmalloc(&p->d_petd, (size_t)p->ndays * p->npad))) return rc;
+        if ((rc = p->dmalloc(&p->d_ratio, 24))) return rc;
+        if ((rc = p->dmalloc(&p->d_fstatus, 2))) return rc;
+        HIPCHK(hipMemset(p->d_prcp16, 0, (size_t)p->nt * p->npad * sizeof(unsigned short)));
+        HIPCHK(hipMemset(p->d_petd, 0xFF, (size_t)p->ndays * p->npad * sizeof(float)));      // NaN = "day not determined yet"
+        HIPCHK(hipMemset(p->d_fstatus, 0, 2 * sizeof(unsigned)));
+        HIPCHK(hipMemcpy(p->d_ratio, p->flay.pet_ratio, 24 * sizeof(float), hipMemcpyHostToDevice));
+        p->A.prcp16 = p->d_prcp16; p->A.petd = p->d_petd; p->A.pet_ratio = p->d_ratio;
+        p->A.prcp_c = p->flay.prcp_factor; p->A.prcp_gap = -99.f; p->A.hour0 = p->flay.pet_hour0;
+        p->A.prcp = nullptr; p->A.pet = nullptr;
+        return 0;
+    }
     if ((rc = p->dmalloc(&p->d_prcp, (size_t)p->nt * p->npad))) return rc;
     if ((rc = p->dmalloc(&p->d_pet, (size_t)p->nt * p->npad))) return rc;
     p->A.prcp = p->d_prcp; p->A.pet = p->d_pet;
+    p->A.prcp16 = nullptr; p->A.petd = nullptr; p->A.pet_ratio = nullptr;
+    return 0;
+}
+
+static void drop_compact(smashx_plan* p) {
+    p->dfree(p->d_prcp16); p->dfree(p->d_petd); p->dfree(p->d_ratio); p->dfree(p->d_fstatus);
+    p->d_prcp16 = nullptr; p->d_petd = nullptr; p->d_ratio = nullptr; p->d_fstatus = nullptr;
+    p->A.prcp16 = nullptr; p->A.petd = nullptr; p->A.pet_ratio = nullptr;
+    p->flay.compact = 0;
+}
+
+// encode + verify rows [t0, t0 + rows) from fp32 device rows (row stride ld, cell k at idx[k] or k); *ok = every value is
+// reproduced bit for bit by the kernels' decode
+static int encode_block(smashx_plan* p, int t0, int rows, const float* d_prcp_src, const float* d_pet_src, const int* idx, long ld,
+                        hipStream_t st, bool* ok) {
+    const int h0 = p->flay.pet_hour0;
+    const int d0 = (t0 + h0) / 24, d1 = (t0 + rows - 1 + h0) / 24;
+    for (int r0 = 0; r0 < rows; r0 += 32768) {      // grid.y limit
+        const int rr = std::min(32768, rows - r0);
+        hipLaunchKernelGGL(k_encode_prcp, dim3((p->n + 255) / 256, rr), dim3(256), 0, st, p->d_prcp16 + (size_t)(t0 + r0) * p->npad,
+                           d_prcp_src + (size_t)r0 * ld, idx, p->n, p->npad, ld, rr, p->flay.prcp_factor, p->d_fstatus);
+    }
+    hipLaunchKernelGGL(k_encode_pet, dim3((p->n + 255) / 256, d1 - d0 + 1), dim3(256), 0, st, p->d_petd, d_pet_src, idx, p->n, p->npad, ld,
+                       t0, rows, h0, p->d_ratio, p->d_fstatus);
+    unsigned status[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(status, p->d_fstatus, sizeof(status), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    *ok = status[0] == 0;
+    if (status[1]) { float g; std::memcpy(&g, &status[1], 4); p->A.prcp_gap = g; }
+    p->petd_open = true;
+    return 0;
+}
+
+int smashx_set_forcing_layout(smashx_plan* p, const smashx_forcing_layout* lay) {
+    if (!p || !lay) return fail(SMASHX_E_ARG, "null argument");
+    if (p->d_prcp || p->d_prcp16) {
+        if (p->have_forcing && !p->d_prcp16 == !lay->compact) return fail(SMASHX_E_STATE, "the forcing is already resident in this layout");
+        int rc = set_device(p); if (rc) return rc;                     // reset: drop what is resident, the caller sends the forcing again
+        HIPCHK(hipStreamSynchronize(p->stream)); HIPCHK(hipStreamSynchronize(p->stream_r));
+        drop_compact(p);
+        p->dfree(p->d_prcp); p->dfree(p->d_pet); p->d_prcp = p->d_pet = nullptr; p->A.prcp = p->A.pet = nullptr;
+        p->have_forcing = false;
+    }
+    if (lay->compact) {
+        if (p->cfg.dt != 3600.f) return fail(SMASHX_E_UNSUPPORTED, "compact forcing: the daily-PET form is defined for dt = 3600 s");
+        if (!(lay->prcp_factor > 0.f) || lay->pet_hour0 < 0 || lay->pet_hour0 > 23) return fail(SMASHX_E_ARG, "bad prcp_factor / pet_hour0");
+        for (int h = 0; h < 24; ++h) if (!(lay->pet_ratio[h] >= 0.f)) return fail(SMASHX_E_ARG, "pet_ratio must be >= 0");
+    }
+    p->flay = *lay;
+    return 0;
+}
+
+int smashx_forcing_info(const smashx_plan* p, int* compact, double* bytes_per_cellstep) {
+    if (!p) return fail(SMASHX_E_ARG, "null plan");
+    const bool c = p->d_prcp16 != nullptr || (!p->d_prcp && p->flay.compact);
+    if (compact) *compact = c ? 1 : 0;
+    if (bytes_per_cellstep) *bytes_per_cellstep = c ? 2.0 + 4.0 * ((p->nt + p->flay.pet_hour0 + 23) / 24) / (double)p->nt : 8.0;
     return 0;
 }
 
@@ -669,19 +898,44 @@ int smashx_set_forcing(smashx_plan* p, const float* prcp, const float* pet, int 
     if (!p || !prcp || !pet) return fail(SMASHX_E_ARG, "null argument");
     int rc = set_device(p); if (rc) return rc;
     if (sparse && !p->d_sparse_idx) return fail(SMASHX_E_ARG, "sparse forcing needs mesh.path at plan creation");
-    if ((rc = alloc_forcing(p))) return rc;
     const long plane = sparse ? p->n : p->n2;
     const int* idx = sparse ? p->d_sparse_idx : p->d_cell_flat;
-    const float* src[2] = {prcp, pet};
-    float* dst[2] = {p->d_prcp, p->d_pet};
-    for (int v = 0; v < 2; ++v)
-        for (int t = 0; t < p->nt; t += (int)p->stage_planes) {
-            const int rows = (int)std::min<long>(p->stage_planes, p->nt - t);
-            HIPCHK(hipMemcpyAsync(p->d_stage, src[v] + (size_t)t * plane, (size_t)rows * plane * 4, hipMemcpyHostToDevice, p->stream));
-            hipLaunchKernelGGL(k_gather_rows, dim3((p->n + 255) / 256, rows), dim3(256), 0, p->stream,
-                               dst[v] + (size_t)t * p->npad, p->d_stage, idx, p->n, p->npad, plane, rows);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if ((rc = alloc_forcing(p))) return rc;
+        const bool compact = p->d_prcp16 != nullptr;
+        bool ok = true;
+        if (compact) {
+            // staged in blocks of whole days, so that a day's PET is determined from all of its hours at once; both variables of a
+            // block share the staging buffer
+            const long half = std::max<long>(1, p->stage_planes / 2);
+            for (int t = 0; t < p->nt && ok;) {
+                int rows = (int)std::min<long>(half, p->nt - t);
+                const int to_day_end = 24 - (t + p->flay.pet_hour0) % 24;
+                if (rows > to_day_end) rows = to_day_end + (rows - to_day_end) / 24 * 24;
+                float* sp = p->d_stage; float* se = p->d_stage + (size_t)half * p->n2;
+                HIPCHK(hipMemcpyAsync(sp, prcp + (size_t)t * plane, (size_t)rows * plane * 4, hipMemcpyHostToDevice, p->stream));
+                HIPCHK(hipMemcpyAsync(se, pet + (size_t)t * plane, (size_t)rows * plane * 4, hipMemcpyHostToDevice, p->stream));
+                if ((rc = encode_block(p, t, rows, sp, se, idx, plane, p->stream, &ok))) return rc;
+                t += rows;
+            }
+            if (ok) break;
+            // not of the reader's form: never approximate -- keep the fp32 rows
             HIPCHK(hipStreamSynchronize(p->stream));
+            drop_compact(p);
+            continue;
         }
+        const float* src[2] = {prcp, pet};
+        float* dst[2] = {p->d_prcp, p->d_pet};
+        for (int v = 0; v < 2; ++v)
+            for (int t = 0; t < p->nt; t += (int)p->stage_planes) {
+                const int rows = (int)std::min<long>(p->stage_planes, p->nt - t);
+                HIPCHK(hipMemcpyAsync(p->d_stage, src[v] + (size_t)t * plane, (size_t)rows * plane * 4, hipMemcpyHostToDevice, p->stream));
+                hipLaunchKernelGGL(k_gather_rows, dim3((p->n + 255) / 256, rows), dim3(256), 0, p->stream,
+                                   dst[v] + (size_t)t * p->npad, p->d_stage, idx, p->n, p->npad, plane, rows);
+                HIPCHK(hipStreamSynchronize(p->stream));
+            }
+        break;
+    }
     p->have_forcing = true;
     return 0;
 }
@@ -690,6 +944,17 @@ int smashx_set_forcing_device_block(smashx_plan* p, int t0, int t1, const float*
     if (!p || !d_prcp || !d_pet || t0 < 0 || t1 > p->nt || t0 >= t1) return fail(SMASHX_E_ARG, "bad block");
     int rc = set_device(p); if (rc) return rc;
     if ((rc = alloc_forcing(p))) return rc;
+    if (p->d_prcp16) {
+        bool ok = true;
+        if ((rc = encode_block(p, t0, t1 - t0, d_prcp, d_pet, nullptr, (long)p->n, p->stream, &ok))) return rc;
+        if (!ok) {
+            HIPCHK(hipMemset(p->d_fstatus, 0, sizeof(unsigned)));
+            return fail(SMASHX_E_UNSUPPORTED, "forcing block [" + std::to_string(t0) + ", " + std::to_string(t1) + ") is not of the compact form "
+                        "(prcp = k * factor with k < 65535 or one gap value; pet = daily * ratio(hour)): reset the layout to fp32 and send the forcing again");
+        }
+        p->have_forcing = true;
+        return 0;
+    }
     HIPCHK(hipMemcpy2DAsync(p->d_prcp + (size_t)t0 * p->npad, (size_t)p->npad * 4, d_prcp, (size_t)p->n * 4, (size_t)p->n * 4, t1 - t0, hipMemcpyDeviceToDevice, p->stream));
     HIPCHK(hipMemcpy2DAsync(p->d_pet + (size_t)t0 * p->npad, (size_t)p->npad * 4, d_pet, (size_t)p->n * 4, (size_t)p->n * 4, t1 - t0, hipMemcpyDeviceToDevice, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -865,15 +1130,44 @@ int smashx_upload(smashx_plan* p, const smashx_parameters* params, const smashx_
     return 0;
 }
 
+static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_out);
+static int close_forcing(smashx_plan* p) {       // compact PET: days that never showed a daytime hour take the value 0
+    if (!p->petd_open || !p->d_petd) return 0;
+    const size_t n = (size_t)p->ndays * p->npad;
+    hipLaunchKernelGGL(k_close_petd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, p->stream, p->d_petd, n);
+    p->petd_open = false;
+    return 0;
+}
+
+// A chained routing launch only makes progress if the groups it waits for are resident or get dispatched (workgroups are
+// dispatched in blockIdx order; HIP does not promise that).  A waiting group that exhausts its poll limit raises a flag and
+// the sweep's results are void: the plan then drops to one launch per round for good and the sweep is run again.
 int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
+    bool stalled = false;
+    int rc = sweep_once(p, adjoint, cost_b, &stalled);
+    if (rc || !stalled) return rc;
+    if (p->xcomm || p->halo_fn)      // the neighbours of a tile cannot be made to repeat their sweep from here
+        return fail(SMASHX_E_HIP, "chained routing launch stalled waiting for an upstream group (results invalid); set SMASHX_CHAIN_ROUNDS=0");
+    fprintf(stderr, "smashx: a chained routing launch stalled (poll limit reached); this plan now runs one launch per routing round\n");
+    p->chain = false;
+    p->A.mute_group = -1;
+    rc = sweep_once(p, adjoint, cost_b, &stalled);
+    if (rc) return rc;
+    return stalled ? fail(SMASHX_E_HIP, "routing stalled without chained rounds (internal error)") : 0;
+}
+
+static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_out) {
+    *stalled_out = false;
     if (!p) return fail(SMASHX_E_ARG, "null plan");
     if (!p->have_forcing) return fail(SMASHX_E_STATE, "forcing not set");
     if (!p->uploaded) return fail(SMASHX_E_STATE, "parameters/states not uploaded");
     int rc = set_device(p); if (rc) return rc;
     if ((rc = ensure_chunk_buffers(p, adjoint != 0))) return rc;
-    if ((p->n_out > 0 || p->n_in > 0) && !p->halo_fn) return fail(SMASHX_E_STATE, "tile has boundary series but no halo exchange is set (smashx_set_halo)");
+    if ((p->n_out > 0 || p->n_in > 0) && !p->halo_fn && !p->xcomm)
+        return fail(SMASHX_E_STATE, "tile has boundary series but no exchange is set (smashx_set_exchange / smashx_set_halo)");
     p->launches.clear(); p->pool_used = 0;
     hipStream_t sV = p->stream, sR = p->stream_r;
+    if ((rc = close_forcing(p))) return rc;
     HIPCHK(hipEventRecord(p->ev0, sV));
     HIPCHK(hipStreamWaitEvent(sR, p->ev0, 0));
     p->chain_used = false;
@@ -886,20 +1180,53 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     const int C = p->nchunks;
     auto nsub_of = [&](int T) { return (T + p->Tp - 1) / p->Tp; };
     // forward over one storage chunk: V(j) on the V stream, R(j) on the R stream as soon as V(j) is done
-    const bool halo = p->halo_fn && (p->n_out > 0 || p->n_in > 0);
-    // move the boundary series of one sub-chunk between the exchange rows and the caller's message buffers
+    const bool native = p->xcomm != nullptr;
+    const bool halo = (p->halo_fn || native) && (p->n_out > 0 || p->n_in > 0);
+    // move the boundary series of one sub-chunk between the exchange rows and the message buffers (the caller's, or the
+    // plan's own in peer-grouped edge order when RCCL carries them)
     auto halo_move = [&](bool pack, bool out_edges, int off, int T) {
         const int nedge = out_edges ? p->n_out : p->n_in;
         if (nedge == 0) return;
         const int Tq = (T + 3) / 4;
         float4* x4 = reinterpret_cast<float4*>(p->A.xT) + (size_t)(off / 4) * p->A.nx;
-        float4* buf = reinterpret_cast<float4*>(out_edges ? p->halo_out : p->halo_in);
-        const int* slots = out_edges ? p->d_out_x : p->d_in_x;
+        float4* buf = reinterpret_cast<float4*>(native ? (out_edges ? p->x_out : p->x_in) : (out_edges ? p->halo_out : p->halo_in));
+        const int* slots = native ? (out_edges ? p->d_out_xp : p->d_in_xp) : (out_edges ? p->d_out_x : p->d_in_x);
         const dim3 g((nedge * Tq + 255) / 256), b(256);
         if (pack) hipLaunchKernelGGL(k_halo_pack, g, b, 0, sR, buf, x4, slots, nedge, p->A.nx, Tq);
         else hipLaunchKernelGGL(k_halo_unpack, g, b, 0, sR, x4, buf, slots, nedge, p->A.nx, Tq);
     };
+    // one grouped send or recv per sub-chunk: a message per peer = its edges x the sub-chunk's steps, stream-ordered on sR
+    auto xfer = [&](bool send, bool out_edges, int T) -> int {
+        const std::vector<PeerSeg>& segs = out_edges ? p->out_segs : p->in_segs;
+        if (segs.empty()) return 0;
+        RcclApi& R = rccl();
+        float* buf = out_edges ? p->x_out : p->x_in;
+        const size_t per_edge = (size_t)((T + 3) / 4) * 4;
+        static const bool trace = getenv("SMASHX_TRACE_XFER") != nullptr;     // debugging aid: one line per posted group, completion awaited
+        if (trace) {
+            std::string peers;
+            for (const PeerSeg& sg : segs) peers += " " + std::to_string(sg.rank) + ":" + std::to_string(sg.count);
+            fprintf(stderr, "[smashx rank %d] %s %s edges, %d steps, peers(rank:edges)%s\n", p->xcomm->rank, send ? "send" : "recv",
+                    out_edges ? "out" : "in", T, peers.c_str());
+        }
+        NCCLCHK(R.GroupStart());
+        for (const PeerSeg& sg : segs) {
+            float* b = buf + (size_t)sg.first * per_edge;
+            const ncclResult_t r = send ? R.Send(b, (size_t)sg.count * per_edge, ncclFloat, sg.rank, p->xcomm->comm, sR)
+                                        : R.Recv(b, (size_t)sg.count * per_edge, ncclFloat, sg.rank, p->xcomm->comm, sR);
+            if (r != ncclSuccess) { (void)R.GroupEnd(); return fail(SMASHX_E_HIP, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(r)); }
+        }
+        NCCLCHK(R.GroupEnd());
+        if (trace) {
+            HIPCHK(hipStreamSynchronize(sR));
+            fprintf(stderr, "[smashx rank %d]   ... completed\n", p->xcomm->rank);
+        }
+        return 0;
+    };
+    // phases as in smashx_halo_fn: 0 FWD_RECV (in), 1 FWD_SEND (out), 2 ADJ_RECV (out), 3 ADJ_SEND (in)
     auto hook = [&](int phase, int t0, int T) -> int {
+        if (native) return xfer(phase == 1 || phase == 3, phase == 1 || phase == 2, T);
+        if (phase == 1 || phase == 3) HIPCHK(hipStreamSynchronize(sR));     // the packed buffer must be complete before the host moves it
         const int rc2 = p->halo_fn(p->halo_user, phase, t0, T);
         return rc2 ? fail(SMASHX_E_ARG, "halo callback failed") : 0;
     };
@@ -935,7 +1262,6 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
             route_fwd(p, off, tape, t0c + off, T, ev_rest[jb]);
             if (halo && p->n_out > 0) {
                 halo_move(true, true, off, T);
-                HIPCHK(hipStreamSynchronize(sR));
                 if ((rc = hook(1, t0c + off, T))) return rc;
             }
         }
@@ -1044,7 +1370,6 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
                 }
                 if (halo && p->n_in > 0) {
                     halo_move(true, false, off, T);
-                    HIPCHK(hipStreamSynchronize(sR));
                     if ((rc = hook(3, t0c + off, T))) return rc;
                 }
             }
@@ -1063,7 +1388,7 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     if (p->chain_used) {
         int stalled = 0;
         HIPCHK(hipMemcpy(&stalled, p->A.prog + p->sch.ngroups, sizeof(int), hipMemcpyDeviceToHost));
-        if (stalled) return fail(SMASHX_E_HIP, "chained routing launch stalled waiting for an upstream group (results invalid); set SMASHX_CHAIN_ROUNDS=0");
+        if (stalled) { *stalled_out = true; return 0; }
     }
     // timing
     smashx_timing& tm = p->timing;
@@ -1073,10 +1398,10 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
         float ms = 0.f;
         if (l.a && l.b) (void)hipEventElapsedTime(&ms, l.a, l.b);
         switch (l.kind) {
-            case 0: tm.vert_fwd_ms += ms; tm.vert_fwd_launches++; break;
-            case 1: tm.route_fwd_ms += ms; tm.route_fwd_launches++; break;
-            case 2: tm.route_adj_ms += ms; tm.route_adj_launches++; break;
-            case 3: tm.vert_adj_ms += ms; tm.vert_adj_launches++; break;
+            case 0: tm.vert_fwd_ms += ms; tm.vert_fwd_launches++; tm.cellsteps[0] += l.cellsteps; break;
+            case 1: tm.route_fwd_ms += ms; tm.route_fwd_launches++; tm.cellsteps[1] += l.cellsteps; break;
+            case 2: tm.route_adj_ms += ms; tm.route_adj_launches++; tm.cellsteps[2] += l.cellsteps; break;
+            case 3: tm.vert_adj_ms += ms; tm.vert_adj_launches++; tm.cellsteps[3] += l.cellsteps; break;
             default: tm.cost_ms += ms; break;
         }
     }
@@ -1171,6 +1496,132 @@ int smashx_set_halo(smashx_plan* p, float* d_out_buf, float* d_in_buf, smashx_ha
     if (!p) return fail(SMASHX_E_ARG, "null plan");
     if (fn && ((p->n_out > 0 && !d_out_buf) || (p->n_in > 0 && !d_in_buf))) return fail(SMASHX_E_ARG, "halo buffers missing");
     p->halo_out = d_out_buf; p->halo_in = d_in_buf; p->halo_fn = fn; p->halo_user = user;
+    return 0;
+}
+
+// ---- native exchange over RCCL -----------------------------------------------------------------------------------
+int smashx_comm_unique_id(unsigned char id[SMASHX_COMM_ID_BYTES]) {
+    if (!id) return fail(SMASHX_E_ARG, "null argument");
+    RcclApi& R = rccl();
+    if (!R.ok()) return fail(SMASHX_E_UNSUPPORTED, "RCCL unavailable: " + R.err);
+    static_assert(sizeof(ncclUniqueId) == SMASHX_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    NCCLCHK(R.GetUniqueId(&u));
+    std::memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int smashx_comm_create(const unsigned char id[SMASHX_COMM_ID_BYTES], int rank, int nranks, int device, void** comm) {
+    if (!id || !comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(SMASHX_E_ARG, "bad argument");
+    *comm = nullptr;
+    RcclApi& R = rccl();
+    if (!R.ok()) return fail(SMASHX_E_UNSUPPORTED, "RCCL unavailable: " + R.err);
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    SxComm* c = new SxComm();
+    c->rank = rank; c->nranks = nranks; c->device = device;
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    ncclResult_t r = R.CommInitRank(&c->comm, nranks, u, rank);
+    if (r != ncclSuccess) { delete c; return fail(SMASHX_E_HIP, std::string("ncclCommInitRank: ") + R.GetErrorString(r)); }
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipMalloc((void**)&c->d_buf, 64 * sizeof(double)) != hipSuccess) {
+        (void)R.CommDestroy(c->comm); delete c; return fail(SMASHX_E_HIP, "hipStreamCreate / hipMalloc failed");
+    }
+    *comm = c;
+    return 0;
+}
+
+int smashx_comm_destroy(void* comm) {
+    SxComm* c = (SxComm*)comm;
+    if (!c) return 0;
+    if (c->device >= 0) (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->d_buf) (void)hipFree(c->d_buf);
+    if (c->comm) (void)rccl().CommDestroy(c->comm);
+    delete c;
+    return 0;
+}
+
+int smashx_comm_allreduce_sum(void* comm, double* values, int n) {
+    SxComm* c = (SxComm*)comm;
+    if (!c || !values || n < 1 || n > 64) return fail(SMASHX_E_ARG, "bad argument (1 <= n <= 64)");
+    if (c->device >= 0) HIPCHK(hipSetDevice(c->device));
+    RcclApi& R = rccl();
+    HIPCHK(hipMemcpyAsync(c->d_buf, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(R.AllReduce(c->d_buf, c->d_buf, (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+    HIPCHK(hipMemcpyAsync(values, c->d_buf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int smashx_set_exchange(smashx_plan* p, void* comm, const int* out_peer, const int* in_peer) {
+    if (!p) return fail(SMASHX_E_ARG, "null plan");
+    SxComm* c = (SxComm*)comm;
+    if (!c) { p->xcomm = nullptr; return 0; }
+    if ((p->n_out > 0 && !out_peer) || (p->n_in > 0 && !in_peer)) return fail(SMASHX_E_ARG, "peer lists missing");
+    int rc = set_device(p); if (rc) return rc;
+    if ((rc = ensure_chunk_buffers(p, false))) return rc;
+    // every rank must cut time identically: the messages are per pipeline sub-chunk
+    {
+        RcclApi& R = rccl();
+        double v[6] = {(double)p->Tc, -(double)p->Tc, (double)p->Tp, -(double)p->Tp, (double)p->nt, -(double)p->nt};
+        HIPCHK(hipMemcpyAsync(c->d_buf, v, sizeof(v), hipMemcpyHostToDevice, c->stream));
+        NCCLCHK(R.AllReduce(c->d_buf, c->d_buf, 6, ncclDouble, ncclMax, c->comm, c->stream));
+        HIPCHK(hipMemcpyAsync(v, c->d_buf, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (v[0] != -v[1] || v[2] != -v[3] || v[4] != -v[5])
+            return fail(SMASHX_E_ARG, "the ranks of the decomposition disagree on chunk_steps / pipe_steps / nt (this rank: " +
+                                      std::to_string(p->Tc) + " / " + std::to_string(p->Tp) + " / " + std::to_string(p->nt) + ")");
+    }
+    // regroup the boundary edges by peer rank; inside a peer they keep the order both sides share (sorted by source cell)
+    auto regroup = [&](int n, const int* peer, const std::vector<int>& xs, std::vector<PeerSeg>& segs, int** d_xp) -> int {
+        segs.clear();
+        std::vector<int> order(n), xp(std::max(n, 1), 0);
+        for (int i = 0; i < n; ++i) {
+            if (peer[i] < 0 || peer[i] >= c->nranks || peer[i] == c->rank) return fail(SMASHX_E_ARG, "boundary edge with a bad peer rank");
+            order[i] = i;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return peer[a] < peer[b]; });
+        for (int i = 0; i < n; ++i) {
+            xp[i] = xs[order[i]];
+            if (segs.empty() || segs.back().rank != peer[order[i]]) segs.push_back(PeerSeg{peer[order[i]], i, 0});
+            segs.back().count++;
+        }
+        return p->upload_vec(d_xp, xp);
+    };
+    if ((rc = regroup(p->n_out, out_peer, p->sch.out_x, p->out_segs, &p->d_out_xp))) return rc;
+    if ((rc = regroup(p->n_in, in_peer, p->sch.in_x, p->in_segs, &p->d_in_xp))) return rc;
+    if (!p->x_out) {
+        if ((rc = p->dmalloc(&p->x_out, (size_t)std::max(p->n_out, 1) * p->Tp))) return rc;
+        if ((rc = p->dmalloc(&p->x_in, (size_t)std::max(p->n_in, 1) * p->Tp))) return rc;
+    }
+    // Connect now, symmetrically: RCCL sets a point-to-point connection up the first time a pair is used, inside ncclGroupEnd on the
+    // HOST, and both ends must be inside a group naming each other at that moment.  During a sweep the ranks reach their groups in
+    // dependency order (a tile only sends after it has received and routed), so first use there makes rank A wait for B's NEXT
+    // group while B waits for A's current one (observed: 3 sub-catchment parts hang in their first sub-chunk).  Here every rank
+    // exchanges one float with each neighbour in both directions within ONE group -- the all-to-all shape RCCL's schedule is built
+    // for -- so no connection is ever set up inside a sweep.
+    {
+        RcclApi& R = rccl();
+        std::vector<int> peers;
+        for (const PeerSeg& sg : p->out_segs) peers.push_back(sg.rank);
+        for (const PeerSeg& sg : p->in_segs) if (std::find(peers.begin(), peers.end(), sg.rank) == peers.end()) peers.push_back(sg.rank);
+        std::sort(peers.begin(), peers.end());
+        if (!peers.empty()) {
+            float* hello = nullptr;
+            if ((rc = p->dmalloc(&hello, 2 * peers.size()))) return rc;
+            HIPCHK(hipMemsetAsync(hello, 0, 2 * peers.size() * sizeof(float), c->stream));
+            NCCLCHK(R.GroupStart());
+            for (size_t i = 0; i < peers.size(); ++i) {
+                ncclResult_t r1 = R.Send(hello + 2 * i, 1, ncclFloat, peers[i], c->comm, c->stream);
+                ncclResult_t r2 = R.Recv(hello + 2 * i + 1, 1, ncclFloat, peers[i], c->comm, c->stream);
+                if (r1 != ncclSuccess || r2 != ncclSuccess) { (void)R.GroupEnd(); return fail(SMASHX_E_HIP, "ncclSend/ncclRecv (connection set-up) failed"); }
+            }
+            NCCLCHK(R.GroupEnd());
+            HIPCHK(hipStreamSynchronize(c->stream));
+            p->dfree(hello);
+        }
+    }
+    p->xcomm = c;
     return 0;
 }
 
@@ -1412,6 +1863,7 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
     }
     // sweep
     p->launches.clear(); p->pool_used = 0;
+    if ((rc = close_forcing(p))) return rc;
     HIPCHK(hipEventRecord(p->ev0, sV));
     HIPCHK(hipStreamWaitEvent(sR, p->ev0, 0));
     p->chain_used = false;

@@ -87,6 +87,7 @@ __device__ __forceinline__ void sx_pin(float4& v) {
 }
 
 __device__ __forceinline__ void sx_pin1(float& v) { asm volatile("" : "+v"(v) : : "memory"); }
+__device__ __forceinline__ void sx_pinu(unsigned& v) { asm volatile("" : "+v"(v) : : "memory"); }
 
 // ---- rounds chained inside one launch (DESIGN.md "Chained rounds") --------------------------------------
 // A group of round r only needs, for time block b, what the groups of earlier rounds published for block b,
@@ -103,14 +104,14 @@ typedef __attribute__((address_space(1))) int sx_gint;
 #ifndef SX_PK
 #define SX_PK 16              // macro-steps between two publications (x SX_MU x SX_BT = 256 time steps); 2..16 measured, fences dominate
 #endif
-#define SX_SPIN_LIMIT (1 << 22)   // polls (~1 us each at least) before a stalled chain is reported instead of hanging
-__device__ __forceinline__ void sx_wait_prog(const int* prog, int need, int& seen, int* stalled) {
+#define SX_SPIN_LIMIT (1 << 22)   // polls (~1 us each at least) before a stalled chain is reported instead of hanging (SxDeviceArrays::spin_limit)
+__device__ __forceinline__ void sx_wait_prog(const int* prog, int need, int& seen, int* stalled, int limit) {
     if (seen >= need) return;
     int spins = 0;
     while (seen < need) {
         seen = __hip_atomic_load((const sx_gint*)prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (seen < need) {
-            if (++spins > SX_SPIN_LIMIT) { __hip_atomic_store((sx_gint*)stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); seen = 0x7fffffff; break; }
+            if (++spins > limit) { __hip_atomic_store((sx_gint*)stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); seen = 0x7fffffff; break; }
             __builtin_amdgcn_s_sleep(32);
         }
     }
@@ -127,8 +128,14 @@ struct SxDeviceArrays {
     int k0, k1;                   // cell range [k0, k1) of a vertical launch (whole domain: 0, n)
     int nx;                       // exchange series count (>= 1)
     float dt, dx;
-    // forcing
+    // forcing: fp32 rows [nt][npad], or -- prcp16 != null -- the lossless compact form (smashx_set_forcing_layout):
+    //   prcp16 [nt][npad] u16: rain depth in raster units, prcp = real(k) * prcp_c exactly as the reference's reader forms it
+    //          (_read_input_data.py:191-196); 65535 = the gap marker prcp_gap
+    //   petd   [ndays][npad]: daily PET; pet(t) = petd(day(t)) * pet_ratio(hour(t)), the reader's product (:255-283); a negative
+    //          daily value is a gap day and stands for every hour
     const float* prcp; const float* pet;
+    const unsigned short* prcp16; const float* petd; const float* pet_ratio;   // pet_ratio: 24 floats in HBM, read by the scalar unit
+    float prcp_c, prcp_gap; int hour0;
     // parameters (denormalised) and per-cell invariants
     float *ci, *cp, *cft, *cst, *exc, *lr;
     // vic-a reuses the slots above (b -> ci, cusl1 -> cp, cusl2 -> cft, clsl -> cst, ks -> exc; husl1 -> hi, husl2 -> hp,
@@ -157,6 +164,8 @@ struct SxDeviceArrays {
     const int *x_prod, *x_cons;   // per exchange series: publishing group / group holding the inlet (-1: other tile)
     int* prog;                    // [ngroups + 1] blocks published by each group in the running launch; last = stall flag
     int ngroups;
+    int spin_limit;               // polls before a waiting group gives up and raises the stall flag
+    int mute_group;               // tests only (SMASHX_DEBUG_MUTE_GROUP): this group never publishes -> its consumers stall; -1 = none
     long long* gtime;             // diagnostics (SMASHX_TRACE_GROUPS=1): [2 passes][ngroups][start, end] wall_clock64 ticks, else null
 };
 
@@ -203,6 +212,48 @@ __device__ __forceinline__ void sx_row_store(float* row, unsigned byte_off, floa
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, byte_off, 0, AUX);
 }
 
+template <int AUX = 0>
+__device__ __forceinline__ unsigned sx_row_load_u16(const unsigned short* row, unsigned byte_off) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0x7fffffff, 0x00020000);
+    return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, AUX);
+}
+
+// Forcing cursor of one marching thread.  Loads return RAW words (fp32 bits, or the u16 rain count / the day's PET) and are
+// decoded only where the step uses them, so that the request stays one step ahead of its use in both layouts.  `compact`,
+// the hour of day and the day index are wave-uniform: the layout test, the day-change test and the ratio fetch are scalar work.
+struct SxForcing {
+    const SxDeviceArrays& A;
+    const unsigned kb;          // byte offset of the cell in an fp32 row
+    const size_t npad;
+    const bool compact;
+    __device__ __forceinline__ SxForcing(const SxDeviceArrays& A_, unsigned kb_) : A(A_), kb(kb_), npad((size_t)A_.npad), compact(A_.prcp16 != nullptr) {}
+    template <int AUX> __device__ __forceinline__ unsigned load_p(int t) const {
+        return compact ? sx_row_load_u16<AUX>(A.prcp16 + (size_t)t * npad, kb >> 1) : __float_as_uint(sx_row_load<AUX>(A.prcp + (size_t)t * npad, kb));
+    }
+    // PET word of step t; `cur` = the word of the neighbouring step already held (compact: reused unless the day changes)
+    template <int AUX> __device__ __forceinline__ float load_e(int t, float cur, bool first, bool backwards) const {
+        if (!compact) return sx_row_load<AUX>(A.pet + (size_t)t * npad, kb);
+        const int q = t + A.hour0, h = q % 24;
+        if (first || (backwards ? h == 23 : h == 0)) return sx_row_load<AUX>(A.petd + (size_t)(q / 24) * npad, kb);
+        return cur;
+    }
+    __device__ __forceinline__ float prcp(unsigned raw) const {
+        if (!compact) return __uint_as_float(raw);
+        const float v = (float)raw * A.prcp_c;
+        return raw == 65535u ? A.prcp_gap : v;
+    }
+    __device__ __forceinline__ float pet(float raw, int t) const {
+        if (!compact) return raw;
+        const float r = A.pet_ratio[(t + A.hour0) % 24];
+        return raw < 0.f ? raw : raw * r;
+    }
+    // both values of step t at once (kernels off the headline path: no prefetch)
+    __device__ __forceinline__ void at(int t, float& p, float& e) const {
+        p = prcp(load_p<0>(t));
+        e = pet(load_e<0>(t, 0.f, true, false), t);
+    }
+};
+
 // ------------------------------------------------------------------------------------------------
 // vertical forward: one thread per cell marches the time chunk [t0, t0+T)
 // ------------------------------------------------------------------------------------------------
@@ -229,21 +280,19 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
 
     // rows are wave-uniform (sx_row_load / sx_row_store): the vector unit does no address arithmetic in the time loop
     const unsigned kb = (unsigned)k * 4u;
-    const float* prcp_r = A.prcp + (size_t)t0 * npad;
-    const float* pet_r = A.pet + (size_t)t0 * npad;
-    float prcp_n = 0.f, pet_n = 0.f;
-    if (T > 0) { prcp_n = sx_row_load<SX_NT>(prcp_r, kb); pet_n = sx_row_load<SX_NT>(pet_r, kb); }
+    const SxForcing F(A, kb);
+    unsigned prcp_n = 0u; float pet_n = 0.f;
+    if (T > 0) { prcp_n = F.load_p<SX_NT>(t0); pet_n = F.load_e<SX_NT>(t0, 0.f, true, false); }
     for (int tq = 0; tq * 4 < T; ++tq) {
         float q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int tt = tq * 4 + i;
             if (tt < T) {
-                float prcp = prcp_n, pet = pet_n;
-                sx_pin1(prcp); sx_pin1(pet);     // the wait for this step's forcing goes here, before the next loads
-                if (tt + 1 < T) {
-                    prcp_n = sx_row_load<SX_NT>(prcp_r + (size_t)(tt + 1) * npad, kb); pet_n = sx_row_load<SX_NT>(pet_r + (size_t)(tt + 1) * npad, kb);
-                }
+                unsigned prcp_w = prcp_n; float pet_w = pet_n;
+                sx_pinu(prcp_w); sx_pin1(pet_w);     // the wait for this step's forcing goes here, before the next loads
+                if (tt + 1 < T) { prcp_n = F.load_p<SX_NT>(t0 + tt + 1); pet_n = F.load_e<SX_NT>(t0 + tt + 1, pet_w, false, false); }
+                const float prcp = F.prcp(prcp_w), pet = F.pet(pet_w, t0 + tt);
                 if (TAPE) {
                     const size_t o = (size_t)tt * npad;
                     if (ST == 2 || ST == 3) {     // the interception level: a full tape when it fits, else one checkpoint per SX_HIK steps
@@ -283,8 +332,7 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A,
     const SxVicParams P = sx_vic_load(A, k);
     const float cusl2_m4 = sx_pow_m4(P.cusl2);
     float husl1 = A.hi[k], husl2 = A.hp[k], hlsl = A.hft[k];
-    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
-    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    const SxForcing F(A, (unsigned)k * 4u);
     float4* qt4 = reinterpret_cast<float4*>(A.qtT) + k;
     for (int tq = 0; tq * 4 < T; ++tq) {
         float q[4] = {0.f, 0.f, 0.f, 0.f};
@@ -296,7 +344,9 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A,
                     const size_t o = (size_t)tt * npad + k;
                     A.tape_hi[o] = husl1; A.tape_hp[o] = husl2; A.tape_hft[o] = hlsl;
                 }
-                const float v = sx_vic_step(P, cusl2_m4, prcp_p[(size_t)tt * npad], pet_p[(size_t)tt * npad], husl1, husl2, hlsl);
+                float prcp, pet;
+                F.at(t0 + tt, prcp, pet);
+                const float v = sx_vic_step(P, cusl2_m4, prcp, pet, husl1, husl2, hlsl);
                 if (i == 0) q[0] = v; else if (i == 1) q[1] = v; else if (i == 2) q[2] = v; else q[3] = v;
             }
         }
@@ -317,12 +367,13 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A,
     G.ds_b = A.px_b[0][k]; G.dsm_b = A.px_b[1][k]; G.ws_b = A.px_b[2][k];
     G.husl1_b = A.hi_b[k]; G.husl2_b = A.hp_b[k]; G.hlsl_b = A.hft_b[k];
     const float* qtb = A.qtT + (size_t)k * 4;
-    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
-    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    const SxForcing F(A, (unsigned)k * 4u);
     for (int tt = T - 1; tt >= 0; --tt) {
         const size_t o = (size_t)tt * npad;
         const float q_b = qtb[(size_t)(tt >> 2) * npad * 4 + (tt & 3)];
-        sx_vic_step_b(P, cusl2_m4, cusl2_m5, prcp_p[o], pet_p[o], A.tape_hi[o + k], A.tape_hp[o + k], A.tape_hft[o + k], q_b, G);
+        float prcp, pet;
+        F.at(t0 + tt, prcp, pet);
+        sx_vic_step_b(P, cusl2_m4, cusl2_m5, prcp, pet, A.tape_hi[o + k], A.tape_hp[o + k], A.tape_hft[o + k], q_b, G);
     }
     A.ci_b[k] = G.b_b; A.cp_b[k] = G.cusl1_b; A.cft_b[k] = G.cusl2_b; A.cst_b[k] = G.clsl_b; A.exc_b[k] = G.ks_b;
     A.px_b[0][k] = G.ds_b; A.px_b[1][k] = G.dsm_b; A.px_b[2][k] = G.ws_b;
@@ -341,12 +392,13 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic_d(SxDeviceArrays 
     float cusl2_m4, cusl2_m5;
     sx_pow_m4_m5(P.cusl2, &cusl2_m4, &cusl2_m5);
     SxVD husl1 = sx_vd(A.hi[k], A.hi_b[k]), husl2 = sx_vd(A.hp[k], A.hp_b[k]), hlsl = sx_vd(A.hft[k], A.hft_b[k]);
-    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
-    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    const SxForcing F(A, (unsigned)k * 4u);
     float* qt = A.qtT + (size_t)k * 4;
     float* qd = A.qtdT + (size_t)k * 4;
     for (int tt = 0; tt < T; ++tt) {
-        const SxVD r = sx_vic_step_d(P, D, cusl2_m4, cusl2_m5, prcp_p[(size_t)tt * npad], pet_p[(size_t)tt * npad], husl1, husl2, hlsl);
+        float prcp, pet;
+        F.at(t0 + tt, prcp, pet);
+        const SxVD r = sx_vic_step_d(P, D, cusl2_m4, cusl2_m5, prcp, pet, husl1, husl2, hlsl);
         const size_t o = (size_t)(tt >> 2) * npad * 4 + (tt & 3);
         qt[o] = r.v; qd[o] = r.d;
     }
@@ -388,8 +440,7 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
     hp = sx_mk(A.hp[k], A.hp_b[k]);
     hft = sx_mk(A.hft[k], A.hft_b[k]);
     if (ST == 3) hst = sx_mk(A.hst[k], A.hst_b[k]);
-    const float* prcp_p = A.prcp + (size_t)t0 * npad + k;
-    const float* pet_p = A.pet + (size_t)t0 * npad + k;
+    const SxForcing F(A, (unsigned)k * 4u);
     float4* qt4 = reinterpret_cast<float4*>(A.qtT) + k;
     float4* qd4 = reinterpret_cast<float4*>(A.qtdT) + k;
     for (int tq = 0; tq * 4 < T; ++tq) {
@@ -398,7 +449,9 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
         for (int i = 0; i < 4; ++i) {
             const int tt = tq * 4 + i;
             if (tt < T) {
-                const SxDual r = sx_vertical_step_d<ST>(P, Q, D, prcp_p[(size_t)tt * npad], pet_p[(size_t)tt * npad], hi, hp, hft, hst);
+                float prcp, pet;
+                F.at(t0 + tt, prcp, pet);
+                const SxDual r = sx_vertical_step_d<ST>(P, Q, D, prcp, pet, hi, hp, hft, hst);
                 q[i] = r.v; qd[i] = r.d;
             }
         }
@@ -490,7 +543,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
     auto fetch = [&](int tb) -> float4 { return cell >= 0 ? sx_gload4s(src + (size_t)tb * sstride) : sx_gload4(src + (size_t)tb * sstride); };
 
     float4 nxt[SX_MU], outq[SX_MU], outh[SX_MU], nhr[SX_MU];
-    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - stage, nb), seen, A.prog + A.ngroups);
+    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - stage, nb), seen, A.prog + A.ngroups, A.spin_limit);
 #pragma unroll
     for (int u = 0; u < SX_MU; ++u) {
         const int tb = u - stage;
@@ -526,7 +579,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
         }
         if (mw == nmacro) break;
         // inputs of the next macro-step are requested now
-        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - stage, nb), seen, A.prog + A.ngroups);
+        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - stage, nb), seen, A.prog + A.ngroups, A.spin_limit);
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
             const int tb = SX_MU * (mw + 1) + u - stage;
@@ -611,7 +664,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
             sx_lds_barrier();
             // every wave has passed this macro-step's vmcnt(0): what the roots (stage dmax) stored one macro-step
             // ago -- blocks below SX_MU (mw-1) - dmax -- has reached L2 and can be released
-            if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0) sx_publish(A.prog + g, done); }
+            if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0 && g != A.mute_group) sx_publish(A.prog + g, done); }
         }
     }
     if (valid && cell >= 0) { if (TAN) A.hlr_b[cell] = hlr; else A.hlr[cell] = hlr; }
@@ -619,7 +672,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
     if (CHAIN) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (j == 0) sx_publish(A.prog + g, nb);
+        if (j == 0 && g != A.mute_group) sx_publish(A.prog + g, nb);
     }
 }
 
@@ -686,7 +739,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
     if (CHAIN && root_in) { const int cg = A.x_cons[xout]; if (cg >= g0 && cg < gend) wprog = A.prog + cg; }
     auto fetch_in = [&](int tb) -> float4 { return sx_gload4(x4 + (size_t)tb * A.nx + xout); };
     float4 nhr[SX_MU], nin[SX_MU], nsd[SX_MU], outq[SX_MU];
-    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - rstage, nb), seen, A.prog + A.ngroups);
+    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - rstage, nb), seen, A.prog + A.ngroups, A.spin_limit);
 #pragma unroll
     for (int u = 0; u < SX_MU; ++u) {
         const int tbr = u - rstage;
@@ -719,7 +772,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
             }
         }
         if (mw == nmacro) break;
-        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - rstage, nb), seen, A.prog + A.ngroups);
+        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - rstage, nb), seen, A.prog + A.ngroups, A.spin_limit);
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
             const int tbr = SX_MU * (mw + 1) + u - rstage;
@@ -781,7 +834,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
             }
             sx_lds_barrier();
             // inlet slots sit at reverse stage <= dmax: reverse blocks below SX_MU (mw-1) - dmax are complete
-            if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0) sx_publish(A.prog + g, done); }
+            if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0 && g != A.mute_group) sx_publish(A.prog + g, done); }
         }
     }
     if (valid && cell >= 0) { A.hlr_b[cell] = hr_b; A.lr_b[cell] = lr_b; }
@@ -789,7 +842,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
     if (CHAIN) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (j == 0) sx_publish(A.prog + g, nb);
+        if (j == 0 && g != A.mute_group) sx_publish(A.prog + g, nb);
     }
 }
 
@@ -835,11 +888,12 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDevi
     // addresses = wave-uniform row (buffer descriptor in scalar registers, advanced by the scalar unit) + the cell's 32-bit
     // byte offset: no vector address arithmetic in the time loop
     const unsigned kb = (unsigned)k * 4u;
-    float n_prcp = 0.f, n_pet = 0.f, n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
+    const SxForcing F(A, kb);
+    unsigned n_prcp = 0u; float n_pet = 0.f, n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
     const bool hi_taped = (ST == 2 || ST == 3) && A.tape_hi != nullptr;       // wave-uniform
-    auto fetch = [&](int tt) {
-        const size_t o = (size_t)tt * npad, of = (size_t)(t0 + tt) * npad;
-        n_prcp = sx_row_load<SX_VADJ_NT>(A.prcp + of, kb); n_pet = sx_row_load<SX_VADJ_NT>(A.pet + of, kb);
+    auto fetch = [&](int tt, bool first) {
+        const size_t o = (size_t)tt * npad;
+        n_prcp = F.load_p<SX_VADJ_NT>(t0 + tt); n_pet = F.load_e<SX_VADJ_NT>(t0 + tt, n_pet, first, true);
         if (hi_taped) n_hi = sx_row_load<SX_VADJ_NT>(A.tape_hi + o, kb);
         n_hp = sx_row_load<SX_VADJ_NT>(A.tape_hp + o, kb); n_hft = sx_row_load<SX_VADJ_NT>(A.tape_hft + o, kb);
         if (ST == 3) n_hst = sx_row_load<SX_VADJ_NT>(A.tape_hst + o, kb);
@@ -850,16 +904,13 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDevi
     // sx_interception on the same operands, hence the same bits -- and the pre-step levels wait in this thread's LDS
     // column for the reverse steps of the block.
     __shared__ float s_hi[(ST == 2 || ST == 3) ? SX_HIK : 1][SX_VBLOCK];
-    if (T > 0) fetch(T - 1);
+    if (T > 0) fetch(T - 1, true);
     for (int tb = (T - 1) / SX_HIK; tb >= 0; --tb) {
         const int tt0 = tb * SX_HIK, len = min(SX_HIK, T - tt0);
         if ((ST == 2 || ST == 3) && !hi_taped) {
             float fp[SX_HIK], fe[SX_HIK];
 #pragma unroll
-            for (int j = 0; j < SX_HIK; ++j) {
-                const size_t of = (size_t)(t0 + tt0 + (j < len ? j : 0)) * npad;
-                fp[j] = sx_row_load<SX_VADJ_NT>(A.prcp + of, kb); fe[j] = sx_row_load<SX_VADJ_NT>(A.pet + of, kb);
-            }
+            for (int j = 0; j < SX_HIK; ++j) F.at(t0 + tt0 + (j < len ? j : 0), fp[j], fe[j]);
             float h = sx_row_load(A.ckpt_hi + (size_t)tb * npad, kb);
 #pragma unroll
             for (int j = 0; j < SX_HIK; ++j) {
@@ -868,11 +919,12 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDevi
             }
         }
         for (int tt = tt0 + len - 1; tt >= tt0; --tt) {
-            float prcp = n_prcp, pet = n_pet, hit = n_hi, hp = n_hp, hft = n_hft, hst = n_hst, q = n_q;
-            sx_pin1(prcp); sx_pin1(pet); sx_pin1(hp); sx_pin1(hft); sx_pin1(q);
+            unsigned prcp_w = n_prcp; float pet_w = n_pet, hit = n_hi, hp = n_hp, hft = n_hft, hst = n_hst, q = n_q;
+            sx_pinu(prcp_w); sx_pin1(pet_w); sx_pin1(hp); sx_pin1(hft); sx_pin1(q);
             if (ST == 2 || ST == 3) sx_pin1(hit);
             if (ST == 3) sx_pin1(hst);
-            if (tt > 0) fetch(tt - 1);
+            if (tt > 0) fetch(tt - 1, false);
+            const float prcp = F.prcp(prcp_w), pet = F.pet(pet_w, t0 + tt);
             const float hi = (ST == 2 || ST == 3) ? (hi_taped ? hit : s_hi[tt - tt0][threadIdx.x]) : 0.f;
             sx_vertical_step_b<ST>(P, Q, prcp, pet, hi, hp, hft, hst, q, G);
         }

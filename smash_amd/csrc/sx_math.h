@@ -16,6 +16,13 @@
 
 #include <stdint.h>
 
+// SX_EXACT_LIBM=1 (the libsmashx_exact.so build): every power, exponential and logarithm goes through glibc 2.35's own float
+// algorithms restated in sx_libm.h, every division is the IEEE division.  Slower; exists to show that the default build's
+// distance from the reference is libm rounding and nothing else (tests/test_gpu_exact.py, DESIGN.md "Numerics").
+#ifndef SX_EXACT_LIBM
+#define SX_EXACT_LIBM 0
+#endif
+
 #if defined(__HIPCC__) || defined(__HIP__)
 #include <hip/hip_runtime.h>
 #define SX_HD __host__ __device__ __forceinline__
@@ -71,9 +78,13 @@ SX_HD float sx_seed_sqrt(float x) {
 struct SxDiv { float d, r; };
 SX_HD SxDiv sx_mkdiv(float d) { SxDiv D; D.d = d; D.r = 1.0f / d; return D; }
 SX_HD float sx_div(float a, const SxDiv& D) {
+#if SX_EXACT_LIBM
+    return a / D.d;
+#else
     const float q = a * D.r;
     const float e = fmaf(-D.d, q, a);
     return fmaf(e, D.r, q);
+#endif
 }
 
 // Division by a denominator that changes every step (1 + hp*tanh, the two quotients inside tanh).  hipcc expands
@@ -83,7 +94,7 @@ SX_HD float sx_div(float a, const SxDiv& D) {
 // boundary, and then q is the correctly rounded quotient.  6 instructions; mismatches against a/b are counted on
 // the device by smashx_selftest_math (tests/test_gpu_parity.py: < 1e-6 of calls, 1 ulp).
 SX_HD float sx_fdiv(float a, float b) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !SX_EXACT_LIBM
     float r = __builtin_amdgcn_rcpf(b);
     r = fmaf(fmaf(-b, r, 1.0f), r, r);
     const float q = a * r;
@@ -94,7 +105,7 @@ SX_HD float sx_fdiv(float a, float b) {
 }
 SX_HD SxDiv sx_mkdiv_fast(float d) {
     SxDiv D; D.d = d;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !SX_EXACT_LIBM
     const float r = __builtin_amdgcn_rcpf(d);
     D.r = fmaf(fmaf(-d, r, 1.0f), r, r);
 #else
@@ -103,6 +114,21 @@ SX_HD SxDiv sx_mkdiv_fast(float d) {
     return D;
 }
 
+SX_HD float sx_nanf() { return sx_u2f(0x7fc00000u); }
+SX_HD float sx_inff() { return sx_u2f(0x7f800000u); }
+#if SX_EXACT_LIBM
+#include "sx_libm.h"
+// the model's powers, exponential and logarithm exactly as the reference's compiler emits them: calls of powf / expf / logf
+SX_HD float sx_pow_m4(float x) { return sx_g_powf(x, -4.0f); }
+SX_HD void sx_pow_m4_m5(float x, float* m4, float* m5) { *m4 = sx_g_powf(x, -4.0f); *m5 = sx_g_powf(x, -5.0f); }
+SX_HD float sx_pow_m025(float y) { return sx_g_powf(y, -0.25f); }
+SX_HD void sx_pow_m025_m125(float y, float* m025, float* m125) { *m025 = sx_g_powf(y, -0.25f); *m125 = sx_g_powf(y, -1.25f); }
+SX_HD float sx_pow_3p5(float h) { return sx_g_powf(h, 3.5f); }
+SX_HD void sx_pow_3p5_2p5(float h, float* p35, float* p25) { *p35 = sx_g_powf(h, 3.5f); *p25 = sx_g_powf(h, 2.5f); }
+SX_HD float sx_expf(float x) { return sx_g_expf(x); }
+SX_HD float sx_logf(float x) { return sx_g_logf(x); }
+SX_HD float sx_powf(float x, float y) { return sx_g_powf(x, y); }
+#else
 // 1/x in fp64 to ~2^-45 from an fp32 seed: one Newton step  u <- u + u(1 - x u)
 SX_HD double sx_rcp_d(float x) {
     const double d = (double)x;
@@ -197,8 +223,6 @@ SX_HD double sx_exp2_d(double t) {
     p = fma(p, u, 1.0); p = fma(p, u, 1.0);
     return ldexp(p, (int)n);
 }
-SX_HD float sx_nanf() { return sx_u2f(0x7fc00000u); }
-SX_HD float sx_inff() { return sx_u2f(0x7f800000u); }
 SX_HD float sx_logf(float x) {
     const SxLog2 L = sx_log2_d(x);
     if (L.special) return L.special == 1 ? -sx_inff() : L.special == 3 ? sx_inff() : sx_nanf();
@@ -213,6 +237,8 @@ SX_HD float sx_pow_from(const SxLog2& L, float x, float y) {
     return (float)sx_exp2_d((double)y * L.l2);
 }
 SX_HD float sx_powf(float x, float y) { return sx_pow_from(sx_log2_d(x), x, y); }
+
+#endif   // SX_EXACT_LIBM
 
 // ---- fdlibm float expm1 / tanh (Sun Microsystems 1993, public algorithm; the float port is what
 // ---- glibc 2.35 ships as expm1f/tanhf).  Restated for arguments the model can produce:

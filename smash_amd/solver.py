@@ -23,6 +23,11 @@ from .types import JOBS_FUN, JREG_FUN, STRUCTURES
 from .synth import PARAM_NAMES, STATE_NAMES
 
 
+# hourly share of the daily PET in the reference's reader (smash/core/_constant.py:47-75)
+RATIO_PET_HOURLY = np.array([0, 0, 0, 0, 0, 0, 0, 0.035, 0.062, 0.079, 0.097, 0.11, 0.117, 0.117, 0.11, 0.097, 0.079, 0.062, 0.035,
+                             0, 0, 0, 0, 0], dtype=np.float32)
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
@@ -43,6 +48,33 @@ def _f32(a):
 
 def _i32(a):
     return np.asfortranarray(a, dtype=np.int32)
+
+
+class Comm:
+    """One RCCL communicator per process (= per GPU) for the native exchange of boundary series (include/smashx.h
+    "native exchange").  Rank 0 draws the id (Comm.unique_id()); the launcher hands it to every rank."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_ubyte * 128)()
+        _lib.check(_lib.lib().smashx_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid: bytes, rank: int, nranks: int, device: int = -1):
+        buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+        self.handle = C.c_void_p()
+        self.rank, self.nranks = rank, nranks
+        _lib.check(_lib.lib().smashx_comm_create(buf, int(rank), int(nranks), int(device), C.byref(self.handle)))
+
+    def allreduce_sum(self, values):
+        v = np.ascontiguousarray(values, np.float64).copy()
+        _lib.check(_lib.lib().smashx_comm_allreduce_sum(self.handle, _ptr(v), int(v.size)))
+        return v
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().smashx_comm_destroy(self.handle)
+            self.handle = None
 
 
 class Solver:
@@ -100,6 +132,24 @@ class Solver:
         _lib.check(_lib.lib().smashx_set_forcing_device_block(self._h, int(t0), int(t1), C.c_void_p(d_prcp_ptr),
                                                               C.c_void_p(d_pet_ptr)))
 
+    def set_forcing_layout(self, compact=True, prcp_factor=0.1, pet_ratio=None, pet_hour0=1):
+        """Lossless compact residency of the forcing (include/smashx.h smashx_set_forcing_layout): uint16 rain counts x
+        prcp_factor + daily PET x pet_ratio[(t + pet_hour0) % 24], verified bit for bit when the forcing is set.
+        pet_ratio defaults to the reference's RATIO_PET_HOURLY (smash/core/_constant.py:47-75); pet_hour0 = 1 is a run that
+        starts at midnight (the first step is start_time + dt)."""
+        lay = _lib.ForcingLayout()
+        lay.compact, lay.prcp_factor, lay.pet_hour0 = int(bool(compact)), float(np.float32(prcp_factor)), int(pet_hour0)
+        r = RATIO_PET_HOURLY if pet_ratio is None else np.asarray(pet_ratio, np.float32)
+        for h in range(24):
+            lay.pet_ratio[h] = float(r[h])
+        _lib.check(_lib.lib().smashx_set_forcing_layout(self._h, C.byref(lay)))
+
+    def forcing_info(self):
+        c, b = C.c_int(0), C.c_double(0.0)
+        _lib.check(_lib.lib().smashx_forcing_info(self._h, C.byref(c), C.byref(b)))
+        return {"layout": "compact: uint16 rain counts + daily PET x hourly ratio (lossless, verified bit for bit)" if c.value
+                else "fp32 rows", "resident_bytes_per_cellstep": round(b.value, 4)}
+
     def set_qobs(self, qobs):
         q = _f32(qobs)
         _lib.check(_lib.lib().smashx_set_qobs(self._h, _ptr(q)))
@@ -151,6 +201,13 @@ class Solver:
                 return 1
         self._halo_cb = _lib.HALO_FN(tramp)
         _lib.check(_lib.lib().smashx_set_halo(self._h, C.c_void_p(out_ptr), C.c_void_p(in_ptr), self._halo_cb, None))
+
+    def set_exchange(self, comm, out_peer, in_peer):
+        """Native exchange (smashx_set_exchange): comm = a Comm (or None to unset); out_peer / in_peer = the rank owning the
+        other end of every out / in boundary edge, in the order of halo_edges()."""
+        op, ip = np.ascontiguousarray(out_peer, np.int32), np.ascontiguousarray(in_peer, np.int32)
+        self._comm = comm
+        _lib.check(_lib.lib().smashx_set_exchange(self._h, comm.handle if comm is not None else None, _ptr(op), _ptr(ip)))
 
     def set_options(self, opt):
         o = _lib.Options()
@@ -211,7 +268,10 @@ class Solver:
     def timing(self):
         t = _lib.Timing()
         _lib.check(_lib.lib().smashx_get_timing(self._h, C.byref(t)))
-        return {k: getattr(t, k) for k, _ in _lib.Timing._fields_}
+        d = {k: getattr(t, k) for k, _ in _lib.Timing._fields_ if k != "cellsteps"}
+        for i, k in enumerate(("vert_fwd", "route_fwd", "route_adj", "vert_adj")):
+            d[k + "_cellsteps"] = float(t.cellsteps[i])
+        return d
 
     def download(self, adjoint, parameters, states, output, parameters_b=None, states_b=None, only_b=None):
         """parameters / states None: nothing but cost, discharge and gradients comes back; only_b = the gradient fields wanted."""

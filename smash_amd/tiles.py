@@ -93,9 +93,30 @@ class PeerLists:
         else:
             o_owner = owner_of(out_dst, nrow, ncol, pr, pc) if self.n_out else np.zeros(0, np.int64)
             i_owner = owner_of(in_src, nrow, ncol, pr, pc) if self.n_in else np.zeros(0, np.int64)
+        self.out_owner, self.in_owner = o_owner.astype(np.int32), i_owner.astype(np.int32)
         self.out_peers = {int(p): np.flatnonzero(o_owner == p) for p in np.unique(o_owner)}
         self.in_peers = {int(p): np.flatnonzero(i_owner == p) for p in np.unique(i_owner)}
         self.out_src, self.out_dst, self.in_src, self.in_dst = out_src, out_dst, in_src, in_dst
+
+
+class RcclExchange:
+    """Native exchange: the plan posts grouped ncclSend / ncclRecv on its routing stream itself (smashx_set_exchange); nothing
+    runs on the host per sub-chunk.  comm: a smash_amd.solver.Comm spanning the ranks of the decomposition."""
+
+    def __init__(self, solver, comm, nrow, ncol, pr, pc, owner=None):
+        self.peers = PeerLists(solver, nrow, ncol, pr, pc, owner)
+        solver.set_exchange(comm, self.peers.out_owner, self.peers.in_owner)
+
+
+def share_one_gpu_env(rank: int):
+    """Rehearsals on a one-GPU box: RCCL refuses two ranks on one device unless they claim different hosts; with a host id
+    per rank the duplicate-GPU check passes and the socket transport (loopback) carries the messages.  Call before the first
+    RCCL communicator is created.  Production runs (one GPU per rank) never call this."""
+    import os
+    os.environ["NCCL_HOSTID"] = f"smashx-rank-{rank}"
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    for k in ("NCCL_IB_DISABLE", "NCCL_P2P_DISABLE", "NCCL_SHM_DISABLE"):
+        os.environ.setdefault(k, "1")
 
 
 class TorchDistExchange:
@@ -115,10 +136,13 @@ class TorchDistExchange:
         solver.set_halo(self.out_buf.data_ptr(), self.in_buf.data_ptr(), self)
         # one handshake per neighbour now: RCCL creates its point-to-point channels on first use, which belongs to the set-up
         # and not to the first sweep
+        # (both directions with every neighbour in ONE batch: a connection first used inside a sweep would be set up while the two
+        # ranks sit in different groups of their dependency chain -- see smashx_set_exchange)
         mdev = "cpu" if self.host_staged else device
-        hello = {p: torch.zeros(1, dtype=torch.float32, device=mdev) for p in set(self.idx_out) | set(self.idx_in)}
-        ops = [dist.P2POp(dist.isend, torch.ones(1, dtype=torch.float32, device=mdev), p) for p in self.idx_out] + \
-              [dist.P2POp(dist.irecv, hello[p], p) for p in self.idx_in]
+        nbrs = sorted(set(self.idx_out) | set(self.idx_in))
+        hello = {p: torch.zeros(1, dtype=torch.float32, device=mdev) for p in nbrs}
+        ops = [dist.P2POp(dist.isend, torch.ones(1, dtype=torch.float32, device=mdev), p) for p in nbrs] + \
+              [dist.P2POp(dist.irecv, hello[p], p) for p in nbrs]
         if ops:
             if self.host_staged:
                 for r in [op.op(op.tensor, op.peer) for op in ops]:

@@ -2,6 +2,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "../../smash_amd/csrc/sx_math.h"
+#include "../../smash_amd/csrc/sx_libm.h"
 
 extern "C" {
 
@@ -87,6 +88,67 @@ long sxt_pow_specials(void) {
     }
     if (sx_logf(0.f) != logf(0.f)) bad++;
     if (sx_logf(-1.f) == sx_logf(-1.f)) bad++;
+    return bad;
+}
+
+/* ---- exact-libm build (sx_libm.h): glibc's expf / logf / powf restated; counts of results whose BITS differ from the C library's ---- */
+long sxt_g_expf_mismatches(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride) {
+    long bad = 0;
+    for (uint64_t u = lo_bits; u < hi_bits; u += stride) {
+        const float x = sx_u2f((uint32_t)u), a = sx_g_expf(x), b = expf(x);
+        if (sx_f2u(a) != sx_f2u(b) && !(a != a && b != b)) bad++;
+    }
+    return bad;
+}
+long sxt_g_logf_mismatches(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride) {
+    long bad = 0;
+    for (uint64_t u = lo_bits; u < hi_bits; u += stride) {
+        const float x = sx_u2f((uint32_t)u), a = sx_g_logf(x), b = logf(x);
+        if (sx_f2u(a) != sx_f2u(b) && !(a != a && b != b)) bad++;
+    }
+    return bad;
+}
+/* powf: the six fixed exponents of the GR operators on every float of a base range, then n random (x, y) pairs of the vic-a kind
+ * and of any magnitude, then the special values */
+long sxt_g_powf_fixed_mismatches(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride) {
+    const float ys[6] = {-4.f, -5.f, -0.25f, -1.25f, 3.5f, 2.5f};
+    long bad = 0;
+    for (uint64_t u = lo_bits; u < hi_bits; u += stride) {
+        const float x = sx_u2f((uint32_t)u);
+        for (int j = 0; j < 6; ++j) if (sx_f2u(sx_g_powf(x, ys[j])) != sx_f2u(powf(x, ys[j]))) bad++;
+    }
+    return bad;
+}
+long sxt_g_powf_random_mismatches(long n, unsigned seed) {
+    srand(seed);
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        float x, y;
+        switch (i & 3) {
+            case 0: x = rnd(1e-7f, 1.f); y = rnd(0.05f, 3.f); break;
+            case 1: x = rnd(1e-3f, 50.f); y = rnd(-5.f, 5.f); break;
+            case 2: x = sx_u2f(0x3f800000u + (uint32_t)(rand() % 2000000) - 1000000u); y = rnd(-3.f, 3.f); break;
+            default: x = sx_u2f((((uint32_t)rand() << 16) ^ (uint32_t)rand()) & 0x7fffffffu); y = sx_u2f(((uint32_t)rand() << 16) ^ (uint32_t)rand()); break;
+        }
+        const float a = sx_g_powf(x, y), b = powf(x, y);
+        if (sx_f2u(a) != sx_f2u(b) && !(a != a && b != b)) bad++;
+    }
+    return bad;
+}
+long sxt_g_specials(void) {
+    const float inf = sx_inff(), nan = sx_nanf();
+    const float xs[] = {0.f, -0.f, 1.f, -1.f, 2.f, -2.f, 1e-45f, 1e-40f, -1e-40f, 3.4e38f, 0.5f, -0.5f, inf, -inf, nan};
+    const float ys[] = {0.f, -0.f, 1.f, -1.f, 0.5f, 2.f, 3.f, -3.f, -2.5f, 30.f, -30.f, 1e30f, -1e30f, inf, -inf, nan};
+    long bad = 0;
+    for (float x : xs) for (float y : ys) {
+        const float a = sx_g_powf(x, y), b = powf(x, y);
+        if (!(sx_f2u(a) == sx_f2u(b) || (a != a && b != b))) bad++;
+    }
+    for (float x : xs) {
+        const float a = sx_g_logf(x), b = logf(x), c = sx_g_expf(x), d = expf(x);
+        if (!(sx_f2u(a) == sx_f2u(b) || (a != a && b != b))) bad++;
+        if (!(sx_f2u(c) == sx_f2u(d) || (c != c && d != d))) bad++;
+    }
     return bad;
 }
 

@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""One rank of a multi-process tile run (launched by tests/test_gpu_rccl.py under torch.distributed.run): builds its tile of a
+golden case, exchanges the boundary series with the other ranks over REAL RCCL -- natively (grouped ncclSend / ncclRecv
+posted by libsmashx on its routing stream) or through the torch.distributed callback -- and checks that discharge and every
+gradient field are bit-identical to the single-domain run it computes on the same GPU.  On a box with fewer GPUs than ranks
+the ranks share a device (tiles.share_one_gpu_env: one host id per rank, socket transport)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", default="gr_b_64x64x720_nse")
+    ap.add_argument("--nt", type=int, default=96)
+    ap.add_argument("--chunk", type=int, default=96)
+    ap.add_argument("--pipe", type=int, default=16)
+    ap.add_argument("--exchange", default="rccl")
+    ap.add_argument("--cut", default="rect")
+    a = ap.parse_args()
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+
+    def say(msg):                                   # progress on stderr: a hang must be locatable from the log
+        print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+    import torch
+    import torch.distributed as dist
+    from smash_amd import tiles
+    ndev = max(torch.cuda.device_count(), 1)
+    if ndev < world:
+        tiles.share_one_gpu_env(rank)
+    local = int(os.environ.get("LOCAL_RANK", rank)) % ndev
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.zeros(1, device=dev)                      # torch's HIP runtime initialises first (tests/conftest.py)
+    dist.init_process_group("nccl", device_id=dev)
+    dist.barrier()
+    say("process group up")
+
+    import golden_util as gu
+    import smash_amd
+    from smash_amd.solver import Comm, Solver
+    from test_gpu_parity import _run_adjoint
+    from test_gpu_tiles import _short, _tile_inputs
+    g = _short(a.case, a.nt)
+    _, _, ref_out, ref_pb, ref_sb = _run_adjoint(g)
+    pr, pc = tiles.tile_grid(world)
+    nrow, ncol = g.mesh.nrow, g.mesh.ncol
+    owner = None
+    if a.cut == "rect":
+        rect = tiles.tile_rect(rank, nrow, ncol, pr, pc)
+        setup, mesh, loc = _tile_inputs(g, rect, g.mesh.ng)
+        sol = Solver(setup, mesh, chunk_steps=a.chunk, pipe_steps=a.pipe, group_size=128, device=local, tile=rect)
+    else:
+        owner = tiles.partition_subcatchments(g.mesh, world) if a.cut == "sub" else tiles.partition_trunk(g.mesh, world)
+        mine = np.asarray(owner) == rank
+        setup, mesh, loc = _tile_inputs(g, None, g.mesh.ng, mine)
+        sol = Solver(setup, mesh, chunk_steps=a.chunk, pipe_steps=a.pipe, group_size=128, device=local, owner_mask=mine)
+    rows, cols = sol.cell_order()
+    say(f"plan built: {sol.ncells} cells, edges {sol.halo_counts()}")
+    sol.set_forcing(g.prcp, g.pet)
+    if loc:
+        sol.set_qobs(np.asfortranarray(g.qobs[loc]))
+    sol.set_options(setup.optimize)
+    comm = None
+    if a.exchange == "rccl":
+        uid = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0, device=dev)
+        comm = Comm(uid[0], rank, world, local)
+        ex = tiles.RcclExchange(sol, comm, nrow, ncol, pr, pc, owner)
+    else:
+        ex = tiles.TorchDistExchange(sol, nrow, ncol, pr, pc, dev, owner)
+    say(f"exchange set ({a.exchange}): out peers {sorted(ex.peers.out_peers)} in peers {sorted(ex.peers.in_peers)}")
+    par = smash_amd.ParametersDT.from_dict(mesh, g.params)
+    sta = smash_amd.StatesDT.from_dict(mesh, g.states)
+    out = smash_amd.OutputDT(setup, mesh)
+    pb, sb = par.copy(), sta.copy()
+    bad = []
+    for rep in range(2):                            # twice: the second sweep reuses every buffer and the communicator
+        sol.upload(par, sta)
+        sol.sweep(True, 1.0)
+        say(f"sweep {rep} done")
+        sol.download(True, par, sta, out, pb, sb)
+        for i, gi in enumerate(loc):
+            if not np.array_equal(out.qsim[i], ref_out.qsim[gi]):
+                bad.append(("qsim", gi, rep))
+        for k in gu.STRUCT_PARAMS[g.structure]:
+            if not np.array_equal(getattr(pb, k)[rows, cols], getattr(ref_pb, k)[rows, cols]):
+                bad.append((k, rep))
+        for k in gu.STRUCT_STATES[g.structure]:
+            if not np.array_equal(getattr(sb, k)[rows, cols], getattr(ref_sb, k)[rows, cols]):
+                bad.append((k, rep))
+    if comm is not None:
+        cost = float(comm.allreduce_sum([out.cost])[0])
+    else:
+        ct = torch.tensor([out.cost], dtype=torch.float64, device=dev)
+        dist.all_reduce(ct)
+        cost = float(ct.item())
+    if abs(cost - ref_out.cost) > 1e-6 * abs(ref_out.cost) + 1e-7:
+        bad.append(("cost", cost, ref_out.cost))
+    n_out, n_in = sol.halo_counts()
+    print(f"rank {rank}/{world} [{a.exchange}, {a.cut}]: cells {sol.ncells}, edges out {n_out} in {n_in}, chunking {sol.chunking()}, "
+          f"{'BIT-IDENTICAL' if not bad else 'MISMATCH ' + str(bad[:6])}", flush=True)
+    dist.barrier()
+    sol.close()
+    if comm is not None:
+        comm.close()
+    dist.destroy_process_group()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -43,7 +43,10 @@ def _types(g, **solver_kw):
         if "params_bgd" in g.opts else (par.copy(), sta.copy())
     if solver_kw:
         from smash_amd.solver import Solver
+        layout = solver_kw.pop("layout", None)       # compact forcing residency (tests/test_gpu_compact.py)
         s = Solver(setup, mesh, **solver_kw)
+        if layout is not None:
+            s.set_forcing_layout(**layout)
         s.set_forcing(inp.prcp, inp.pet)
         inp._smashx_solver = s
     return setup, mesh, inp, par, sta, out

@@ -1,0 +1,52 @@
+"""GPU: the multi-process tile path over REAL RCCL (BASELINE.json configs[4] in the small).  Every rank is its
+own process (torch.distributed.run, backend nccl); the boundary discharge series travel as grouped ncclSend / ncclRecv posted by
+libsmashx on its routing stream (smashx_set_exchange) or, for comparison, through the torch.distributed callback.  Each rank
+checks bit-identity with the single-domain run (tests/mp_tile_worker.py).  With fewer GPUs than ranks the ranks share the card
+(every rank claims its own host id, so RCCL's duplicate-GPU check passes and the loopback socket transport carries the data):
+the RCCL code paths -- communicator set-up, grouping, stream ordering, buffer reuse across sweeps -- are the production ones,
+only the wire differs from xGMI."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _launch(world, extra, port_off):
+    port = 29600 + (os.getpid() % 1500) + port_off
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(HERE, "mp_tile_worker.py")] + extra
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    sys.stdout.write(r.stdout[-3000:])
+    sys.stderr.write(r.stderr[-3000:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.count("BIT-IDENTICAL") == world
+
+
+@pytest.mark.parametrize("world,chunk,pipe,exchange", [(2, 96, 16, "rccl"), (4, 32, 16, "rccl"), (2, 96, 32, "torch")])
+def test_ranks_over_rccl_equal_single_domain(world, chunk, pipe, exchange):
+    _launch(world, ["--chunk", str(chunk), "--pipe", str(pipe), "--exchange", exchange], world)
+
+
+def test_subcatchment_parts_over_rccl_equal_single_domain():
+    """All eight D8 codes: the river tree cut into 3 parts (owner masks), one process per part, native exchange."""
+    _launch(3, ["--case", "gr_c_32x32x240_d8_ragged", "--cut", "sub", "--chunk", "96", "--pipe", "16"], 7)
+
+
+def test_bench_self_launch_two_ranks():
+    """python bench.py --gpus 2 with no launcher starts both ranks itself and prints one JSON line with n_gpus = 2."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--tile-rows", "64", "--tile-cols", "64", "--nt", "240", "--pipe", "64", "--ng", "4", "--raw-forcing"],
+                       capture_output=True, text=True, timeout=900)
+    sys.stderr.write(r.stderr[-3000:])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["grid"] == [64, 128]
+    assert "ncclSend" in line["config"]["parallelism"] and line["value"] > 0

@@ -74,14 +74,14 @@ def _short(name, nt):
     return g
 
 
-@pytest.mark.parametrize("world,chunk,pipe", [(2, 0, 16), (4, 32, 16), (8, 0, 32)])
+@pytest.mark.parametrize("world,chunk,pipe", [(2, 96, 16), (4, 32, 16), (8, 96, 32)])
 def test_tiled_sweep_equals_single_domain(world, chunk, pipe):
     _check_partitioned(_short("gr_b_64x64x720_nse", 96), world, chunk, pipe, None)
 
 
-@pytest.mark.parametrize("name,world,chunk,pipe,cut", [("gr_c_32x32x240_d8_ragged", 3, 0, 16, "sub"), ("gr_b_20x20x96_d8", 4, 32, 16, "sub"),
-                                                       ("vic_a_24x24x240_d8_kge", 5, 0, 32, "sub"),
-                                                       ("gr_c_32x32x240_d8_ragged", 4, 0, 16, "trunk"), ("gr_a_cance_28x28x1440", 3, 0, 32, "trunk")])
+@pytest.mark.parametrize("name,world,chunk,pipe,cut", [("gr_c_32x32x240_d8_ragged", 3, 96, 16, "sub"), ("gr_b_20x20x96_d8", 4, 32, 16, "sub"),
+                                                       ("vic_a_24x24x240_d8_kge", 5, 96, 32, "sub"),
+                                                       ("gr_c_32x32x240_d8_ragged", 4, 96, 16, "trunk"), ("gr_a_cance_28x28x1440", 3, 96, 32, "trunk")])
 def test_subcatchment_partition_equals_single_domain(name, world, chunk, pipe, cut):
     """A flow field with all eight D8 codes cut into sub-catchment parts (tiles.partition_subcatchments): each part is
     a plan with an owner mask, the boundary series travel between the plans as between ranks."""
@@ -151,3 +151,18 @@ def _check_partitioned(g, world, chunk, pipe, owner):
             assert np.array_equal(getattr(sb, k)[rows, cols], getattr(ref_sb, k)[rows, cols]), (rank, k)
     assert abs(cost - ref_out.cost) <= 1e-6 * abs(ref_out.cost) + 1e-7
     assert sum(r[6] for r in res.values()) > 0       # the exchange really ran
+
+
+def test_tile_refuses_self_sized_chunks():
+    """A tile with boundary series must be told its chunk length: sizing it from this rank's free HBM (chunk_steps = 0) would
+    cut time differently on different ranks and end in mismatched messages (smashx.h "native exchange")."""
+    import smash_amd
+    from smash_amd import _lib, tiles
+    from smash_amd.solver import Solver
+    g = _short("gr_b_64x64x720_nse", 96)
+    rect = tiles.tile_rect(0, g.mesh.nrow, g.mesh.ncol, 1, 2)
+    setup, mesh, loc = _tile_inputs(g, rect, g.mesh.ng)
+    sol = Solver(setup, mesh, chunk_steps=0, pipe_steps=16, tile=rect)
+    with pytest.raises(smash_amd.SmashxError) as e:
+        sol.chunking()
+    assert e.value.code == _lib.E_ARG and "chunk_steps" in str(e.value)

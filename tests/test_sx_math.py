@@ -20,7 +20,8 @@ SO = os.path.join(HERE, "csrc", "sx_math_host.so")
 def lib():
     src = os.path.join(HERE, "csrc", "sx_math_host.cpp")
     hdr = os.path.join(HERE, "..", "smash_amd", "csrc", "sx_math.h")
-    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdr2 = os.path.join(HERE, "..", "smash_amd", "csrc", "sx_libm.h")
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(hdr2)):
         subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-fPIC", "-shared", "-o", SO, src, "-lm"])
     L = C.CDLL(SO)
     L.sxt_tanh_mismatches.restype = C.c_long
@@ -61,3 +62,21 @@ def test_runtime_pow_and_log(lib):
 
 def test_reciprocal_fma_division_is_ieee_division(lib):
     assert lib.sxt_div_mismatches(20_000_000) == 0
+
+
+def test_restated_glibc_expf_logf_powf_are_bit_identical_to_the_c_library(lib):
+    """smash_amd/csrc/sx_libm.h (the exact-libm build of the kernels) against glibc 2.35 itself: expf on every 7th float,
+    logf on every 5th positive float, powf with the six fixed exponents of the GR operators on every 11th base in [1e-7, 1e4],
+    powf on 5e7 random (x, y) pairs incl. arbitrary bit patterns, and the special values.  Zero differing bit patterns."""
+    for f in ("sxt_g_expf_mismatches", "sxt_g_logf_mismatches", "sxt_g_powf_fixed_mismatches"):
+        getattr(lib, f).restype = C.c_long
+        getattr(lib, f).argtypes = [C.c_uint32] * 3
+    lib.sxt_g_powf_random_mismatches.restype = C.c_long
+    lib.sxt_g_powf_random_mismatches.argtypes = [C.c_long, C.c_uint]
+    lib.sxt_g_specials.restype = C.c_long
+    assert lib.sxt_g_specials() == 0
+    assert lib.sxt_g_expf_mismatches(0, 0x7F800000, 7) == 0
+    assert lib.sxt_g_expf_mismatches(0x80000000, 0xFF800000, 7) == 0
+    assert lib.sxt_g_logf_mismatches(0, 0x7F800000, 5) == 0
+    assert lib.sxt_g_powf_fixed_mismatches(0x33D6BF95, 0x461C4000, 11) == 0
+    assert lib.sxt_g_powf_random_mismatches(50_000_000, 99) == 0
