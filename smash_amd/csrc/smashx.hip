@@ -490,8 +490,11 @@ template <int ST>
 void launch_vert_fwd(smashx_plan* p, const SxDeviceArrays& B, bool tape, int t0, int T) {
     const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
     p->mark_begin(0, p->stream, (double)(B.k1 - B.k0) * T);
-    if (tape) hipLaunchKernelGGL((sx_k_vert_fwd<ST, true>), grid, block, 0, p->stream, B, t0, T);
-    else      hipLaunchKernelGGL((sx_k_vert_fwd<ST, false>), grid, block, 0, p->stream, B, t0, T);
+    const bool cf = B.prcp16 != nullptr;
+    if (tape) { if (cf) hipLaunchKernelGGL((sx_k_vert_fwd<ST, true, true>), grid, block, 0, p->stream, B, t0, T);
+                else    hipLaunchKernelGGL((sx_k_vert_fwd<ST, true, false>), grid, block, 0, p->stream, B, t0, T); }
+    else      { if (cf) hipLaunchKernelGGL((sx_k_vert_fwd<ST, false, true>), grid, block, 0, p->stream, B, t0, T);
+                else    hipLaunchKernelGGL((sx_k_vert_fwd<ST, false, false>), grid, block, 0, p->stream, B, t0, T); }
     p->mark_end();
 }
 void vert_fwd(smashx_plan* p, int off, bool tape, int t0, int T, int k0 = 0, int k1 = -1) {
@@ -518,13 +521,17 @@ void vert_adj(smashx_plan* p, int off, int t0, int T, int k0 = 0, int k1 = -1) {
     if (B.k1 <= B.k0) return;
     const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
     p->mark_begin(3, p->stream, (double)(B.k1 - B.k0) * T);
+    const bool cf = B.prcp16 != nullptr;
+#define SX_VADJ(ST) do { if (cf) hipLaunchKernelGGL((sx_k_vert_adj<ST, true>), grid, block, 0, p->stream, B, t0, T); \
+                         else hipLaunchKernelGGL((sx_k_vert_adj<ST, false>), grid, block, 0, p->stream, B, t0, T); } while (0)
     switch (p->st) {
-        case 1: hipLaunchKernelGGL((sx_k_vert_adj<1>), grid, block, 0, p->stream, B, t0, T); break;
-        case 2: hipLaunchKernelGGL((sx_k_vert_adj<2>), grid, block, 0, p->stream, B, t0, T); break;
-        case 3: hipLaunchKernelGGL((sx_k_vert_adj<3>), grid, block, 0, p->stream, B, t0, T); break;
+        case 1: SX_VADJ(1); break;
+        case 2: SX_VADJ(2); break;
+        case 3: SX_VADJ(3); break;
         case 5: hipLaunchKernelGGL(sx_k_vert_adj_vic, grid, block, 0, p->stream, B, t0, T); break;
-        default: hipLaunchKernelGGL((sx_k_vert_adj<4>), grid, block, 0, p->stream, B, t0, T); break;
+        default: SX_VADJ(4); break;
     }
+#undef SX_VADJ
     p->mark_end();
 }
 // Routing launches of one pass.  Rounds below p->chain_from keep one launch per round (they are wide and

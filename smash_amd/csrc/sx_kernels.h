@@ -218,46 +218,70 @@ __device__ __forceinline__ unsigned sx_row_load_u16(const unsigned short* row, u
     return (unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, AUX);
 }
 
-// Forcing cursor of one marching thread.  Loads return RAW words (fp32 bits, or the u16 rain count / the day's PET) and are
-// decoded only where the step uses them, so that the request stays one step ahead of its use in both layouts.  `compact`,
-// the hour of day and the day index are wave-uniform: the layout test, the day-change test and the ratio fetch are scalar work.
+// Forcing cursor of one marching thread.  request() issues the loads of a step and returns at once; hold() -- called one step
+// later -- is where the wait lands (the words are pinned there, before the next request is issued), and prcp() / pet() decode the
+// held words.  Layouts: COMPACT = false: fp32 rows; true: u16 rain count + the day's PET + the hour's ratio.  The hour of day is
+// wave-uniform, so the day-change test is scalar work; the ratio is requested like a row, one step ahead (a load issued where it is
+// used drags the prefetched rows of the next step into this step's wait -- measured: vert_fwd 42 -> 55 ms, vert_adj 76 -> 97 ms).
+typedef const __attribute__((address_space(4))) float sx_cfloat;
+template <bool COMPACT>
 struct SxForcing {
     const SxDeviceArrays& A;
     const unsigned kb;          // byte offset of the cell in an fp32 row
     const size_t npad;
-    const bool compact;
-    __device__ __forceinline__ SxForcing(const SxDeviceArrays& A_, unsigned kb_) : A(A_), kb(kb_), npad((size_t)A_.npad), compact(A_.prcp16 != nullptr) {}
-    template <int AUX> __device__ __forceinline__ unsigned load_p(int t) const {
-        return compact ? sx_row_load_u16<AUX>(A.prcp16 + (size_t)t * npad, kb >> 1) : __float_as_uint(sx_row_load<AUX>(A.prcp + (size_t)t * npad, kb));
+    int h;                      // hour index of the step the next request() is for
+    unsigned p_n, p_w; float e_n, e_w, r_n, r_w;
+    __device__ __forceinline__ SxForcing(const SxDeviceArrays& A_, unsigned kb_, int t_first)
+        : A(A_), kb(kb_), npad((size_t)A_.npad), h(COMPACT ? (t_first + A_.hour0) % 24 : 0), p_n(0u), p_w(0u), e_n(0.f), e_w(0.f), r_n(0.f), r_w(0.f) {}
+    // t: absolute time step; first: nothing is held yet; BACK: the march runs backwards in time
+    template <int AUX, bool BACK> __device__ __forceinline__ void request(int t, bool first) {
+        if (!COMPACT) {
+            p_n = __float_as_uint(sx_row_load<AUX>(A.prcp + (size_t)t * npad, kb));
+            e_n = sx_row_load<AUX>(A.pet + (size_t)t * npad, kb);
+            return;
+        }
+        // the u16 count travels as the dword that holds it (lane pairs share one): nothing may touch the loaded word before hold(),
+        // and a 16-bit load result is zero-extended by an ALU instruction right behind the load -- a wait in the same step
+        // (measured: vert_adj 76 -> 89 ms).  The ratio comes the same way, one broadcast dword: a scalar load would be waited for
+        // on the spot as well.
+        p_n = __float_as_uint(sx_row_load<AUX>((const float*)(A.prcp16 + (size_t)t * npad), (kb >> 1) & ~3u));
+        if (first || h == (BACK ? 23 : 0)) e_n = sx_row_load<AUX>(A.petd + (size_t)((t + A.hour0) / 24) * npad, kb);   // a new day
+        r_n = sx_row_load(A.pet_ratio + h, 0u);
+        h = BACK ? (h == 0 ? 23 : h - 1) : (h == 23 ? 0 : h + 1);
     }
-    // PET word of step t; `cur` = the word of the neighbouring step already held (compact: reused unless the day changes)
-    template <int AUX> __device__ __forceinline__ float load_e(int t, float cur, bool first, bool backwards) const {
-        if (!compact) return sx_row_load<AUX>(A.pet + (size_t)t * npad, kb);
-        const int q = t + A.hour0, h = q % 24;
-        if (first || (backwards ? h == 23 : h == 0)) return sx_row_load<AUX>(A.petd + (size_t)(q / 24) * npad, kb);
-        return cur;
+    __device__ __forceinline__ void hold() {
+        p_w = p_n; e_w = e_n; r_w = r_n;
+        sx_pinu(p_w); sx_pin1(e_w);
+        if (COMPACT) sx_pin1(r_w);
     }
-    __device__ __forceinline__ float prcp(unsigned raw) const {
-        if (!compact) return __uint_as_float(raw);
-        const float v = (float)raw * A.prcp_c;
-        return raw == 65535u ? A.prcp_gap : v;
+    __device__ __forceinline__ float prcp() const {
+        if (!COMPACT) return __uint_as_float(p_w);
+        const unsigned k = (p_w >> ((kb & 4u) << 2)) & 0xffffu;     // this lane's half of the dword (kb = 4 x cell)
+        const float v = (float)k * A.prcp_c;
+        return k == 65535u ? A.prcp_gap : v;
     }
-    __device__ __forceinline__ float pet(float raw, int t) const {
-        if (!compact) return raw;
-        const float r = A.pet_ratio[(t + A.hour0) % 24];
-        return raw < 0.f ? raw : raw * r;
-    }
-    // both values of step t at once (kernels off the headline path: no prefetch)
-    __device__ __forceinline__ void at(int t, float& p, float& e) const {
-        p = prcp(load_p<0>(t));
-        e = pet(load_e<0>(t, 0.f, true, false), t);
+    __device__ __forceinline__ float pet() const {
+        if (!COMPACT) return e_w;
+        return e_w < 0.f ? e_w : e_w * r_w;
     }
 };
+
+// both values of step t at once, layout decided at run time (kernels off the headline path: no prefetch)
+__device__ __forceinline__ void sx_forcing_at(const SxDeviceArrays& A, int t, unsigned kb, float& p, float& e) {
+    const size_t npad = (size_t)A.npad;
+    if (A.prcp16 == nullptr) { p = sx_row_load(A.prcp + (size_t)t * npad, kb); e = sx_row_load(A.pet + (size_t)t * npad, kb); return; }
+    const unsigned raw = sx_row_load_u16(A.prcp16 + (size_t)t * npad, kb >> 1);
+    const float v = (float)raw * A.prcp_c;
+    p = raw == 65535u ? A.prcp_gap : v;
+    const int q = t + A.hour0;
+    const float D = sx_row_load(A.petd + (size_t)(q / 24) * npad, kb);
+    e = D < 0.f ? D : D * ((sx_cfloat*)A.pet_ratio)[q % 24];
+}
 
 // ------------------------------------------------------------------------------------------------
 // vertical forward: one thread per cell marches the time chunk [t0, t0+T)
 // ------------------------------------------------------------------------------------------------
-template <int ST, bool TAPE>
+template <int ST, bool TAPE, bool CF>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
@@ -280,19 +304,17 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int
 
     // rows are wave-uniform (sx_row_load / sx_row_store): the vector unit does no address arithmetic in the time loop
     const unsigned kb = (unsigned)k * 4u;
-    const SxForcing F(A, kb);
-    unsigned prcp_n = 0u; float pet_n = 0.f;
-    if (T > 0) { prcp_n = F.load_p<SX_NT>(t0); pet_n = F.load_e<SX_NT>(t0, 0.f, true, false); }
+    SxForcing<CF> F(A, kb, t0);
+    if (T > 0) F.template request<SX_NT, false>(t0, true);
     for (int tq = 0; tq * 4 < T; ++tq) {
         float q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int tt = tq * 4 + i;
             if (tt < T) {
-                unsigned prcp_w = prcp_n; float pet_w = pet_n;
-                sx_pinu(prcp_w); sx_pin1(pet_w);     // the wait for this step's forcing goes here, before the next loads
-                if (tt + 1 < T) { prcp_n = F.load_p<SX_NT>(t0 + tt + 1); pet_n = F.load_e<SX_NT>(t0 + tt + 1, pet_w, false, false); }
-                const float prcp = F.prcp(prcp_w), pet = F.pet(pet_w, t0 + tt);
+                F.hold();                            // the wait for this step's forcing goes here, before the next loads
+                if (tt + 1 < T) F.template request<SX_NT, false>(t0 + tt + 1, false);
+                const float prcp = F.prcp(), pet = F.pet();
                 if (TAPE) {
                     const size_t o = (size_t)tt * npad;
                     if (ST == 2 || ST == 3) {     // the interception level: a full tape when it fits, else one checkpoint per SX_HIK steps
@@ -332,7 +354,6 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A,
     const SxVicParams P = sx_vic_load(A, k);
     const float cusl2_m4 = sx_pow_m4(P.cusl2);
     float husl1 = A.hi[k], husl2 = A.hp[k], hlsl = A.hft[k];
-    const SxForcing F(A, (unsigned)k * 4u);
     float4* qt4 = reinterpret_cast<float4*>(A.qtT) + k;
     for (int tq = 0; tq * 4 < T; ++tq) {
         float q[4] = {0.f, 0.f, 0.f, 0.f};
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A,
                     A.tape_hi[o] = husl1; A.tape_hp[o] = husl2; A.tape_hft[o] = hlsl;
                 }
                 float prcp, pet;
-                F.at(t0 + tt, prcp, pet);
+                sx_forcing_at(A, t0 + tt, (unsigned)k * 4u, prcp, pet);
                 const float v = sx_vic_step(P, cusl2_m4, prcp, pet, husl1, husl2, hlsl);
                 if (i == 0) q[0] = v; else if (i == 1) q[1] = v; else if (i == 2) q[2] = v; else q[3] = v;
             }
@@ -367,12 +388,11 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A,
     G.ds_b = A.px_b[0][k]; G.dsm_b = A.px_b[1][k]; G.ws_b = A.px_b[2][k];
     G.husl1_b = A.hi_b[k]; G.husl2_b = A.hp_b[k]; G.hlsl_b = A.hft_b[k];
     const float* qtb = A.qtT + (size_t)k * 4;
-    const SxForcing F(A, (unsigned)k * 4u);
     for (int tt = T - 1; tt >= 0; --tt) {
         const size_t o = (size_t)tt * npad;
         const float q_b = qtb[(size_t)(tt >> 2) * npad * 4 + (tt & 3)];
         float prcp, pet;
-        F.at(t0 + tt, prcp, pet);
+        sx_forcing_at(A, t0 + tt, (unsigned)k * 4u, prcp, pet);
         sx_vic_step_b(P, cusl2_m4, cusl2_m5, prcp, pet, A.tape_hi[o + k], A.tape_hp[o + k], A.tape_hft[o + k], q_b, G);
     }
     A.ci_b[k] = G.b_b; A.cp_b[k] = G.cusl1_b; A.cft_b[k] = G.cusl2_b; A.cst_b[k] = G.clsl_b; A.exc_b[k] = G.ks_b;
@@ -392,12 +412,11 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic_d(SxDeviceArrays 
     float cusl2_m4, cusl2_m5;
     sx_pow_m4_m5(P.cusl2, &cusl2_m4, &cusl2_m5);
     SxVD husl1 = sx_vd(A.hi[k], A.hi_b[k]), husl2 = sx_vd(A.hp[k], A.hp_b[k]), hlsl = sx_vd(A.hft[k], A.hft_b[k]);
-    const SxForcing F(A, (unsigned)k * 4u);
     float* qt = A.qtT + (size_t)k * 4;
     float* qd = A.qtdT + (size_t)k * 4;
     for (int tt = 0; tt < T; ++tt) {
         float prcp, pet;
-        F.at(t0 + tt, prcp, pet);
+        sx_forcing_at(A, t0 + tt, (unsigned)k * 4u, prcp, pet);
         const SxVD r = sx_vic_step_d(P, D, cusl2_m4, cusl2_m5, prcp, pet, husl1, husl2, hlsl);
         const size_t o = (size_t)(tt >> 2) * npad * 4 + (tt & 3);
         qt[o] = r.v; qd[o] = r.d;
@@ -440,7 +459,6 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
     hp = sx_mk(A.hp[k], A.hp_b[k]);
     hft = sx_mk(A.hft[k], A.hft_b[k]);
     if (ST == 3) hst = sx_mk(A.hst[k], A.hst_b[k]);
-    const SxForcing F(A, (unsigned)k * 4u);
     float4* qt4 = reinterpret_cast<float4*>(A.qtT) + k;
     float4* qd4 = reinterpret_cast<float4*>(A.qtdT) + k;
     for (int tq = 0; tq * 4 < T; ++tq) {
@@ -450,7 +468,7 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
             const int tt = tq * 4 + i;
             if (tt < T) {
                 float prcp, pet;
-                F.at(t0 + tt, prcp, pet);
+                sx_forcing_at(A, t0 + tt, (unsigned)k * 4u, prcp, pet);
                 const SxDual r = sx_vertical_step_d<ST>(P, Q, D, prcp, pet, hi, hp, hft, hst);
                 q[i] = r.v; qd[i] = r.d;
             }
@@ -854,7 +872,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
 #ifndef SX_VADJ_WAVES
 #define SX_VADJ_WAVES 1
 #endif
-template <int ST>
+template <int ST, bool CF>
 __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
@@ -888,12 +906,12 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDevi
     // addresses = wave-uniform row (buffer descriptor in scalar registers, advanced by the scalar unit) + the cell's 32-bit
     // byte offset: no vector address arithmetic in the time loop
     const unsigned kb = (unsigned)k * 4u;
-    const SxForcing F(A, kb);
-    unsigned n_prcp = 0u; float n_pet = 0.f, n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
+    SxForcing<CF> F(A, kb, t0 + T - 1);
+    float n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
     const bool hi_taped = (ST == 2 || ST == 3) && A.tape_hi != nullptr;       // wave-uniform
     auto fetch = [&](int tt, bool first) {
         const size_t o = (size_t)tt * npad;
-        n_prcp = F.load_p<SX_VADJ_NT>(t0 + tt); n_pet = F.load_e<SX_VADJ_NT>(t0 + tt, n_pet, first, true);
+        F.template request<SX_VADJ_NT, true>(t0 + tt, first);
         if (hi_taped) n_hi = sx_row_load<SX_VADJ_NT>(A.tape_hi + o, kb);
         n_hp = sx_row_load<SX_VADJ_NT>(A.tape_hp + o, kb); n_hft = sx_row_load<SX_VADJ_NT>(A.tape_hft + o, kb);
         if (ST == 3) n_hst = sx_row_load<SX_VADJ_NT>(A.tape_hst + o, kb);
@@ -910,7 +928,7 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDevi
         if ((ST == 2 || ST == 3) && !hi_taped) {
             float fp[SX_HIK], fe[SX_HIK];
 #pragma unroll
-            for (int j = 0; j < SX_HIK; ++j) F.at(t0 + tt0 + (j < len ? j : 0), fp[j], fe[j]);
+            for (int j = 0; j < SX_HIK; ++j) sx_forcing_at(A, t0 + tt0 + (j < len ? j : 0), kb, fp[j], fe[j]);
             float h = sx_row_load(A.ckpt_hi + (size_t)tb * npad, kb);
 #pragma unroll
             for (int j = 0; j < SX_HIK; ++j) {
@@ -919,12 +937,13 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDevi
             }
         }
         for (int tt = tt0 + len - 1; tt >= tt0; --tt) {
-            unsigned prcp_w = n_prcp; float pet_w = n_pet, hit = n_hi, hp = n_hp, hft = n_hft, hst = n_hst, q = n_q;
-            sx_pinu(prcp_w); sx_pin1(pet_w); sx_pin1(hp); sx_pin1(hft); sx_pin1(q);
+            float hit = n_hi, hp = n_hp, hft = n_hft, hst = n_hst, q = n_q;
+            F.hold();
+            sx_pin1(hp); sx_pin1(hft); sx_pin1(q);
             if (ST == 2 || ST == 3) sx_pin1(hit);
             if (ST == 3) sx_pin1(hst);
             if (tt > 0) fetch(tt - 1, false);
-            const float prcp = F.prcp(prcp_w), pet = F.pet(pet_w, t0 + tt);
+            const float prcp = F.prcp(), pet = F.pet();
             const float hi = (ST == 2 || ST == 3) ? (hi_taped ? hit : s_hi[tt - tt0][threadIdx.x]) : 0.f;
             sx_vertical_step_b<ST>(P, Q, prcp, pet, hi, hp, hft, hst, q, G);
         }

@@ -64,8 +64,18 @@ def test_real_data_that_is_not_of_the_form_falls_back_to_fp32():
     setup, mesh, inp, par, sta, out = _types(g, layout=dict(lay))
     assert inp._smashx_solver.forcing_info()["layout"] == "fp32 rows"
     _same(_run_adjoint(g, chunk_steps=0), _run_adjoint(g, layout=dict(lay)), g)
-    # with the rainfall put on the reader's form (what the reference's own reader would have produced) the case compacts
+    # with both fields put on the fp32 reader's form -- real(k) * 0.1 and daily * ratio(hour) as float32 products, what the reference's
+    # reader produces from Float32 / integer rasters (the fixture went through float64) -- the case compacts
+    from smash_amd.solver import RATIO_PET_HOURLY as R
     g.prcp = np.asfortranarray(np.where(g.prcp < 0, g.prcp, np.rint(g.prcp / np.float32(0.1)).astype(np.float32) * np.float32(0.1)).astype(np.float32))
+    pet = g.pet.copy(order="F")
+    for d in range((g.nt + 1 + 23) // 24):
+        ts = list(range(max(0, d * 24 - 1), min(g.nt, (d + 1) * 24 - 1)))
+        tb = max(ts, key=lambda t: R[(t + 1) % 24])
+        daily = (pet[:, :, tb] / R[(tb + 1) % 24]).astype(np.float32) if R[(tb + 1) % 24] > 0 else np.zeros(pet.shape[:2], np.float32)
+        for t in ts:
+            pet[:, :, t] = daily * R[(t + 1) % 24]
+    g.pet = pet
     setup, mesh, inp, par, sta, out = _types(g, layout=dict(lay))
     assert inp._smashx_solver.forcing_info()["layout"].startswith("compact")
     _same(_run_adjoint(g, chunk_steps=0), _run_adjoint(g, layout=dict(lay)), g)
