@@ -146,8 +146,24 @@ module smashx_c
     logical, save :: sx_abi_checked = .false.
     type(c_ptr), save :: sx_key_forcing = c_null_ptr
     integer, save :: sx_key(6) = 0
+    !  what the cached plan was built from, beyond the sizes: dt, dx, a hash of the mesh arrays, and a strided hash of the
+    !  forcing that is recomputed on every call (in-place writes through the f90wrap setters, or a new Model whose arrays land
+    !  at the freed address with the same shape, must not be served the old forcing or mesh)
+    real(c_float), save :: sx_key_dt = -1._c_float, sx_key_dx = -1._c_float
+    integer(c_long), save :: sx_key_mesh = -1_c_long, sx_key_force = -1_c_long
 
 contains
+
+    !  order-sensitive hash of n 32-bit words taken every `step` (h stays below 2**31, the products below 2**51: no overflow)
+    function sx_hash_words(a, n, step, h0) result(h)
+        integer(c_int), intent(in) :: a(*)
+        integer(c_long), intent(in) :: n, step, h0
+        integer(c_long) :: h, i
+        h = h0
+        do i = 1, n, step
+            h = mod(h*1000003_c_long + iand(int(a(i), c_long), 4294967295_c_long) + i, 2147483647_c_long)
+        end do
+    end function sx_hash_words
 
     subroutine sx_check(rc, where)
         integer(c_int), intent(in) :: rc
@@ -236,6 +252,8 @@ subroutine smashx_prepare(setup, mesh, input_data, plain)
     real(c_float), allocatable, target, save :: wg(:)
     type(c_ptr) :: fkey
     integer :: key(6), j
+    integer(c_long) :: n2, nf, hmesh, hforce
+    integer(c_int), pointer :: wp(:), we(:)
     integer(c_int) :: abi(7), ver
     type(smashx_parameters) :: abi_p
     type(smashx_states) :: abi_s
@@ -259,8 +277,41 @@ subroutine smashx_prepare(setup, mesh, input_data, plain)
         fkey = c_loc(input_data%prcp)
     end if
     key = [sx_structure_id(setup%structure), mesh%nrow, mesh%ncol, setup%ntime_step, mesh%ng, merge(1, 0, setup%sparse_storage)]
+    n2 = int(mesh%nrow, c_long)*int(mesh%ncol, c_long)
+    hmesh = sx_hash_words(mesh%flwdir, n2, 1_c_long, 7_c_long)
+    hmesh = sx_hash_words(mesh%active_cell, n2, 1_c_long, hmesh)
+    hmesh = sx_hash_words(mesh%flwacc, n2, 1_c_long, hmesh)
+    if (mesh%ng .gt. 0) then
+        hmesh = sx_hash_words(mesh%gauge_pos, 2_c_long*mesh%ng, 1_c_long, hmesh)
+        hmesh = sx_hash_words(transfer(mesh%area, [1_c_int]), int(mesh%ng, c_long), 1_c_long, hmesh)
+    end if
+    !  forcing: ~65 k samples per field, every call (0.1 ms); transfer() would copy the arrays, so the words are read in place
+    if (setup%sparse_storage) then
+        nf = int(size(input_data%sparse_prcp, kind=c_long), c_long)
+        call c_f_pointer(c_loc(input_data%sparse_prcp), wp, [nf])
+        call c_f_pointer(c_loc(input_data%sparse_pet), we, [nf])
+    else
+        nf = int(size(input_data%prcp, kind=c_long), c_long)
+        call c_f_pointer(c_loc(input_data%prcp), wp, [nf])
+        call c_f_pointer(c_loc(input_data%pet), we, [nf])
+    end if
+    hforce = sx_hash_words(wp, nf, max(1_c_long, nf/65536_c_long), 11_c_long)
+    hforce = sx_hash_words(we, nf, max(1_c_long, nf/65536_c_long), hforce)
 
-    if (.not. c_associated(sx_plan) .or. .not. c_associated(fkey, sx_key_forcing) .or. any(key .ne. sx_key)) then
+    if (c_associated(sx_plan) .and. c_associated(fkey, sx_key_forcing) .and. all(key .eq. sx_key) .and. setup%dt .eq. sx_key_dt &
+    &   .and. mesh%dx .eq. sx_key_dx .and. hmesh .eq. sx_key_mesh .and. hforce .ne. sx_key_force) then
+        !  same plan, new forcing values (written in place): only the forcing goes up again
+        if (setup%sparse_storage) then
+            call sx_check(smashx_set_forcing(sx_plan, c_loc(input_data%sparse_prcp), c_loc(input_data%sparse_pet), 1_c_int), &
+            & "set_forcing")
+        else
+            call sx_check(smashx_set_forcing(sx_plan, c_loc(input_data%prcp), c_loc(input_data%pet), 0_c_int), "set_forcing")
+        end if
+        sx_key_force = hforce
+    end if
+
+    if (.not. c_associated(sx_plan) .or. .not. c_associated(fkey, sx_key_forcing) .or. any(key .ne. sx_key) .or. &
+    &   setup%dt .ne. sx_key_dt .or. mesh%dx .ne. sx_key_dx .or. hmesh .ne. sx_key_mesh) then
         if (c_associated(sx_plan)) call sx_check(smashx_plan_destroy(sx_plan), "plan_destroy")
         sx_plan = c_null_ptr
         cfg%structure = key(1); cfg%nrow = mesh%nrow; cfg%ncol = mesh%ncol; cfg%nt = setup%ntime_step; cfg%ng = mesh%ng
@@ -285,6 +336,7 @@ subroutine smashx_prepare(setup, mesh, input_data, plain)
         end if
         sx_key_forcing = fkey
         sx_key = key
+        sx_key_dt = setup%dt; sx_key_dx = mesh%dx; sx_key_mesh = hmesh; sx_key_force = hforce
     end if
 
     if (mesh%ng .gt. 0) call sx_check(smashx_set_qobs(sx_plan, c_loc(input_data%qobs)), "set_qobs")

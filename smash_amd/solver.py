@@ -104,7 +104,20 @@ class Solver:
 
     @staticmethod
     def signature(setup, mesh):
-        return (setup.structure, setup.ntime_step, float(setup.dt), mesh.nrow, mesh.ncol, mesh.ng, float(mesh.dx))
+        """Everything a cached plan was built from: sizes, dt, dx and the contents of the mesh arrays."""
+        h = hash(tuple(np.ascontiguousarray(getattr(mesh, k)).tobytes() for k in ("flwdir", "flwacc", "active_cell", "gauge_pos", "area")))
+        return (setup.structure, setup.ntime_step, float(setup.dt), mesh.nrow, mesh.ncol, mesh.ng, float(mesh.dx), bool(setup.sparse_storage), h)
+
+    @staticmethod
+    def forcing_fingerprint(prcp, pet):
+        """Strided hash (~65 k samples per field) of the forcing arrays, recomputed on every call: values written in place, or new
+        arrays that happen to land at the old address, must not be served the forcing already resident in HBM."""
+        out = []
+        for a in (prcp, pet):
+            a = np.asarray(a)
+            flat = a.reshape(-1, order="A") if (a.flags.f_contiguous or a.flags.c_contiguous) else a.ravel()
+            out.append((a.shape, flat[::max(1, flat.size // 65536)].tobytes()))
+        return hash(tuple(out))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -126,9 +139,11 @@ class Solver:
 
     def set_forcing(self, prcp, pet, sparse=False):
         p, e = _f32(prcp), _f32(pet)
+        self._fp = Solver.forcing_fingerprint(prcp, pet)
         _lib.check(_lib.lib().smashx_set_forcing(self._h, _ptr(p), _ptr(e), int(bool(sparse))))
 
     def set_forcing_device_block(self, t0, t1, d_prcp_ptr, d_pet_ptr):
+        self._forcing_external = True
         _lib.check(_lib.lib().smashx_set_forcing_device_block(self._h, int(t0), int(t1), C.c_void_p(d_prcp_ptr),
                                                               C.c_void_p(d_pet_ptr)))
 
@@ -321,13 +336,21 @@ def _tangent_call(s, parameters, parameters_d, parameters_bgd, states, states_d,
 
 def _solver_for(setup, mesh, input_data, **kw):
     s = getattr(input_data, "_smashx_solver", None)
+    if s is not None and getattr(s, "_forcing_external", False):      # the caller placed the forcing in HBM itself (device blocks)
+        fp = None
+    else:
+        fp = Solver.forcing_fingerprint(*((input_data.sparse_prcp, input_data.sparse_pet) if setup.sparse_storage
+                                          else (input_data.prcp, input_data.pet)))
     if s is None or s._sig != Solver.signature(setup, mesh):
         s = Solver(setup, mesh, **kw)
+        s._fp = None
+        input_data._smashx_solver = s
+    if fp is not None and getattr(s, "_fp", None) != fp:
         if setup.sparse_storage:
             s.set_forcing(input_data.sparse_prcp, input_data.sparse_pet, sparse=True)
         else:
             s.set_forcing(input_data.prcp, input_data.pet, sparse=False)
-        input_data._smashx_solver = s
+        s._fp = fp
     if mesh.ng:
         s.set_qobs(input_data.qobs)
     s.set_options(setup.optimize)

@@ -74,6 +74,15 @@ def tol(noise, base=1e-6, k=3.0):
     return max(base, k * float(noise))
 
 
+# On noise-dominated outputs (cold-start fixtures: the reference's two builds differ by 1e-2..1e-1 on a few cells whose transfer
+# store is nearly empty) this bar is wide, and a ceiling does not help: the default build of the kernels differs from the reference
+# there by 5e-2 on two cells of one field, for the same reason the reference differs from itself (a last-bit difference in powf,
+# amplified).  What makes the bar non-vacuous is the exact-libm build: with glibc's float functions restated it is held to
+# BIT-IDENTITY with the reference on every output of every fixture, forward and adjoint (tests/test_gpu_exact.py;
+# profiles/r2_parity_exact.md: 160 / 160 forward outputs and 158 / 158 gradient fields identical), so every difference the default
+# build shows (profiles/r2_parity_default.md) is libm rounding and nothing else.
+
+
 def tol_cost(noise, cost):
     """Absolute bar for the cost: relative as above, floored at 3e-7 absolute because nse/kge are O(1)
     ratios of fp32 sums -- a small cost (good fit) is the difference of nearly equal sums and carries an

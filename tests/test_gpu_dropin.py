@@ -180,3 +180,21 @@ def test_reference_hyper_forward_d_through_dropin(name, mapping):
     dot = sum(float(np.dot(z["adj_hp_b_" + k].astype(np.float64), hd[k])) for k in hp) + \
           sum(float(np.dot(z["adj_hs_b_" + k].astype(np.float64), sd[k])) for k in hs)
     assert abs(t["cost_d"] - dot) <= 2e-4 * abs(dot), (t["cost_d"], dot)
+
+
+def test_dropin_does_not_serve_stale_forcing_or_mesh():
+    """Two models of the same shape in one process: the shim caches its plan (forcing resident in HBM) across calls, and the
+    second model's arrays can land at the freed addresses of the first.  The cache key therefore carries dt, dx, a hash of the
+    mesh arrays and a strided hash of the forcing recomputed on every call (fortran/smashx_dropin.f90)."""
+    g = gu.load("gr_b_16x16x96_nse_gaps")
+    a = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, fast="dropin", **g.opts)
+    wet = np.asfortranarray(np.where(g.prcp < 0, g.prcp, g.prcp * np.float32(1.5)).astype(np.float32))
+    b = refbind.run(g.structure, g.mesh, g.dt, wet, g.pet, g.qobs, g.params, g.states, fast="dropin", **g.opts)
+    ref = refbind.run(g.structure, g.mesh, g.dt, wet, g.pet, g.qobs, g.params, g.states, **g.opts)      # the all-CPU reference
+    assert not np.array_equal(a["qsim"], b["qsim"])
+    for i in range(g.mesh.ng):
+        assert gu.rel_l2(b["qsim"][i], ref["qsim"][i]) <= 1e-5
+    c = refbind.run(g.structure, g.mesh, 1800.0, wet, g.pet, g.qobs, g.params, g.states, fast="dropin", **g.opts)   # another dt
+    refc = refbind.run(g.structure, g.mesh, 1800.0, wet, g.pet, g.qobs, g.params, g.states, **g.opts)
+    for i in range(g.mesh.ng):
+        assert gu.rel_l2(c["qsim"][i], refc["qsim"][i]) <= 1e-5

@@ -8,11 +8,14 @@ adjoint): the oracle cannot run this, so the sweep is checked through size-indep
     derivative         cp, cft and lr (two extra forward sweeps; fp32 finite differences: 5 % bar)
   * storage invariance the chunked checkpoint/recompute adjoint (4 storage chunks) is bit-identical to store-all
 
-BASELINE.json configs[3] (full VDA L-BFGS-B loop, distributed mapping, 2048 x 2048 grid, 1 GPU): a year of hourly fp32
-forcing on 2048^2 cells is 294 GB and cannot be resident on one 288 GB card, so the loop runs on a quarter (2190 steps, the
-same 9.2e9 cell-steps as configs[2]); smash_amd.optimize_lbfgsb (host mirror of mw_optimize::optimize_lbfgsb) drives GPU
-sweeps over 16.8 M control variables; checked: the cost decreases over the iterations and the final forward run reproduces
-the last evaluated cost.
+BASELINE.json configs[3] (full VDA L-BFGS-B loop, distributed mapping, 2048 x 2048 grid, 1 GPU) at its full length: a year of
+hourly fp32 forcing on 2048^2 cells is 294 GB, more than the card; in the lossless compact layout (uint16 rain counts + daily
+PET, smashx_set_forcing_layout) it is 80 GB and the adjoint runs checkpointed in storage chunks.  smash_amd.optimize_lbfgsb
+(host mirror of mw_optimize::optimize_lbfgsb) drives GPU sweeps over 16.8 M control variables; checked: the cost decreases
+over the iterations and the final forward run reproduces the last evaluated cost.
+
+Chained routing rounds (sx_kernels.h): bit-identity with one launch per round at the 2048 x 1024 tile of configs[4], and the
+stall path -- a chained group that never publishes makes its consumers give up, the sweep is repeated unchained, same bits.
 
 SMASHX_FULLSIZE_GRID / SMASHX_FULLSIZE_NT (and SMASHX_VDA_GRID / SMASHX_VDA_NT) shrink the cases for a quick run.
 """
@@ -30,21 +33,24 @@ FIELDS_P = ("ci", "cp", "cft", "exc", "lr")
 FIELDS_S = ("hi", "hp", "hft", "hlr")
 
 
-def _problem(chunk, N=N, NT=NT):
+def _problem(chunk, N=N, NT=NT, ncol=None, compact=False):
     import torch
     import smash_amd
     from smash_amd import synth
     from smash_amd.solver import Solver
     dev = torch.device("cuda", 0)
-    m = synth.make_mesh(N, N, ng=8)
+    M = ncol or N
+    m = synth.make_mesh(N, M, ng=8)
     setup = smash_amd.SetupDT(0, m.ng, structure="gr-b", dt=3600.0, ntime_step=NT)
     setup.optimize.jobs_fun, setup.optimize.wjobs_fun = ["nse"], [1.0]
     mesh = smash_amd.MeshDT.from_synth(setup, m)
     sol = Solver(setup, mesh, chunk_steps=chunk)
+    if compact:                                      # uint16 rain counts + daily PET: a year of 2048^2 forcing is 80 GB instead of 294
+        sol.set_forcing_layout(compact=True, prcp_factor=0.1, pet_ratio=synth._pet_tables()[1], pet_hour0=0)
     rows, cols = sol.cell_order()
     d_rows = torch.from_numpy(rows.astype(np.int64)).to(dev)
     d_cols = torch.from_numpy(cols.astype(np.int64)).to(dev)
-    tb = max(1, min(NT, (1 << 26) // max(sol.ncells, 1)))
+    tb = max(24, (1 << 26) // max(sol.ncells, 1) // 24 * 24)
     for t0 in range(0, NT, tb):
         t1 = min(NT, t0 + tb)
         prcp, pet = synth.forcing_block(d_rows, d_cols, t0, t1, xp=torch, device=dev)
@@ -53,9 +59,9 @@ def _problem(chunk, N=N, NT=NT):
         del prcp, pet
     del d_rows, d_cols
     torch.cuda.empty_cache()
-    par = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(N, N))
-    sta = smash_amd.StatesDT.from_dict(mesh, synth.make_states(N, N, warm=True))
-    parq = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(N, N, perturb=0.1))
+    par = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(N, M))
+    sta = smash_amd.StatesDT.from_dict(mesh, synth.make_states(N, M, warm=True))
+    parq = smash_amd.ParametersDT.from_dict(mesh, synth.make_parameters(N, M, perturb=0.1))
     out = smash_amd.OutputDT(setup, mesh)
     sol.set_options(setup.optimize)
     sol.upload(parq, sta)
@@ -135,8 +141,9 @@ def test_vda_lbfgsb_loop_2048():
     import types
     import smash_amd
     n2 = int(os.environ.get("SMASHX_VDA_GRID", "2048"))
-    nt2 = int(os.environ.get("SMASHX_VDA_NT", "2190"))
-    sol, setup, mesh, par, sta = _problem(0, n2, nt2)
+    nt2 = int(os.environ.get("SMASHX_VDA_NT", "8760"))
+    sol, setup, mesh, par, sta = _problem(0, n2, nt2, compact=True)
+    assert sol.forcing_info()["layout"].startswith("compact")
     out = smash_amd.OutputDT(setup, mesh)
     sol.upload(par, sta)
     sol.sweep(False)
@@ -157,6 +164,56 @@ def test_vda_lbfgsb_loop_2048():
         assert np.all(a >= lb[i] - 1e-3 * abs(ub[i] - lb[i])) and np.all(a <= ub[i] + 1e-3 * abs(ub[i] - lb[i])), k
     del sol
     gc.collect()
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_chained_rounds_equal_launch_per_round_at_the_2048x1024_tile():
+    """Twice the groups of the 1024^2 case in the chained launch (more than the chip holds at once): the progress-counter
+    protocol must neither stall nor change a bit."""
+    nt = int(os.environ.get("SMASHX_CHAIN_NT", "192"))
+    res = {}
+    for chain in ("1", "0"):
+        def run():
+            sol, setup, mesh, par, sta = _problem(0, 2048, nt, ncol=1024)
+            r = _adjoint(sol, setup, mesh, par, sta)
+            tm = sol.timing()
+            del sol
+            gc.collect()
+            return r, tm
+        res[chain] = _with_env({"SMASHX_CHAIN_ROUNDS": chain}, run)
+    (c1, p1, s1, q1), t1 = res["1"]
+    (c0, p0, s0, q0), t0 = res["0"]
+    assert t1["route_fwd_launches"] == 2 and t0["route_fwd_launches"] == t0["n_rounds"] > 2
+    assert c1 == c0 and np.array_equal(q1, q0)
+    assert all(np.array_equal(p1[k], p0[k]) for k in FIELDS_P) and all(np.array_equal(s1[k], s0[k]) for k in FIELDS_S)
+
+
+def test_stalled_chain_falls_back_to_one_launch_per_round(capfd):
+    """SMASHX_DEBUG_MUTE_GROUP=-2: the first chained group never publishes its progress; its consumers hit the poll limit
+    (SMASHX_SPIN_LIMIT) and raise the stall flag; smashx_sweep drops the plan to one launch per round, repeats the sweep and
+    returns the same bits as a healthy plan."""
+    ref, tref = _with_env({}, lambda: (lambda P: (_adjoint(*P), P[0].timing()))(_problem(0, 256, 96)))
+    def run():
+        P = _problem(0, 256, 96)                     # the forward run of _problem already stalls and falls back
+        r = _adjoint(*P)
+        return r, P[0].timing()
+    got, tgot = _with_env({"SMASHX_DEBUG_MUTE_GROUP": "-2", "SMASHX_SPIN_LIMIT": "2000"}, run)
+    assert "stalled" in capfd.readouterr().err
+    assert tref["route_fwd_launches"] == 2 and tgot["route_fwd_launches"] == tgot["n_rounds"] > 2
+    assert got[0] == ref[0] and np.array_equal(got[3], ref[3])
+    assert all(np.array_equal(got[1][k], ref[1][k]) for k in FIELDS_P) and all(np.array_equal(got[2][k], ref[2][k]) for k in FIELDS_S)
 
 
 def sol_qobs(sol, setup, mesh, par, sta):

@@ -374,3 +374,29 @@ def test_error_behaviour():
     with pytest.raises(smash_amd.SmashxError) as e:
         smash_amd.forward(setup, mesh, inp, par, bgd, sta, sta.copy(), out, np.float32(0))
     assert e.value.code == _lib.E_ARG
+
+
+def test_forcing_written_in_place_is_not_served_from_the_cache():
+    """The plan (with the forcing resident in HBM) is cached on the input_data object.  Rain written IN PLACE into the same array
+    -- what the f90wrap setters of the reference do -- must reach the device: the second run has to equal a fresh run on the
+    new values, not the first run (the cache key used to be the array's address and shape)."""
+    import smash_amd
+    g = gu.load("gr_b_16x16x96_nse_gaps")
+    setup, mesh, inp, par, sta, out = _types(g)
+    smash_amd.forward(setup, mesh, inp, par.copy(), inp._bgd[0], sta.copy(), inp._bgd[1], out, np.float32(0))
+    q1 = out.qsim.copy()
+    s1 = inp._smashx_solver
+    inp.prcp[:, :, 10:40] *= np.float32(1.5)                       # same array object, same address
+    smash_amd.forward(setup, mesh, inp, par.copy(), inp._bgd[0], sta.copy(), inp._bgd[1], out, np.float32(0))
+    q2 = out.qsim.copy()
+    assert inp._smashx_solver is s1                                # the plan itself is kept, only the forcing went up again
+    g2 = gu.load("gr_b_16x16x96_nse_gaps")
+    g2.prcp = inp.prcp.copy(order="F")
+    fresh = _run_forward(g2)[2].qsim
+    assert not np.array_equal(q1, q2) and np.array_equal(q2, fresh)
+    # a different mesh of the same shape (one more inactive cell) must rebuild the plan
+    mesh.active_cell = np.asfortranarray(mesh.active_cell.copy())
+    r, c = np.argwhere((np.asarray(mesh.flwacc) == 1) & (np.asarray(mesh.active_cell) == 1))[0]
+    mesh.active_cell[r, c] = 0
+    smash_amd.forward(setup, mesh, inp, par.copy(), inp._bgd[0], sta.copy(), inp._bgd[1], out, np.float32(0))
+    assert inp._smashx_solver is not s1
