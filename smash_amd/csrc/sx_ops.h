@@ -254,11 +254,16 @@ SX_DEV void sx_transfer_b(float prcp, float pr, float& pr_b, float ct, const SxD
         pr_b = pr_imd_b;
     } else {
         pwr3_b = pr_imd_b;
-        // Tapenade guards pwx3 <= 0 with a non-integer exponent (forward_db.f90:6391-6395)
-        pwx3_b = (g_pwx3 <= 0.f) ? 0.f : -0.25f * sx_powf(g_pwx3, -1.25f) * pwr3_b;
+        // Tapenade guards pwx3 <= 0 with a non-integer exponent (forward_db.f90:6391-6395).  The two powers go through the same
+        // fixed-exponent helpers as everywhere else: the general sx_powf would park ~24 fp64 polynomial constants (48 registers) in
+        // the kernel for a branch that runs on 0.1 % of the steps, and cost the whole kernel a wave of occupancy
+        float g_m025, g_m125 = 0.f, g_m4, g_m5;
+        if (g_pwx3 > 0.f) sx_pow_m025_m125(g_pwx3, &g_m025, &g_m125);
+        sx_pow_m4_m5(g_pwx1, &g_m4, &g_m5);
+        pwx3_b = (g_pwx3 <= 0.f) ? 0.f : -0.25f * g_m125 * pwr3_b;
         pwr1_b = pwx3_b;
         pwr2_b = -pwx3_b;
-        pwx1_b = -4.f * sx_powf(g_pwx1, -5.f) * pwr1_b;
+        pwx1_b = -4.f * g_m5 * pwr1_b;
         htb = htb + ct * pwx1_b - ct * pr_imd_b;
         ct_b = ct_b + -4.f * ct_m5 * pwr2_b - ht * pr_imd_b + ht * pwx1_b;
         pr_b = 0.f;
