@@ -14,8 +14,9 @@
  * reference holds them (row index fastest); gauge_pos and path are 0-based here (the Fortran shim
  * subtracts 1), optimize_start_step stays 1-based like setup%optimize%optimize_start_step.  The
  * caller owns every array; the plan owns all device memory.  Every function returns 0 on success
- * or a negative SMASHX_E_* code (the reference has no error channel: the Fortran shim prints and
- * continues).  There is no CPU fallback: without a usable HIP device plan creation fails.
+ * or a negative SMASHX_E_* code (the reference has no error channel: the Fortran shim prints
+ * smashx_last_error() and stops with `error stop`, the Python mirror raises SmashxError).  There is
+ * no CPU fallback: without a usable HIP device plan creation fails.
  */
 #ifndef SMASHX_H
 #define SMASHX_H
@@ -186,6 +187,23 @@ int smashx_sweep(smashx_plan* plan, int adjoint, float cost_b);
 int smashx_download(smashx_plan* plan, int adjoint, smashx_parameters* params, smashx_states* states, float* qsim,
                     smashx_costs* costs, smashx_states* fstates, smashx_parameters* params_b, smashx_states* states_b);
 int smashx_get_timing(const smashx_plan* plan, smashx_timing* out);
+
+/* Control vector of the variational calibration on the device (mw_optimize.f90:679-777: var_to_control_lbfgsb /
+ * control_to_var_lbfgsb).  The control vector holds the fields flagged in optim_parameters / optim_states
+ * (smashx_set_options), parameters first, md_constant order, each over the active cells with the column index outer and the row
+ * index inner, in fp64 -- exactly what the reference hands to lbfgsb.f.  Fields are in the optimiser's space: normalised when
+ * denormalize_forward is set (the calibration's mode of operation).
+ *   smashx_control_size      length n of the control vector (0 when nothing is flagged)
+ *   smashx_control_set       control_to_var: x -> the flagged device fields (denormalised on the device like smashx_upload does);
+ *                            every other field keeps the device copy of the last smashx_upload, which must have happened once
+ *   smashx_control_get       var_to_control of the fields the device holds
+ *   smashx_control_gradient  after an adjoint sweep: d cost / d x, i.e. parameters_b / states_b of the flagged fields packed
+ *                            the same way (what mw_optimize.f90:606 builds from forward_b's output)
+ * x / g are host arrays of n doubles; packing, casts and (de)normalisation run on the device, one contiguous copy crosses PCIe. */
+int smashx_control_size(smashx_plan* plan);
+int smashx_control_set(smashx_plan* plan, const double* x);
+int smashx_control_get(smashx_plan* plan, double* x);
+int smashx_control_gradient(smashx_plan* plan, double* g);
 /* Optional whole-domain stores of the forward run, OutputDT%qsim_domain / net_prcp_domain (mwd_output.f90:43-47,
  * written at md_forward_structure.f90:158-194 when setup%save_qsim_domain / save_net_prcp_domain): caller-owned host
  * arrays (nrow, ncol, nt) column-major -- inactive cells are set to -99 like OutputDT_initialise does -- or, with

@@ -154,6 +154,32 @@ __global__ void k_close_petd(float* petd, size_t n) {      // days that only eve
     if (i < n && !(petd[i] == petd[i])) petd[i] = 0.f;
 }
 
+// ---- control vector of the calibration (mw_optimize.f90:679-777) ------------------------------------------------------------
+// control_to_var: x[off + pos[k]] (fp64, optimiser space) -> cell vector (denormalised like k_denormalize), the full plane the
+// downloads read, and -- when a regulariser is on -- the plane compute_jreg sees (normalise(denormalise(v)), mwd_cost.f90:284-291)
+__global__ void k_control_set(float* cellv, float* full, float* jx, const double* x, const int* pos, const int* flat, int n, long off,
+                              float lb, float ub, int denorm) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float v = (float)x[off + pos[k]];
+    const float d = denorm ? v * (ub - lb) + lb : v;
+    cellv[k] = d;
+    full[flat[k]] = d;
+    if (jx) jx[flat[k]] = denorm ? (d - lb) / (ub - lb) : v;
+}
+// var_to_control (grad = 0): the optimiser-space value of the field; gradient (grad = 1): cell gradient x (ub - lb) under
+// denormalize_forward (DENORMALIZE_*_B, forward_db.f90:967-1057)
+__global__ void k_control_get(double* x, const float* src, const int* pos, const int* flat, int n, long off, float lb, float ub,
+                              int denorm, int grad, int from_full) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const float v = src[from_full ? flat[k] : k];
+    float r;
+    if (grad) r = denorm ? (ub - lb) * v : v;
+    else r = denorm ? (v - lb) / (ub - lb) : v;
+    x[off + pos[k]] = (double)r;
+}
+
 // boundary series <-> dense message buffer [edge][Tq] float4
 __global__ void k_halo_pack(float4* buf, const float4* x4, const int* slots, int nedge, int nx, int Tq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -306,6 +332,8 @@ struct smashx_plan {
     float* st0[5] = {nullptr};       // initial (denormalised) states in cell order
     float* ckpt = nullptr;           // [nchunks][5][npad]
     float* d_prcp = nullptr; float* d_pet = nullptr;
+    // control vector (smashx_control_*): position of cell k among the active cells in column-major order, device staging
+    int* d_ctrl_pos = nullptr; double* d_ctrl = nullptr; size_t ctrl_cap = 0;
     // compact forcing (smashx_set_forcing_layout)
     smashx_forcing_layout flay{};
     unsigned short* d_prcp16 = nullptr; float* d_petd = nullptr; float* d_ratio = nullptr; unsigned* d_fstatus = nullptr;
@@ -508,8 +536,11 @@ void vert_fwd(smashx_plan* p, int off, bool tape, int t0, int T, int k0 = 0, int
         case 5: {
             const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
             p->mark_begin(0, p->stream, (double)(B.k1 - B.k0) * T);
-            if (tape) hipLaunchKernelGGL((sx_k_vert_fwd_vic<true>), grid, block, 0, p->stream, B, t0, T);
-            else      hipLaunchKernelGGL((sx_k_vert_fwd_vic<false>), grid, block, 0, p->stream, B, t0, T);
+            const bool cf = B.prcp16 != nullptr;
+            if (tape) { if (cf) hipLaunchKernelGGL((sx_k_vert_fwd_vic<true, true>), grid, block, 0, p->stream, B, t0, T);
+                        else    hipLaunchKernelGGL((sx_k_vert_fwd_vic<true, false>), grid, block, 0, p->stream, B, t0, T); }
+            else      { if (cf) hipLaunchKernelGGL((sx_k_vert_fwd_vic<false, true>), grid, block, 0, p->stream, B, t0, T);
+                        else    hipLaunchKernelGGL((sx_k_vert_fwd_vic<false, false>), grid, block, 0, p->stream, B, t0, T); }
             p->mark_end();
         } break;
         default: launch_vert_fwd<4>(p, B, tape, t0, T); break;
@@ -528,7 +559,9 @@ void vert_adj(smashx_plan* p, int off, int t0, int T, int k0 = 0, int k1 = -1) {
         case 1: SX_VADJ(1); break;
         case 2: SX_VADJ(2); break;
         case 3: SX_VADJ(3); break;
-        case 5: hipLaunchKernelGGL(sx_k_vert_adj_vic, grid, block, 0, p->stream, B, t0, T); break;
+        case 5: if (cf) hipLaunchKernelGGL(sx_k_vert_adj_vic<true>, grid, block, 0, p->stream, B, t0, T);
+                else hipLaunchKernelGGL(sx_k_vert_adj_vic<false>, grid, block, 0, p->stream, B, t0, T);
+                break;
         default: SX_VADJ(4); break;
     }
 #undef SX_VADJ
@@ -1631,6 +1664,106 @@ int smashx_set_exchange(smashx_plan* p, void* comm, const int* out_peer, const i
     p->xcomm = c;
     return 0;
 }
+
+// ---- control vector -----------------------------------------------------------------------------------------------------------
+namespace {
+int ctrl_fields(const smashx_plan* p, int* idx) {     // flagged fields the structure uses: parameters (0..15) then states (16..23)
+    int nf = 0;
+    for (int f = 0; f < SMASHX_GNP; ++f) if (p->opt.optim_parameters[f] > 0) idx[nf++] = f;
+    for (int f = 0; f < SMASHX_GNS; ++f) if (p->opt.optim_states[f] > 0) idx[nf++] = SMASHX_GNP + f;
+    return nf;
+}
+int ctrl_prepare(smashx_plan* p, int nf) {
+    int rc;
+    if (!p->d_ctrl_pos) {
+        // rank of every plan cell among the active cells in (col outer, row inner) order = ascending flat index row + col * nrow
+        std::vector<int> order(p->n), pos(p->n);
+        for (int k = 0; k < p->n; ++k) order[k] = k;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return p->sch.cell_flat[a] < p->sch.cell_flat[b]; });
+        for (int i = 0; i < p->n; ++i) pos[order[i]] = i;
+        if ((rc = p->upload_vec(&p->d_ctrl_pos, pos))) return rc;
+    }
+    const size_t need = (size_t)nf * p->n;
+    if (need > p->ctrl_cap) {
+        if (p->d_ctrl) p->dfree(p->d_ctrl);
+        if ((rc = p->dmalloc(&p->d_ctrl, need))) return rc;
+        p->ctrl_cap = need;
+    }
+    return 0;
+}
+struct CtrlField { float* cellv; float* full; float lb, ub; bool used; };
+CtrlField ctrl_field(smashx_plan* p, int idx, bool grad) {
+    CtrlField F{nullptr, nullptr, 0.f, 1.f, false};
+    float* pv[NPS] = {p->A.ci, p->A.cp, p->A.cft, p->A.cst, p->A.exc, p->A.lr, p->A.px[0], p->A.px[1], p->A.px[2]};
+    float* pg[NPS] = {p->A.ci_b, p->A.cp_b, p->A.cft_b, p->A.cst_b, p->A.exc_b, p->A.lr_b, p->A.px_b[0], p->A.px_b[1], p->A.px_b[2]};
+    float* sg[5] = {p->A.hi_b, p->A.hp_b, p->A.hft_b, p->A.hst_b, p->A.hlr_b};
+    if (idx < SMASHX_GNP) {
+        const int i = param_slot_of(p->st, idx);
+        F.lb = p->opt.lb_parameters[idx]; F.ub = p->opt.ub_parameters[idx];
+        if (i >= 0) { F.cellv = grad ? pg[i] : pv[i]; F.full = p->d_fullP[idx]; F.used = true; }
+    } else {
+        const int f = idx - SMASHX_GNP, i = state_slot_of(p->st, f);
+        F.lb = p->opt.lb_states[f]; F.ub = p->opt.ub_states[f];
+        if (i >= 0) { F.cellv = grad ? sg[i] : p->st0[i]; F.full = p->d_fullS[f]; F.used = true; }
+    }
+    return F;
+}
+}  // namespace
+
+int smashx_control_size(smashx_plan* p) {
+    if (!p) return fail(SMASHX_E_ARG, "null plan");
+    int idx[SMASHX_GNP + SMASHX_GNS];
+    return ctrl_fields(p, idx) * p->n;
+}
+
+int smashx_control_set(smashx_plan* p, const double* x) {
+    if (!p || !x) return fail(SMASHX_E_ARG, "null argument");
+    if (!p->uploaded) return fail(SMASHX_E_STATE, "smashx_control_set needs one complete smashx_upload first (the fields that are not optimised)");
+    if (p->tiled) return fail(SMASHX_E_UNSUPPORTED, "control vector on a tiled plan");
+    int rc = set_device(p); if (rc) return rc;
+    int idx[SMASHX_GNP + SMASHX_GNS];
+    const int nf = ctrl_fields(p, idx);
+    if (nf == 0) return fail(SMASHX_E_STATE, "no field is flagged in optim_parameters / optim_states");
+    if ((rc = ctrl_prepare(p, nf))) return rc;
+    HIPCHK(hipMemcpyAsync(p->d_ctrl, x, (size_t)nf * p->n * sizeof(double), hipMemcpyHostToDevice, p->stream));
+    const dim3 b(256), gk((p->n + 255) / 256);
+    for (int j = 0; j < nf; ++j) {
+        const CtrlField F = ctrl_field(p, idx[j], false);
+        if (!F.used) continue;                       // flagged but not read by this structure: the reference carries it along, the sweep ignores it
+        float* jx = (p->opt.njr > 0 && p->d_jx[idx[j]]) ? p->d_jx[idx[j]] : nullptr;
+        hipLaunchKernelGGL(k_control_set, gk, b, 0, p->stream, F.cellv, F.full, jx, p->d_ctrl, p->d_ctrl_pos, p->d_cell_flat, p->n,
+                           (long)j * p->n, F.lb, F.ub, p->opt.denormalize_forward);
+    }
+    hipLaunchKernelGGL(sx_k_prep_routing, gk, b, 0, p->stream, p->A);
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int control_read(smashx_plan* p, double* x, int grad) {
+    if (!p || !x) return fail(SMASHX_E_ARG, "null argument");
+    if (!p->uploaded) return fail(SMASHX_E_STATE, "nothing uploaded");
+    if (grad && !(p->adj_ready && p->last_adjoint)) return fail(SMASHX_E_STATE, "the last sweep was not an adjoint sweep");
+    int rc = set_device(p); if (rc) return rc;
+    int idx[SMASHX_GNP + SMASHX_GNS];
+    const int nf = ctrl_fields(p, idx);
+    if (nf == 0) return fail(SMASHX_E_STATE, "no field is flagged in optim_parameters / optim_states");
+    if ((rc = ctrl_prepare(p, nf))) return rc;
+    HIPCHK(hipMemsetAsync(p->d_ctrl, 0, (size_t)nf * p->n * sizeof(double), p->stream));
+    const dim3 b(256), gk((p->n + 255) / 256);
+    for (int j = 0; j < nf; ++j) {
+        const CtrlField F = ctrl_field(p, idx[j], grad != 0);
+        if (!F.used) continue;
+        hipLaunchKernelGGL(k_control_get, gk, b, 0, p->stream, p->d_ctrl, F.cellv, p->d_ctrl_pos, p->d_cell_flat, p->n, (long)j * p->n,
+                           F.lb, F.ub, p->opt.denormalize_forward, grad, 0);
+    }
+    HIPCHK(hipMemcpyAsync(x, p->d_ctrl, (size_t)nf * p->n * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+int smashx_control_get(smashx_plan* p, double* x) { return control_read(p, x, 0); }
+int smashx_control_gradient(smashx_plan* p, double* g) { return control_read(p, g, 1); }
 
 int smashx_get_timing(const smashx_plan* p, smashx_timing* out) {
     if (!p || !out) return fail(SMASHX_E_ARG, "null argument");

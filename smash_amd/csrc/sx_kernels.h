@@ -346,7 +346,9 @@ __device__ __forceinline__ SxVicParams sx_vic_load(const SxDeviceArrays& A, int 
     P.ds = A.px[0][k]; P.dsm = A.px[1][k]; P.ws = A.px[2][k];
     return P;
 }
-template <bool TAPE>
+// Same shape as the GR kernels: wave-uniform rows through buffer descriptors, forcing one step ahead (SxForcing), streaming stores
+// of the tapes, qt as one float4 per four steps; the reverse kernel prefetches the three taped levels and qt_b a step ahead.
+template <bool TAPE, bool CF>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A, int t0, int T) {
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
@@ -354,28 +356,32 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A,
     const SxVicParams P = sx_vic_load(A, k);
     const float cusl2_m4 = sx_pow_m4(P.cusl2);
     float husl1 = A.hi[k], husl2 = A.hp[k], hlsl = A.hft[k];
-    float4* qt4 = reinterpret_cast<float4*>(A.qtT) + k;
+    const unsigned kb = (unsigned)k * 4u;
+    SxForcing<CF> F(A, kb, t0);
+    if (T > 0) F.template request<SX_NT, false>(t0, true);
     for (int tq = 0; tq * 4 < T; ++tq) {
         float q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int tt = tq * 4 + i;
             if (tt < T) {
+                F.hold();
+                if (tt + 1 < T) F.template request<SX_NT, false>(t0 + tt + 1, false);
                 if (TAPE) {
-                    const size_t o = (size_t)tt * npad + k;
-                    A.tape_hi[o] = husl1; A.tape_hp[o] = husl2; A.tape_hft[o] = hlsl;
+                    const size_t o = (size_t)tt * npad;
+                    sx_row_store<SX_NT>(A.tape_hi + o, kb, husl1);
+                    sx_row_store<SX_NT>(A.tape_hp + o, kb, husl2);
+                    sx_row_store<SX_NT>(A.tape_hft + o, kb, hlsl);
                 }
-                float prcp, pet;
-                sx_forcing_at(A, t0 + tt, (unsigned)k * 4u, prcp, pet);
-                const float v = sx_vic_step(P, cusl2_m4, prcp, pet, husl1, husl2, hlsl);
-                if (i == 0) q[0] = v; else if (i == 1) q[1] = v; else if (i == 2) q[2] = v; else q[3] = v;
+                q[i] = sx_vic_step(P, cusl2_m4, F.prcp(), F.pet(), husl1, husl2, hlsl);
             }
         }
-        qt4[(size_t)tq * npad] = make_float4(q[0], q[1], q[2], q[3]);
+        sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
     }
     A.hi[k] = husl1; A.hp[k] = husl2; A.hft[k] = hlsl;
 }
 
+template <bool CF>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A, int t0, int T) {
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
@@ -387,13 +393,23 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A,
     G.b_b = A.ci_b[k]; G.cusl1_b = A.cp_b[k]; G.cusl2_b = A.cft_b[k]; G.clsl_b = A.cst_b[k]; G.ks_b = A.exc_b[k];
     G.ds_b = A.px_b[0][k]; G.dsm_b = A.px_b[1][k]; G.ws_b = A.px_b[2][k];
     G.husl1_b = A.hi_b[k]; G.husl2_b = A.hp_b[k]; G.hlsl_b = A.hft_b[k];
-    const float* qtb = A.qtT + (size_t)k * 4;
-    for (int tt = T - 1; tt >= 0; --tt) {
+    const unsigned kb = (unsigned)k * 4u;
+    SxForcing<CF> F(A, kb, t0 + T - 1);
+    float n_h1 = 0.f, n_h2 = 0.f, n_hl = 0.f, n_q = 0.f;
+    auto fetch = [&](int tt, bool first) {
         const size_t o = (size_t)tt * npad;
-        const float q_b = qtb[(size_t)(tt >> 2) * npad * 4 + (tt & 3)];
-        float prcp, pet;
-        sx_forcing_at(A, t0 + tt, (unsigned)k * 4u, prcp, pet);
-        sx_vic_step_b(P, cusl2_m4, cusl2_m5, prcp, pet, A.tape_hi[o + k], A.tape_hp[o + k], A.tape_hft[o + k], q_b, G);
+        F.template request<SX_VADJ_NT, true>(t0 + tt, first);
+        n_h1 = sx_row_load<SX_VADJ_NT>(A.tape_hi + o, kb); n_h2 = sx_row_load<SX_VADJ_NT>(A.tape_hp + o, kb);
+        n_hl = sx_row_load<SX_VADJ_NT>(A.tape_hft + o, kb);
+        n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
+    };
+    if (T > 0) fetch(T - 1, true);
+    for (int tt = T - 1; tt >= 0; --tt) {
+        float h1 = n_h1, h2 = n_h2, hl = n_hl, q_b = n_q;
+        F.hold();
+        sx_pin1(h1); sx_pin1(h2); sx_pin1(hl); sx_pin1(q_b);
+        if (tt > 0) fetch(tt - 1, false);
+        sx_vic_step_b(P, cusl2_m4, cusl2_m5, F.prcp(), F.pet(), h1, h2, hl, q_b, G);
     }
     A.ci_b[k] = G.b_b; A.cp_b[k] = G.cusl1_b; A.cft_b[k] = G.cusl2_b; A.cst_b[k] = G.clsl_b; A.exc_b[k] = G.ks_b;
     A.px_b[0][k] = G.ds_b; A.px_b[1][k] = G.dsm_b; A.px_b[2][k] = G.ws_b;

@@ -240,6 +240,38 @@ SX_HD float sx_powf(float x, float y) { return sx_pow_from(sx_log2_d(x), x, y); 
 
 #endif   // SX_EXACT_LIBM
 
+// Several powers and the logarithm of ONE base (vic-a: x**y, x**(y-1) and ln x of the same x in the adjoint of the infiltration
+// curve, forward_db.f90:6808-6990).  Default build: the base-2 logarithm is evaluated once -- sx_powb / sx_logb return exactly what
+// sx_powf / sx_logf return, by construction.  Exact-libm build: every call is the C library's own algorithm, nothing is shared.
+struct SxPowBase {
+    float x;
+#if !SX_EXACT_LIBM
+    SxLog2 L;
+#endif
+};
+SX_HD SxPowBase sx_powbase(float x) {
+    SxPowBase B; B.x = x;
+#if !SX_EXACT_LIBM
+    B.L = sx_log2_d(x);
+#endif
+    return B;
+}
+SX_HD float sx_powb(const SxPowBase& B, float y) {
+#if SX_EXACT_LIBM
+    return sx_powf(B.x, y);
+#else
+    return sx_pow_from(B.L, B.x, y);
+#endif
+}
+SX_HD float sx_logb(const SxPowBase& B) {
+#if SX_EXACT_LIBM
+    return sx_logf(B.x);
+#else
+    if (B.L.special) return B.L.special == 1 ? -sx_inff() : B.L.special == 3 ? sx_inff() : sx_nanf();
+    return (float)(B.L.l2 * 0.6931471805599453);
+#endif
+}
+
 // ---- fdlibm float expm1 / tanh (Sun Microsystems 1993, public algorithm; the float port is what
 // ---- glibc 2.35 ships as expm1f/tanhf).  Restated for arguments the model can produce:
 // ---- expm1 for x <= 44 (tanh passes -2|x| in [-2,0) or 2|x| in [2,44)).

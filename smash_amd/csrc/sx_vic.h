@@ -109,6 +109,7 @@ SX_DEV float sx_pow_guard_b(float x, float y, float r_b) {
 SX_DEV void sx_vic_infiltration_b(float prcp, float cusl1, float cusl2, float b, float husl1, float husl2, float runoff_b, SxVicGrads& G) {
     float bp1 = b + 1.f, ifl, cusl = 0.f, wusl = 0.f, iflm = 0.f, iflc = 0.f, pwx1 = 0.f, pwy1 = 0.f, pwr1 = 0.f, pwr1_first = 0.f;
     int c_prcp, c_w1 = 0, c_w2 = 0, c_full = 0, c_min;
+    SxPowBase B1 = sx_powbase(1.f), B2 = B1;
     if (prcp <= 0.f) { ifl = 0.f; c_prcp = 0; c_min = 0; }
     else {
         c_prcp = 1;
@@ -119,13 +120,15 @@ SX_DEV void sx_vic_infiltration_b(float prcp, float cusl1, float cusl2, float b,
         iflm = cusl * bp1;
         pwx1 = 1.f - sx_fdiv(wusl, cusl);
         pwy1 = sx_fdiv(1.f, bp1);
-        pwr1 = sx_powf(pwx1, pwy1);
+        B1 = sx_powbase(pwx1);                     // one logarithm per base: the adjoint below raises each base three times
+        pwr1 = sx_powb(B1, pwy1);
         iflc = iflm * (1.f - pwr1);
         if (iflc + prcp >= iflm) { ifl = cusl - wusl; c_full = 1; }
         else {
             pwx1 = 1.f - sx_fdiv((iflc + prcp), iflm);
             pwr1_first = pwr1;
-            pwr1 = sx_powf(pwx1, bp1);
+            B2 = sx_powbase(pwx1);
+            pwr1 = sx_powb(B2, bp1);
             ifl = cusl - wusl - cusl * pwr1;
             c_full = 0;
         }
@@ -164,9 +167,9 @@ SX_DEV void sx_vic_infiltration_b(float prcp, float cusl1, float cusl2, float b,
             pwr1_b = -(cusl * ifl_b);
             pwr1 = pwr1_first;
             if (pwx1 <= 0.0f && (bp1 == 0.0f || bp1 != (float)(int)bp1)) pwx1_b = 0.f;
-            else pwx1_b = bp1 * sx_powf(pwx1, bp1 - 1.f) * pwr1_b;
+            else pwx1_b = bp1 * sx_powb(B2, bp1 - 1.f) * pwr1_b;
             if (pwx1 <= 0.0f) bp1_b = 0.f;
-            else bp1_b = sx_powf(pwx1, bp1) * sx_logf(pwx1) * pwr1_b;
+            else bp1_b = sx_powb(B2, bp1) * sx_logb(B2) * pwr1_b;
             iflc_b = -(sx_fdiv(pwx1_b, iflm));
             iflm_b = sx_fdiv((prcp + iflc) * pwx1_b, iflm * iflm);
             pwy1 = sx_fdiv(1.f, bp1);
@@ -181,9 +184,9 @@ SX_DEV void sx_vic_infiltration_b(float prcp, float cusl1, float cusl2, float b,
         iflm_b = iflm_b + (1.f - pwr1) * iflc_b;
         pwr1_b = -(iflm * iflc_b);
         if (pwx1 <= 0.0f && (pwy1 == 0.0f || pwy1 != (float)(int)pwy1)) pwx1_b = 0.f;
-        else pwx1_b = pwy1 * sx_powf(pwx1, pwy1 - 1.f) * pwr1_b;
+        else pwx1_b = pwy1 * sx_powb(B1, pwy1 - 1.f) * pwr1_b;
         if (pwx1 <= 0.0f) pwy1_b = 0.f;
-        else pwy1_b = sx_powf(pwx1, pwy1) * sx_logf(pwx1) * pwr1_b;
+        else pwy1_b = sx_powb(B1, pwy1) * sx_logb(B1) * pwr1_b;
         bp1_b = bp1_b + cusl * iflm_b - sx_fdiv(pwy1_b, bp1 * bp1);
         wusl_b = wusl_b - sx_fdiv(pwx1_b, cusl);
         cusl_b = cusl_b + sx_fdiv(wusl * pwx1_b, cusl * cusl) + bp1 * iflm_b;
@@ -354,11 +357,12 @@ struct SxVD { float v, d; };
 SX_DEV SxVD sx_vd(float v, float d) { SxVD x; x.v = v; x.d = d; return x; }
 
 SX_DEV float sx_powd_full(float x, float y, float x_d, float y_d, float& r) {   // d(x**y), both active: Tapenade's three cases
-    const float t = sx_powf(x, y);
+    const SxPowBase B = sx_powbase(x);
+    const float t = sx_powb(B, y);
     r = t;
     if (x <= 0.f && (y == 0.f || y != (float)(int)y)) return 0.f;
-    if (x <= 0.f) return y * sx_powf(x, y - 1.f) * x_d;
-    return y * sx_powf(x, y - 1.f) * x_d + t * sx_logf(x) * y_d;
+    if (x <= 0.f) return y * sx_powb(B, y - 1.f) * x_d;
+    return y * sx_powb(B, y - 1.f) * x_d + t * sx_logb(B) * y_d;
 }
 
 SX_DEV void sx_vic_infiltration_d(float prcp, SxVD cusl1, SxVD cusl2, SxVD b, SxVD& husl1, SxVD& husl2, SxVD& runoff) {

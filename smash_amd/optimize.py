@@ -129,13 +129,23 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
         sol = _solver_for(setup, mesh, input_data)
         sol.upload(parameters, states, par_bgd, sta_bgd)
 
+        device_pack = sol.control_size() == n       # control_to_var / var_to_control on the device (smashx_control_*)
+
         def fg(xc):
-            to_var(xc)
-            sol.upload(parameters, states, par_bgd, sta_bgd, only=moved)
-            sol.sweep(True, 1.0)
-            sol.download(True, None, None, output, par_b, sta_b, only_b=moved)
+            if device_pack:
+                # mw_optimize.f90:590-606 with the packing on the device: one contiguous fp64 vector goes up, the fields are
+                # unpacked, cast and denormalised there; cost + discharge and one contiguous gradient vector come back
+                sol.control_set(xc)
+                sol.sweep(True, 1.0)
+                sol.cost_and_qsim(output)
+                g = sol.control_gradient()
+            else:
+                to_var(xc)
+                sol.upload(parameters, states, par_bgd, sta_bgd, only=moved)
+                sol.sweep(True, 1.0)
+                sol.download(True, None, None, output, par_b, sta_b, only_b=moved)
+                g = to_control(par_b, sta_b)
             hist["nfg"] += 1
-            g = to_control(par_b, sta_b)
             last["f"], last["g"] = float(np.float32(output.cost)), g
             return last["f"], g
 

@@ -277,6 +277,35 @@ class Solver:
         _lib.check(_lib.lib().smashx_upload(self._h, C.byref(P), C.byref(PB) if PB is not None else None, C.byref(S),
                                             C.byref(SB) if SB is not None else None))
 
+    # -- control vector of the calibration, packed / unpacked on the device (mw_optimize.f90:679-777) ----------------------------
+    def control_size(self):
+        return int(_lib.lib().smashx_control_size(self._h))
+
+    def control_set(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        _lib.check(_lib.lib().smashx_control_set(self._h, _ptr(x)))
+
+    def control_get(self):
+        x = np.zeros(self.control_size(), np.float64)
+        _lib.check(_lib.lib().smashx_control_get(self._h, _ptr(x)))
+        return x
+
+    def control_gradient(self):
+        g = np.zeros(self.control_size(), np.float64)
+        _lib.check(_lib.lib().smashx_control_gradient(self._h, _ptr(g)))
+        return g
+
+    def cost_and_qsim(self, output):
+        """cost + discharge of the last sweep only (no field comes back)."""
+        qs = np.zeros((self.ng, self.nt), np.float32, order="F") if self.ng else None
+        costs = _lib.Costs()
+        _lib.check(_lib.lib().smashx_download(self._h, 0, None, None, _ptr(qs), C.byref(costs), None, None, None))
+        if output is not None:
+            if qs is not None:
+                output.qsim = qs
+            output.cost, output.cost_jobs, output.cost_jreg = float(costs.cost), float(costs.cost_jobs), float(costs.cost_jreg)
+        return float(costs.cost)
+
     def sweep(self, adjoint=False, cost_b=1.0):
         _lib.check(_lib.lib().smashx_sweep(self._h, int(bool(adjoint)), C.c_float(cost_b)))
 

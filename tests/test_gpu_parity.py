@@ -400,3 +400,66 @@ def test_forcing_written_in_place_is_not_served_from_the_cache():
     mesh.active_cell[r, c] = 0
     smash_amd.forward(setup, mesh, inp, par.copy(), inp._bgd[0], sta.copy(), inp._bgd[1], out, np.float32(0))
     assert inp._smashx_solver is not s1
+
+
+@pytest.mark.parametrize("name", ["gr_b_24x24x120_norm_jreg", "gr_c_32x32x240_d8_ragged"])
+def test_control_vector_on_the_device_equals_host_packing(name):
+    """smashx_control_set / smashx_control_gradient (control_to_var_lbfgsb / var_to_control_lbfgsb, mw_optimize.f90:679-777, on the
+    device) against the host path: fields scattered with numpy, uploaded, gradient fields downloaded and gathered.  Same cost, same
+    discharge, same gradient vector to the bit -- with a regulariser, on a masked D8 mesh, flagged fields the structure does not use."""
+    import smash_amd
+    g = gu.load(name)
+    g.opts = dict(g.opts)
+    g.opts["denormalize_forward"] = True
+    op = np.zeros(16, np.int32); op[[1, 3, 4, 6, 15]] = 1              # cp, cft, cst (unused by gr-b), exc, lr
+    os_ = np.zeros(8, np.int32); os_[[1, 7]] = 1                        # hp, hlr
+    g.opts["optim_parameters"], g.opts["optim_states"] = op, os_
+    setup, mesh, inp, par, sta, out = _types(g, chunk_steps=0)
+    o = setup.optimize
+    # the optimiser's space: normalised fields
+    for names, obj, lb, ub in ((synth.PARAM_NAMES, par, o.lb_parameters, o.ub_parameters), (synth.STATE_NAMES, sta, o.lb_states, o.ub_states)):
+        for i, k in enumerate(names):
+            setattr(obj, k, np.asfortranarray(((getattr(obj, k) - np.float32(lb[i])) / (np.float32(ub[i]) - np.float32(lb[i]))).astype(np.float32)))
+    bgd_p, bgd_s = (par.copy(), sta.copy()) if "params_bgd" not in g.opts else inp._bgd
+    sol = inp._smashx_solver
+    if mesh.ng:
+        sol.set_qobs(inp.qobs)
+    sol.set_options(o)
+    act = (np.asarray(mesh.active_cell) == 1).reshape(-1, order="F")
+    m = int(act.sum())
+    pf = [k for i, k in enumerate(synth.PARAM_NAMES) if op[i]]
+    sf = [k for i, k in enumerate(synth.STATE_NAMES) if os_[i]]
+    assert sol.control_size() == m * (len(pf) + len(sf))
+    rng = np.random.default_rng(5)
+    x = np.clip(np.concatenate([getattr(par, k).reshape(-1, order="F")[act] for k in pf] +
+                               [getattr(sta, k).reshape(-1, order="F")[act] for k in sf]).astype(np.float64)
+                + rng.normal(0, 0.01, m * (len(pf) + len(sf))), 0.0, 1.0)
+    # host path
+    p2, s2 = par.copy(), sta.copy()
+    for j, k in enumerate(pf):
+        a = getattr(p2, k).reshape(-1, order="F").copy(); a[act] = x[j * m:(j + 1) * m]
+        setattr(p2, k, np.asfortranarray(a.reshape(mesh.nrow, mesh.ncol, order="F").astype(np.float32)))
+    for j, k in enumerate(sf):
+        a = getattr(s2, k).reshape(-1, order="F").copy(); a[act] = x[(len(pf) + j) * m:(len(pf) + j + 1) * m]
+        setattr(s2, k, np.asfortranarray(a.reshape(mesh.nrow, mesh.ncol, order="F").astype(np.float32)))
+    pb, sb = par.copy(), sta.copy()
+    o1 = smash_amd.OutputDT(setup, mesh)
+    sol.upload(p2, s2, bgd_p, bgd_s)
+    sol.sweep(True, 1.0)
+    sol.download(True, None, None, o1, pb, sb)
+    g_host = np.concatenate([getattr(pb, k).reshape(-1, order="F")[act].astype(np.float64) for k in pf] +
+                            [getattr(sb, k).reshape(-1, order="F")[act].astype(np.float64) for k in sf])
+    # device path: the un-perturbed fields go up once, then only the control vector moves
+    o2 = smash_amd.OutputDT(setup, mesh)
+    sol.upload(par, sta, bgd_p, bgd_s)
+    sol.control_set(x)
+    sol.sweep(True, 1.0)
+    sol.cost_and_qsim(o2)
+    g_dev = sol.control_gradient()
+    assert o1.cost == o2.cost and np.array_equal(o1.qsim, o2.qsim)
+    assert np.array_equal(g_host, g_dev)
+    # var_to_control of what the device holds: the normalise(denormalise(x)) round trip, x to fp32 accuracy
+    assert np.allclose(sol.control_get(), np.concatenate(
+        [(getattr(p2, k).reshape(-1, order="F")[act].astype(np.float64) if k in gu.STRUCT_PARAMS[g.structure] else np.zeros(m)) for k in pf] +
+        [(getattr(s2, k).reshape(-1, order="F")[act].astype(np.float64) if k in gu.STRUCT_STATES[g.structure] else np.zeros(m)) for k in sf]),
+        rtol=2e-6, atol=2e-7)
