@@ -163,8 +163,7 @@ __global__ void k_control_set(float* cellv, float* full, float* jx, const double
     if (k >= n) return;
     const float v = (float)x[off + pos[k]];
     const float d = denorm ? v * (ub - lb) + lb : v;
-    cellv[k] = d;
-    full[flat[k]] = d;
+    if (cellv) { cellv[k] = d; full[flat[k]] = d; }       // null: a flagged field the structure does not read (only the regulariser sees it)
     if (jx) jx[flat[k]] = denorm ? (d - lb) / (ub - lb) : v;
 }
 // var_to_control (grad = 0): the optimiser-space value of the field; gradient (grad = 1): cell gradient x (ub - lb) under
@@ -1729,10 +1728,10 @@ int smashx_control_set(smashx_plan* p, const double* x) {
     const dim3 b(256), gk((p->n + 255) / 256);
     for (int j = 0; j < nf; ++j) {
         const CtrlField F = ctrl_field(p, idx[j], false);
-        if (!F.used) continue;                       // flagged but not read by this structure: the reference carries it along, the sweep ignores it
         float* jx = (p->opt.njr > 0 && p->d_jx[idx[j]]) ? p->d_jx[idx[j]] : nullptr;
-        hipLaunchKernelGGL(k_control_set, gk, b, 0, p->stream, F.cellv, F.full, jx, p->d_ctrl, p->d_ctrl_pos, p->d_cell_flat, p->n,
-                           (long)j * p->n, F.lb, F.ub, p->opt.denormalize_forward);
+        if (!F.used && !jx) continue;                // flagged but read by nothing: the reference carries it along, nothing here depends on it
+        hipLaunchKernelGGL(k_control_set, gk, b, 0, p->stream, F.used ? F.cellv : nullptr, F.full, jx, p->d_ctrl, p->d_ctrl_pos, p->d_cell_flat,
+                           p->n, (long)j * p->n, F.lb, F.ub, p->opt.denormalize_forward);
     }
     hipLaunchKernelGGL(sx_k_prep_routing, gk, b, 0, p->stream, p->A);
     HIPCHK(hipStreamSynchronize(p->stream));
@@ -1753,7 +1752,15 @@ static int control_read(smashx_plan* p, double* x, int grad) {
     const dim3 b(256), gk((p->n + 255) / 256);
     for (int j = 0; j < nf; ++j) {
         const CtrlField F = ctrl_field(p, idx[j], grad != 0);
-        if (!F.used) continue;
+        if (!F.used) {
+            // a flagged field the structure does not read: only the regulariser knows it -- its plane (already in the optimiser's
+            // space) or its gradient plane (COMPUTE_JREG_B, scaled like the download scales it)
+            const float* plane = p->opt.njr > 0 ? (grad ? p->d_jg[idx[j]] : p->d_jx[idx[j]]) : nullptr;
+            if (!plane) continue;
+            hipLaunchKernelGGL(k_control_get, gk, b, 0, p->stream, p->d_ctrl, plane, p->d_ctrl_pos, p->d_cell_flat, p->n, (long)j * p->n,
+                               F.lb, F.ub, grad ? p->opt.denormalize_forward : 0, grad, 1);
+            continue;
+        }
         hipLaunchKernelGGL(k_control_get, gk, b, 0, p->stream, p->d_ctrl, F.cellv, p->d_ctrl_pos, p->d_cell_flat, p->n, (long)j * p->n,
                            F.lb, F.ub, p->opt.denormalize_forward, grad, 0);
     }
