@@ -81,6 +81,7 @@ def parse(argv=None):
     ap.add_argument("--trace-groups", default="", help="diagnostics: write per-round start/end times of the routing groups (JSON) here")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the 2048 x 2048 measurement attached to the line")
+    ap.add_argument("--no-exact", action="store_true", help="N = 1: skip the run of the exact-libm build attached to the line")
     ap.add_argument("--secondary-grid", type=int, default=2048)
     ap.add_argument("--cpu-grid", type=int, default=256)
     ap.add_argument("--cpu-nt", type=int, default=360)
@@ -491,6 +492,27 @@ def main():
             c2.close()
         except Exception as e:  # pragma: no cover
             line["secondary"] = {"workload": f"{g}x{g}", "value": None, "error": str(e)}
+    # N = 1: the same workload on the exact-libm build (libsmashx_exact.so: bit-identical to the reference on every golden vector),
+    # in a child process -- the library is chosen when smash_amd is imported
+    if (world == 1 and not solo and not a.no_exact and line is not None and (trows, tcols) == (1024, 1024) and nt == 8760
+            and os.environ.get("SMASHX_EXACT_LIBM", "0") in ("", "0") and os.path.exists(os.path.join(ROOT, "smash_amd", "libsmashx_exact.so"))):
+        import subprocess
+        if "case" in locals():                       # the child needs the HBM this process still holds
+            case.close()
+            del case, sol
+        torch.cuda.empty_cache()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary",
+                                "--no-exact", "--structure", a.structure], env=dict(os.environ, SMASHX_EXACT_LIBM="1"), capture_output=True,
+                               text=True, timeout=600)
+            e = json.loads(r.stdout.strip().splitlines()[-1])
+            line["exact_libm"] = {"what": "same workload on libsmashx_exact.so (-DSX_EXACT_LIBM=1: glibc 2.35 expf/logf/powf/tanhf restated, IEEE divisions): "
+                                          "bit-identical to the reference Fortran on all 318 golden outputs (profiles/r2_parity_exact.md); the "
+                                          "default build differs from it by libm rounding only (profiles/r2_parity_default.md)",
+                                  "value": e["value"], "ms_per_step": e["ms_per_step"], "steps": 2, "warmup": 1, "cost": e["cost"],
+                                  "kernel_ms_per_step": e["kernel_ms_per_step"]}
+        except Exception as ex:  # pragma: no cover
+            line["exact_libm"] = {"value": None, "error": str(ex)}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

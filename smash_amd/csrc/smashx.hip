@@ -304,6 +304,7 @@ struct smashx_plan {
     int chain_from = 1;              // first chained round
     bool split_v = false;            // SMASHX_SPLIT_V=1: vertical kernels in two cell ranges so that routing round 0 overlaps the second.
                                      // Measured slower (185 vs 175 ms at 1024^2 x 8760: both kernels lose more than the overlap hides): off.
+    size_t debug_vlds = 0;           // SMASHX_DEBUG_VLDS: bytes of unused dynamic LDS per vertical workgroup (occupancy experiments)
     int n0 = 0;                      // cells of the round-0 groups = [0, n0) in device order
     std::vector<double> round_ncells;  // cells per routing round
     bool chain_used = false;         // a chained launch ran in the current sweep: check the stall flag afterwards
@@ -518,10 +519,11 @@ void launch_vert_fwd(smashx_plan* p, const SxDeviceArrays& B, bool tape, int t0,
     const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
     p->mark_begin(0, p->stream, (double)(B.k1 - B.k0) * T);
     const bool cf = B.prcp16 != nullptr;
-    if (tape) { if (cf) hipLaunchKernelGGL((sx_k_vert_fwd<ST, true, true>), grid, block, 0, p->stream, B, t0, T);
-                else    hipLaunchKernelGGL((sx_k_vert_fwd<ST, true, false>), grid, block, 0, p->stream, B, t0, T); }
-    else      { if (cf) hipLaunchKernelGGL((sx_k_vert_fwd<ST, false, true>), grid, block, 0, p->stream, B, t0, T);
-                else    hipLaunchKernelGGL((sx_k_vert_fwd<ST, false, false>), grid, block, 0, p->stream, B, t0, T); }
+    const size_t vl = p->debug_vlds;     // diagnostics: unused dynamic LDS that caps the resident waves (SMASHX_DEBUG_VLDS)
+    if (tape) { if (cf) hipLaunchKernelGGL((sx_k_vert_fwd<ST, true, true>), grid, block, vl, p->stream, B, t0, T);
+                else    hipLaunchKernelGGL((sx_k_vert_fwd<ST, true, false>), grid, block, vl, p->stream, B, t0, T); }
+    else      { if (cf) hipLaunchKernelGGL((sx_k_vert_fwd<ST, false, true>), grid, block, vl, p->stream, B, t0, T);
+                else    hipLaunchKernelGGL((sx_k_vert_fwd<ST, false, false>), grid, block, vl, p->stream, B, t0, T); }
     p->mark_end();
 }
 void vert_fwd(smashx_plan* p, int off, bool tape, int t0, int T, int k0 = 0, int k1 = -1) {
@@ -552,8 +554,9 @@ void vert_adj(smashx_plan* p, int off, int t0, int T, int k0 = 0, int k1 = -1) {
     const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
     p->mark_begin(3, p->stream, (double)(B.k1 - B.k0) * T);
     const bool cf = B.prcp16 != nullptr;
-#define SX_VADJ(ST) do { if (cf) hipLaunchKernelGGL((sx_k_vert_adj<ST, true>), grid, block, 0, p->stream, B, t0, T); \
-                         else hipLaunchKernelGGL((sx_k_vert_adj<ST, false>), grid, block, 0, p->stream, B, t0, T); } while (0)
+    const size_t vl = p->debug_vlds;
+#define SX_VADJ(ST) do { if (cf) hipLaunchKernelGGL((sx_k_vert_adj<ST, true>), grid, block, vl, p->stream, B, t0, T); \
+                         else hipLaunchKernelGGL((sx_k_vert_adj<ST, false>), grid, block, vl, p->stream, B, t0, T); } while (0)
     switch (p->st) {
         case 1: SX_VADJ(1); break;
         case 2: SX_VADJ(2); break;
@@ -735,6 +738,7 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         A.ngroups = p->sch.ngroups;
         const char* e = getenv("SMASHX_CHAIN_ROUNDS");
         p->chain = !(e && e[0] == '0');
+        if (const char* dv = getenv("SMASHX_DEBUG_VLDS")) p->debug_vlds = (size_t)std::max(0, atoi(dv));
         const char* sv = getenv("SMASHX_SPLIT_V");
         p->split_v = sv && sv[0] == '1';
         p->round_ncells.assign(p->sch.nrounds, 0.0);

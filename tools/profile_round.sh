@@ -20,5 +20,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_
   i=$((i+1))
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $raw/pmc$i -- python3 bench.py "$@" --no-cpu-baseline > $raw/pmc$i.log 2>&1 || echo "pmc group $i failed" >> $out/${tag}_errors.log
 done
-python3 tools/pmc_summary.py $raw > $out/${tag}_pmc.txt 2>&1
 grep -h "^{" $out/${tag}_stats_run.log | tail -1 > $out/${tag}_bench_under_rocprof.json
+cs=$(python3 -c "import json,sys; d=json.load(open('$out/${tag}_bench_under_rocprof.json')); print(d['config']['active_cells']*d['config']['nt'])" 2>/dev/null || echo 0)
+python3 tools/pmc_summary.py $raw --json $out/${tag}_pmc_traffic.json --cellsteps $cs --command "rocprofv3 --kernel-trace --pmc <group> (separate passes: FETCH_SIZE | WRITE_SIZE | SQ_*) -- python3 bench.py $* --no-cpu-baseline (tools/profile_round.sh)" > $out/${tag}_pmc.txt 2>&1
