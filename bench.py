@@ -34,7 +34,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-N_SIMD, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; a wave64 VALU instruction holds its SIMD for 4 cycles
+N_SIMD, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs
+VALU_CYCLES = 2.0                # a wave64 fp32 instruction on the 32-lane SIMD when another wave is ready (MI355X_MICROARCH.md "Per-instruction
+                                 # cycle constants"; one wave alone issues every 4 cycles; fp64 4, transcendentals 8: the true ceiling is lower)
 KERNELS = ("vert_fwd", "route_fwd", "route_adj", "vert_adj")
 
 
@@ -336,10 +338,13 @@ def roofline(tm, adjoint, structure):
          "algorithmic_bytes_per_launch": alg_bytes,
          "sweep_frac": (16.0 if adjoint else 8.0) * tm["vert_adj_cellsteps" if adjoint else "vert_fwd_cellsteps"] / (tm["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if pk and "valu_per_cellstep" in pk:
-        issue_ms = pk["valu_per_cellstep"] * cs_launch / 64.0 * 4.0 / (N_SIMD * CLOCK_HZ) * 1e3
+        issue_ms = pk["valu_per_cellstep"] * cs_launch / 64.0 * VALU_CYCLES / (N_SIMD * CLOCK_HZ) * 1e3
         r["valu"] = {"instr_per_cellstep": pk["valu_per_cellstep"], "issue_bound_ms": issue_ms, "frac": issue_ms / avg_ms,
-                     "note": "SQ_INSTS_VALU per cell-step x 4 cycles per wave64 instruction on 1024 SIMDs at 2.4 GHz; frac = share of the "
-                             "launch time the VALU is issuing: this ceiling, not HBM, binds the reverse kernel"}
+                     "wave_cycles_share": pk.get("wave_cycles_share"),
+                     "note": "SQ_INSTS_VALU per cell-step (committed PMC pass) x 2 cycles per wave64 fp32 instruction on 1024 SIMDs at 2.4 GHz "
+                             "= the time the vector units need at their fp32 peak rate; frac = that time / the launch time.  fp64 and "
+                             "transcendental instructions (a fifth of the mix) take 4 and 8 cycles: this ceiling, not HBM, is the one the "
+                             "reverse kernel runs against"}
     return r
 
 
