@@ -141,6 +141,29 @@ module smashx_c
         end function
     end interface
 
+    !  include/smashx.h smashx_forcing_layout: lossless compact residency of the forcing
+    type, bind(C) :: smashx_forcing_layout
+        integer(c_int) :: compact
+        real(c_float) :: prcp_factor
+        real(c_float) :: pet_ratio(24)
+        integer(c_int) :: pet_hour0
+    end type smashx_forcing_layout
+
+    interface
+        function smashx_set_forcing_layout(plan, layout) bind(C, name="smashx_set_forcing_layout") result(rc)
+            import
+            type(c_ptr), value :: plan
+            type(smashx_forcing_layout) :: layout
+            integer(c_int) :: rc
+        end function smashx_set_forcing_layout
+    end interface
+
+    !  hourly share of the daily PET in the reference's reader (smash/core/_constant.py:47-75)
+    real(c_float), parameter :: sx_ratio_pet_hourly(24) = [0._c_float, 0._c_float, 0._c_float, 0._c_float, 0._c_float, 0._c_float, &
+    & 0._c_float, 0.035_c_float, 0.062_c_float, 0.079_c_float, 0.097_c_float, 0.11_c_float, 0.117_c_float, 0.117_c_float, &
+    & 0.11_c_float, 0.097_c_float, 0.079_c_float, 0.062_c_float, 0.035_c_float, 0._c_float, 0._c_float, 0._c_float, 0._c_float, &
+    & 0._c_float]
+
     !  one cached plan (the reference calls forward/forward_b many times on the same setup/mesh/input_data)
     type(c_ptr), save :: sx_plan = c_null_ptr
     logical, save :: sx_abi_checked = .false.
@@ -151,8 +174,24 @@ module smashx_c
     !  at the freed address with the same shape, must not be served the old forcing or mesh)
     real(c_float), save :: sx_key_dt = -1._c_float, sx_key_dx = -1._c_float
     integer(c_long), save :: sx_key_mesh = -1_c_long, sx_key_force = -1_c_long
+    integer, save :: sx_key_layout = -1          ! compact forcing requested (hour0 + 1) or not (0)
 
 contains
+
+    !  hour of setup%start_time ("%Y%m%d%H%M", mwd_setup.f90:11, or "YYYY-MM-DD HH:MM" as the user guide writes it): digits 9-10
+    integer function sx_start_hour(stamp) result(hh)
+        character(len=*), intent(in) :: stamp
+        integer :: i, nd, d(12)
+        nd = 0
+        do i = 1, len_trim(stamp)
+            if (stamp(i:i) .ge. "0" .and. stamp(i:i) .le. "9" .and. nd .lt. 12) then
+                nd = nd + 1
+                d(nd) = iachar(stamp(i:i)) - iachar("0")
+            end if
+        end do
+        hh = 0
+        if (nd .ge. 10) hh = mod(10*d(9) + d(10), 24)
+    end function sx_start_hour
 
     !  order-sensitive hash of n 32-bit words taken every `step` (h stays below 2**31, the products below 2**51: no overflow)
     function sx_hash_words(a, n, step, h0) result(h)
@@ -251,7 +290,8 @@ subroutine smashx_prepare(setup, mesh, input_data, plain)
     integer(c_int), allocatable, target, save :: path0(:, :), gpos0(:, :)
     real(c_float), allocatable, target, save :: wg(:)
     type(c_ptr) :: fkey
-    integer :: key(6), j
+    integer :: key(6), j, want_layout
+    type(smashx_forcing_layout) :: lay
     integer(c_long) :: n2, nf, hmesh, hforce
     integer(c_int), pointer :: wp(:), we(:)
     integer(c_int) :: abi(7), ver
@@ -298,6 +338,14 @@ subroutine smashx_prepare(setup, mesh, input_data, plain)
     hforce = sx_hash_words(wp, nf, max(1_c_long, nf/65536_c_long), 11_c_long)
     hforce = sx_hash_words(we, nf, max(1_c_long, nf/65536_c_long), hforce)
 
+    want_layout = 0
+    if (setup%daily_interannual_pet .and. abs(setup%dt - 3600._sp) .lt. 0.5_sp .and. setup%prcp_conversion_factor .gt. 0._sp) &
+    &   want_layout = 1 + mod(sx_start_hour(setup%start_time) + 1, 24)
+    if (want_layout .ne. sx_key_layout .and. c_associated(sx_plan)) then
+        call sx_check(smashx_plan_destroy(sx_plan), "plan_destroy")
+        sx_plan = c_null_ptr
+    end if
+
     if (c_associated(sx_plan) .and. c_associated(fkey, sx_key_forcing) .and. all(key .eq. sx_key) .and. setup%dt .eq. sx_key_dt &
     &   .and. mesh%dx .eq. sx_key_dx .and. hmesh .eq. sx_key_mesh .and. hforce .ne. sx_key_force) then
         !  same plan, new forcing values (written in place): only the forcing goes up again
@@ -328,6 +376,16 @@ subroutine smashx_prepare(setup, mesh, input_data, plain)
         cm%area = c_null_ptr
         if (mesh%ng .gt. 0) cm%area = c_loc(mesh%area)
         call sx_check(smashx_plan_create(cfg, cm, sx_plan), "plan_create")
+        !  A Model whose PET came from the daily inter-annual reader (setup%daily_interannual_pet, hourly steps) holds forcing the
+        !  plan can keep in 2.17 instead of 8 bytes per cell-step: rain counts x prcp_conversion_factor, daily PET x RATIO_PET_HOURLY.
+        !  The library verifies every value bit for bit and keeps fp32 rows by itself when the data is not of that form.
+        if (want_layout .gt. 0) then
+            lay%compact = 1
+            lay%prcp_factor = setup%prcp_conversion_factor
+            lay%pet_ratio = sx_ratio_pet_hourly
+            lay%pet_hour0 = want_layout - 1                                   ! the first step is start_time + dt
+            call sx_check(smashx_set_forcing_layout(sx_plan, lay), "set_forcing_layout")
+        end if
         if (setup%sparse_storage) then
             call sx_check(smashx_set_forcing(sx_plan, c_loc(input_data%sparse_prcp), c_loc(input_data%sparse_pet), 1_c_int), &
             & "set_forcing")
@@ -336,7 +394,7 @@ subroutine smashx_prepare(setup, mesh, input_data, plain)
         end if
         sx_key_forcing = fkey
         sx_key = key
-        sx_key_dt = setup%dt; sx_key_dx = mesh%dx; sx_key_mesh = hmesh; sx_key_force = hforce
+        sx_key_dt = setup%dt; sx_key_dx = mesh%dx; sx_key_mesh = hmesh; sx_key_force = hforce; sx_key_layout = want_layout
     end if
 
     if (mesh%ng .gt. 0) call sx_check(smashx_set_qobs(sx_plan, c_loc(input_data%qobs)), "set_qobs")

@@ -63,7 +63,7 @@ contains
     !           4 = hyper_forward, 5 = hyper_forward_b, 6 = hyper_forward_d (mw_forward.f90:99-181; entry point
     !           ref_run_hyper only; mode 6 reads the direction from hyper_p_b / hyper_s_b)
     !           7 = optimize_sbs (mw_optimize.f90:53-294), maxiter in icfg(13)
-    !  icfg(14) nd (descriptors)   icfg(15) mapping: 1 hyper-linear, 2 hyper-polynomial
+    !  icfg(14) nd (descriptors)   icfg(15) mapping: 1 hyper-linear, 2 hyper-polynomial   icfg(16) reader-form forcing (see below)
     !  icfg(12) nrep (timing repetitions, >=1)     icfg(13) maxiter (mode 2)
     !  rcfg(1) dt  rcfg(2) dx  rcfg(3) wjreg  rcfg(4) cost_b
     !  Arrays are column-major exactly as the reference holds them; path and gauge_pos are 1-based.
@@ -135,6 +135,13 @@ contains
         end select
         setup%dt = rcfg(1)
         setup%sparse_storage = (icfg(6) .ne. 0)
+        !  icfg(16) = 1: the forcing was formed the way the reference's reader forms it (_read_input_data.py:176-283): rain = raster
+        !  count x 0.1, PET = daily x RATIO_PET_HOURLY, run starting at midnight -- the setup fields a Model built from such data carries
+        if (icfg(16) .ne. 0) then
+            setup%prcp_conversion_factor = 0.1_c_float
+            setup%daily_interannual_pet = .true.
+            setup%start_time = "201409150000"
+        end if
         setup%ntime_step = nt
         call SetupDT_initialise(setup, icfg(14), ng)
         if (icfg(15) .eq. 1) then

@@ -70,7 +70,7 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         lb_states=None, ub_states=None, cost_b=1.0, nrep=1, fast=False, optimize_maxiter=None,
         params_d=None, states_d=None, params_bgd_d=None, states_bgd_d=None,
         descriptor=None, hyper_params=None, hyper_states=None, mapping=None, hyper_params_d=None, hyper_states_d=None,
-        optimize_sbs_maxiter=None):
+        optimize_sbs_maxiter=None, reader_form=False):
     """Call the reference forward / forward_b (mw_forward.f90:18-68) on flat arrays.
 
     mesh: object with nrow, ncol, dx, flwdir, flwacc, path (0-based), active_cell, gauge_pos (0-based),
@@ -99,7 +99,7 @@ def run(structure, mesh, dt, prcp, pet, qobs, params, states, *, adjoint=False, 
         mcode = {"hyper-linear": 1, "hyper-polynomial": 2}[mapping]
     icfg = np.array([STRUCTURES[structure], nrow, ncol, nt, ng, int(sparse_storage),
                      int(denormalize_forward), optimize_start_step, len(jobs_fun), len(jreg_fun),
-                     mode, nrep, optimize_maxiter or 0, nd, mcode, 0], dtype=np.int32)
+                     mode, nrep, optimize_maxiter or 0, nd, mcode, int(bool(reader_form))], dtype=np.int32)
     rcfg = np.array([dt, mesh.dx, wjreg, cost_b], dtype=np.float32)
     P = pack(params, PARAM_NAMES, nrow, ncol)
     S = pack(states, STATE_NAMES, nrow, ncol)

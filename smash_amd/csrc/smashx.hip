@@ -980,6 +980,9 @@ int smashx_set_forcing(smashx_plan* p, const float* prcp, const float* pet, int 
         break;
     }
     p->have_forcing = true;
+    if (getenv("SMASHX_VERBOSE"))
+        fprintf(stderr, "smashx: forcing resident as %s (%.2f GB for %d cells x %d steps)\n", p->d_prcp16 ? "compact uint16 rain counts + daily PET" : "fp32 rows",
+                (p->d_prcp16 ? 2.0 * p->nt + 4.0 * p->ndays : 8.0 * p->nt) * p->npad * 1e-9, p->n, p->nt);
     return 0;
 }
 

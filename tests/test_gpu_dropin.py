@@ -198,3 +198,39 @@ def test_dropin_does_not_serve_stale_forcing_or_mesh():
     refc = refbind.run(g.structure, g.mesh, 1800.0, wet, g.pet, g.qobs, g.params, g.states, **g.opts)
     for i in range(g.mesh.ng):
         assert gu.rel_l2(c["qsim"][i], refc["qsim"][i]) <= 1e-5
+
+
+def test_dropin_keeps_reader_form_forcing_compact(capfd, monkeypatch):
+    """A Model whose forcing came from the reference's reader with daily inter-annual PET (setup%daily_interannual_pet, hourly steps,
+    prcp_conversion_factor) reaches the shim with setup fields that say so; the shim then asks the library for the lossless compact
+    layout (rain counts x factor, daily PET x RATIO_PET_HOURLY).  Same discharge and gradients as without it; and forcing that is NOT
+    of that form (the synthetic generator's own diurnal weights) silently stays in fp32 rows with the same results."""
+    from smash_amd.solver import RATIO_PET_HOURLY as R
+    monkeypatch.setenv("SMASHX_VERBOSE", "1")
+    g = gu.load("gr_b_16x16x96_nse_gaps")
+    # put the fixture's PET on the reader's form: daily value x RATIO_PET_HOURLY, first step = 01:00
+    pet = g.pet.copy(order="F")
+    for d in range((g.nt + 1 + 23) // 24):
+        ts = list(range(max(0, d * 24 - 1), min(g.nt, (d + 1) * 24 - 1)))
+        daily = np.float32(1.0) + pet[:, :, ts].max(axis=2) * np.float32(8.0)
+        for t in ts:
+            pet[:, :, t] = daily * R[(t + 1) % 24]
+    ref = refbind.run(g.structure, g.mesh, g.dt, g.prcp, pet, g.qobs, g.params, g.states, adjoint=True, **g.opts)      # all-CPU reference
+    capfd.readouterr()
+    for form in (True, False):
+        b = refbind.run(g.structure, g.mesh, g.dt, g.prcp, pet, g.qobs, g.params, g.states, adjoint=True, fast="dropin", reader_form=form, **g.opts)
+        err = capfd.readouterr().err
+        assert ("forcing resident as compact" in err) == form and ("forcing resident as fp32 rows" in err) == (not form), err
+        for i in range(g.mesh.ng):
+            assert gu.rel_l2(b["qsim"][i], ref["qsim"][i]) <= 1e-5
+        for k in gu.STRUCT_PARAMS[g.structure]:
+            assert gu.rel_l2(b["parameters_b"][k], ref["parameters_b"][k]) <= 1e-4, k
+        if form:
+            keep = b
+        else:
+            assert np.array_equal(keep["qsim"], b["qsim"]) and all(np.array_equal(keep["parameters_b"][k], b["parameters_b"][k]) for k in gu.STRUCT_PARAMS[g.structure])
+    # reader-form flags on forcing that is not of the form: falls back, results as ever
+    c = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, fast="dropin", reader_form=True, **g.opts)
+    assert "forcing resident as fp32 rows" in capfd.readouterr().err
+    for i in range(g.mesh.ng):
+        assert gu.rel_l2(c["qsim"][i], g.fwd["qsim"][i]) <= gu.tol(g.noise["qsim"][i])
