@@ -1,0 +1,53 @@
+"""CPU: the parts of bench.py that need no GPU -- the chunk plan every rank of a decomposition must agree on, the roofline
+arithmetic, and the self-launch of N ranks (`python bench.py --gpus 2 --backend gloo` with no launcher): both ranks start as
+fresh children, complete the host-side rendezvous, and then stop loudly because there is no HIP device (libsmashx has no CPU path)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def test_chunk_plan_is_a_function_of_shared_quantities_only():
+    import bench
+    hbm = 309e9                                                    # 288 GiB card
+    cells = 2048 * 1024
+    # the metric's tile: compact forcing 40 GB -> two storage chunks; fp32 rows 147 GB -> four
+    c = bench.chunk_plan(8760, cells, hbm, cells * 8760 * (2 + 4 / 24), "gr-b")
+    assert c % 16 == 0 and -(-8760 // c) == 2
+    r = bench.chunk_plan(8760, cells, hbm, cells * 8760 * 8.0, "gr-b")
+    assert r % 16 == 0 and -(-8760 // r) == 4
+    # the 1024^2 tile stays store-all; a forced length is taken as is; more taped levels (gr-c) never lengthen a chunk
+    assert bench.chunk_plan(8760, 1024 * 1024, hbm, 1024 * 1024 * 8760 * 2.17, "gr-b") >= 8760
+    assert bench.chunk_plan(8760, cells, hbm, 0.0, "gr-b", forced=1104) == 1104
+    assert bench.chunk_plan(8760, cells, hbm, 40e9, "gr-c") <= c
+
+
+def test_roofline_uses_the_cell_steps_one_launch_processes():
+    """Sub-chunked launches are shorter than the period: the per-launch figures must come from the cell-step counters of the
+    launches themselves (the roofline of a 4-rank rehearsal was 8x too high)."""
+    import bench
+    cs = 1024.0 * 1024 * 8760
+    tm = {"vert_fwd_ms": 40.0, "route_fwd_ms": 25.0, "route_adj_ms": 28.0, "vert_adj_ms": 72.0, "sweep_ms": 170.0,
+          "vert_fwd_launches": 8, "route_fwd_launches": 16, "route_adj_launches": 16, "vert_adj_launches": 8,
+          "vert_fwd_cellsteps": cs, "route_fwd_cellsteps": cs, "route_adj_cellsteps": cs, "vert_adj_cellsteps": cs}
+    r = bench.roofline(tm, True, "gr-b")
+    assert r["kernel"] == "sx_k_vert_adj" and r["launches_per_step"] == 8
+    assert abs(r["cellsteps_per_launch"] - cs / 8) < 1 and abs(r["algorithmic_bytes_per_launch"] - 8 * cs / 8) < 8
+    assert abs(r["achieved"] - 8 * cs / 72e-3 / 1e9) < 1e-6 * r["achieved"]          # same GB/s as one whole-period launch of 72 ms
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    if "valu" in r:
+        assert 0 < r["valu"]["frac"] < 1.5
+
+
+def test_bench_self_launch_reaches_the_rendezvous_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a HIP device is present (tests/test_gpu_rccl.py covers the real run)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-cpu-baseline",
+                        "--tile-rows", "32", "--tile-cols", "32", "--nt", "48"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    assert r.stderr.count("handshake ok (gloo)") == 2 and "rank 0/2" in r.stderr and "rank 1/2" in r.stderr
+    assert "no HIP device" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())     # (gloo prints a banner on stdout)
