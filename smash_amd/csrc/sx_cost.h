@@ -58,6 +58,7 @@ __device__ __forceinline__ float sx_qo(const SxCostArgs& C, int g, int t) {
 
 // one wavefront per gauge
 __global__ __launch_bounds__(64) void sx_k_cost_sums(SxCostArgs C) {
+    SX_LIBM_INIT();
     const int g = blockIdx.x, lane = threadIdx.x;
     SxGaugeSums S; S.n = 0; S.sum_x = S.sum_y = S.sum_xx = S.sum_yy = S.sum_xy = S.se = S.lg = 0.f;
     const float w = C.wgauge[g];
@@ -239,6 +240,7 @@ __global__ void sx_k_cost_final(SxCostArgs C, int adjoint) {
 
 // parallel over (gauge, t): qsim_b(g,t)  (forward_db.f90:2709-2712)
 __global__ void sx_k_cost_seeds(SxCostArgs C) {
+    SX_LIBM_INIT();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int g = blockIdx.y;
     if (t >= C.nt) return;
@@ -305,6 +307,7 @@ __device__ inline void sx_heap_sort_pair(int n, float* arr, float* arr_d) {
 }
 
 __global__ void sx_k_cost_tangent(SxCostArgs C, const float* qgd, float* out) {
+    SX_LIBM_INIT();
     float* gj = C.med; float* gjd = C.med + C.ng;     // gauge_jobs, gauge_jobs_d
     for (int g = threadIdx.x; g < C.ng; g += blockDim.x) {
         gj[g] = 0.f; gjd[g] = 0.f;

@@ -174,6 +174,7 @@ struct SxDeviceArrays {
 // forward_db.f90:6643-6648; UPSTREAM_DISCHARGE_B :6551)
 // ------------------------------------------------------------------------------------------------
 __global__ void sx_k_prep_routing(SxDeviceArrays A) {
+    SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= A.n) return;
     const float lr = A.lr[k];
@@ -283,6 +284,7 @@ __device__ __forceinline__ void sx_forcing_at(const SxDeviceArrays& A, int t, un
 // ------------------------------------------------------------------------------------------------
 template <int ST, bool TAPE, bool CF>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
+    SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;
@@ -350,6 +352,7 @@ __device__ __forceinline__ SxVicParams sx_vic_load(const SxDeviceArrays& A, int 
 // of the tapes, qt as one float4 per four steps; the reverse kernel prefetches the three taped levels and qt_b a step ahead.
 template <bool TAPE, bool CF>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A, int t0, int T) {
+    SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;
@@ -383,6 +386,7 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A,
 
 template <bool CF>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A, int t0, int T) {
+    SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A,
 
 // vic-a with tangents (VIC_A_FORWARD_D): tangents of the parameters / levels live in the gradient arrays
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic_d(SxDeviceArrays A, int t0, int T) {
+    SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;
     if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;
@@ -446,6 +451,7 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic_d(SxDeviceArrays 
 // ------------------------------------------------------------------------------------------------
 template <int ST>
 __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, int t0, int T) {
+    SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;
@@ -890,6 +896,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
 #endif
 template <int ST, bool CF>
 __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
+    SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
     const size_t npad = (size_t)A.npad;

@@ -78,13 +78,16 @@ SX_HD float sx_seed_sqrt(float x) {
 struct SxDiv { float d, r; };
 SX_HD SxDiv sx_mkdiv(float d) { SxDiv D; D.d = d; D.r = 1.0f / d; return D; }
 SX_HD float sx_div(float a, const SxDiv& D) {
-#if SX_EXACT_LIBM
-    return a / D.d;
-#else
     const float q = a * D.r;
     const float e = fmaf(-D.d, q, a);
-    return fmaf(e, D.r, q);
+    const float q2 = fmaf(e, D.r, q);
+#if SX_EXACT_LIBM
+    // the theorem needs the residual to be exact: outside the comfortable exponent range (tiny quotients on their way to the
+    // subnormals, huge ones) the exact build takes the IEEE division
+    const float m = fabsf(q2);
+    if (!(m > 0x1p-100f && m < 0x1p100f) && a != 0.f) return a / D.d;
 #endif
+    return q2;
 }
 
 // Division by a denominator that changes every step (1 + hp*tanh, the two quotients inside tanh).  hipcc expands
@@ -120,11 +123,11 @@ SX_HD float sx_inff() { return sx_u2f(0x7f800000u); }
 #include "sx_libm.h"
 // the model's powers, exponential and logarithm exactly as the reference's compiler emits them: calls of powf / expf / logf
 SX_HD float sx_pow_m4(float x) { return sx_g_powf(x, -4.0f); }
-SX_HD void sx_pow_m4_m5(float x, float* m4, float* m5) { *m4 = sx_g_powf(x, -4.0f); *m5 = sx_g_powf(x, -5.0f); }
+SX_HD void sx_pow_m4_m5(float x, float* m4, float* m5) { sx_g_powf2(x, -4.0f, -5.0f, m4, m5); }      // one log2_inline per base
 SX_HD float sx_pow_m025(float y) { return sx_g_powf(y, -0.25f); }
-SX_HD void sx_pow_m025_m125(float y, float* m025, float* m125) { *m025 = sx_g_powf(y, -0.25f); *m125 = sx_g_powf(y, -1.25f); }
+SX_HD void sx_pow_m025_m125(float y, float* m025, float* m125) { sx_g_powf2(y, -0.25f, -1.25f, m025, m125); }
 SX_HD float sx_pow_3p5(float h) { return sx_g_powf(h, 3.5f); }
-SX_HD void sx_pow_3p5_2p5(float h, float* p35, float* p25) { *p35 = sx_g_powf(h, 3.5f); *p25 = sx_g_powf(h, 2.5f); }
+SX_HD void sx_pow_3p5_2p5(float h, float* p35, float* p25) { sx_g_powf2(h, 3.5f, 2.5f, p35, p25); }
 SX_HD float sx_expf(float x) { return sx_g_expf(x); }
 SX_HD float sx_logf(float x) { return sx_g_logf(x); }
 SX_HD float sx_powf(float x, float y) { return sx_g_powf(x, y); }
@@ -239,6 +242,9 @@ SX_HD float sx_pow_from(const SxLog2& L, float x, float y) {
 SX_HD float sx_powf(float x, float y) { return sx_pow_from(sx_log2_d(x), x, y); }
 
 #endif   // SX_EXACT_LIBM
+#ifndef SX_LIBM_INIT
+#define SX_LIBM_INIT()       // default build: nothing to stage (the exact-libm build copies its tables into LDS here, sx_libm.h)
+#endif
 
 // Several powers and the logarithm of ONE base (vic-a: x**y, x**(y-1) and ln x of the same x in the adjoint of the infiltration
 // curve, forward_db.f90:6808-6990).  Default build: the base-2 logarithm is evaluated once -- sx_powb / sx_logb return exactly what

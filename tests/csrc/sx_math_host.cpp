@@ -135,6 +135,20 @@ long sxt_g_powf_random_mismatches(long n, unsigned seed) {
     }
     return bad;
 }
+/* sx_g_powf2 (one log2_inline for two exponents of a base) against two separate library calls */
+long sxt_g_powf2_mismatches(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride) {
+    const float ys[3][2] = {{-4.f, -5.f}, {-0.25f, -1.25f}, {3.5f, 2.5f}};
+    long bad = 0;
+    for (uint64_t u = lo_bits; u < hi_bits; u += stride) {
+        const float x = sx_u2f((uint32_t)u);
+        for (int j = 0; j < 3; ++j) {
+            float a, b;
+            sx_g_powf2(x, ys[j][0], ys[j][1], &a, &b);
+            if (sx_f2u(a) != sx_f2u(powf(x, ys[j][0])) || sx_f2u(b) != sx_f2u(powf(x, ys[j][1]))) bad++;
+        }
+    }
+    return bad;
+}
 long sxt_g_specials(void) {
     const float inf = sx_inff(), nan = sx_nanf();
     const float xs[] = {0.f, -0.f, 1.f, -1.f, 2.f, -2.f, 1e-45f, 1e-40f, -1e-40f, 3.4e38f, 0.5f, -0.5f, inf, -inf, nan};

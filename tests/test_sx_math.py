@@ -80,3 +80,7 @@ def test_restated_glibc_expf_logf_powf_are_bit_identical_to_the_c_library(lib):
     assert lib.sxt_g_logf_mismatches(0, 0x7F800000, 5) == 0
     assert lib.sxt_g_powf_fixed_mismatches(0x33D6BF95, 0x461C4000, 11) == 0
     assert lib.sxt_g_powf_random_mismatches(50_000_000, 99) == 0
+    # the paired form the exact build uses for x^-4 / x^-5, y^-1/4 / y^-5/4, h^3.5 / h^2.5 (one log2 per base), incl. zero and subnormals
+    lib.sxt_g_powf2_mismatches.restype = C.c_long
+    lib.sxt_g_powf2_mismatches.argtypes = [C.c_uint32] * 3
+    assert lib.sxt_g_powf2_mismatches(0, 0x7F800000, 37) == 0
