@@ -231,21 +231,28 @@ struct SxForcing {
     const unsigned kb;          // byte offset of the cell in an fp32 row
     const size_t npad;
     int h;                      // hour index of the step the next request() is for
+    const char* prow; const char* erow;      // rows of that step (wave-uniform running pointers: one scalar add per step and stream)
     unsigned p_n, p_w; float e_n, e_w, r_n, r_w;
     __device__ __forceinline__ SxForcing(const SxDeviceArrays& A_, unsigned kb_, int t_first)
-        : A(A_), kb(kb_), npad((size_t)A_.npad), h(COMPACT ? (t_first + A_.hour0) % 24 : 0), p_n(0u), p_w(0u), e_n(0.f), e_w(0.f), r_n(0.f), r_w(0.f) {}
-    // t: absolute time step; first: nothing is held yet; BACK: the march runs backwards in time
+        : A(A_), kb(kb_), npad((size_t)A_.npad), h(COMPACT ? (t_first + A_.hour0) % 24 : 0),
+          prow(COMPACT ? (const char*)(A_.prcp16 + (size_t)t_first * A_.npad) : (const char*)(A_.prcp + (size_t)t_first * A_.npad)),
+          erow(COMPACT ? nullptr : (const char*)(A_.pet + (size_t)t_first * A_.npad)),
+          p_n(0u), p_w(0u), e_n(0.f), e_w(0.f), r_n(0.f), r_w(0.f) {}
+    // t: absolute time step (consecutive calls move by one step, forwards or BACKwards); first: nothing is held yet
     template <int AUX, bool BACK> __device__ __forceinline__ void request(int t, bool first) {
+        const long step = (long)npad * (COMPACT ? 2 : 4) * (BACK ? -1 : 1);
         if (!COMPACT) {
-            p_n = __float_as_uint(sx_row_load<AUX>(A.prcp + (size_t)t * npad, kb));
-            e_n = sx_row_load<AUX>(A.pet + (size_t)t * npad, kb);
+            p_n = __float_as_uint(sx_row_load<AUX>((const float*)prow, kb));
+            e_n = sx_row_load<AUX>((const float*)erow, kb);
+            prow += step; erow += step;
             return;
         }
         // the u16 count travels as the dword that holds it (lane pairs share one): nothing may touch the loaded word before hold(),
         // and a 16-bit load result is zero-extended by an ALU instruction right behind the load -- a wait in the same step
         // (measured: vert_adj 76 -> 89 ms).  The ratio comes the same way, one broadcast dword: a scalar load would be waited for
         // on the spot as well.
-        p_n = __float_as_uint(sx_row_load<AUX>((const float*)(A.prcp16 + (size_t)t * npad), (kb >> 1) & ~3u));
+        p_n = __float_as_uint(sx_row_load<AUX>((const float*)prow, (kb >> 1) & ~3u));
+        prow += step;
         if (first || h == (BACK ? 23 : 0)) e_n = sx_row_load<AUX>(A.petd + (size_t)((t + A.hour0) / 24) * npad, kb);   // a new day
         r_n = sx_row_load(A.pet_ratio + h, 0u);
         h = BACK ? (h == 0 ? 23 : h - 1) : (h == 23 ? 0 : h + 1);
@@ -932,12 +939,18 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDevi
     SxForcing<CF> F(A, kb, t0 + T - 1);
     float n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
     const bool hi_taped = (ST == 2 || ST == 3) && A.tape_hi != nullptr;       // wave-uniform
+    // tape rows of the step the next fetch is for: running pointers, stepped back one row per fetch
+    const size_t olast = (size_t)(T > 0 ? T - 1 : 0) * npad;
+    const float* r_hi = hi_taped ? A.tape_hi + olast : nullptr;
+    const float* r_hp = A.tape_hp + olast;
+    const float* r_hft = A.tape_hft + olast;
+    const float* r_hst = (ST == 3) ? A.tape_hst + olast : nullptr;
     auto fetch = [&](int tt, bool first) {
-        const size_t o = (size_t)tt * npad;
         F.template request<SX_VADJ_NT, true>(t0 + tt, first);
-        if (hi_taped) n_hi = sx_row_load<SX_VADJ_NT>(A.tape_hi + o, kb);
-        n_hp = sx_row_load<SX_VADJ_NT>(A.tape_hp + o, kb); n_hft = sx_row_load<SX_VADJ_NT>(A.tape_hft + o, kb);
-        if (ST == 3) n_hst = sx_row_load<SX_VADJ_NT>(A.tape_hst + o, kb);
+        if (hi_taped) { n_hi = sx_row_load<SX_VADJ_NT>(r_hi, kb); r_hi -= npad; }
+        n_hp = sx_row_load<SX_VADJ_NT>(r_hp, kb); n_hft = sx_row_load<SX_VADJ_NT>(r_hft, kb);
+        r_hp -= npad; r_hft -= npad;
+        if (ST == 3) { n_hst = sx_row_load<SX_VADJ_NT>(r_hst, kb); r_hst -= npad; }
         n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
     };
     // When the interception level is not taped (it depends on the forcing and ci only; the plan drops its tape when that is what
