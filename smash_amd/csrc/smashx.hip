@@ -121,6 +121,9 @@ __global__ void k_encode_pet(float* petd, const float* src, const int* idx, int 
     const size_t col = idx ? idx[k] : k;
     float* slot = petd + (size_t)d * npad + k;
     float D = *slot;
+    // two "not determined yet" marks: nothing seen (all ones) / only night hours seen, all of them +0 (then the day cannot be a gap day)
+    const unsigned PENDING_ZEROS = 0x7fc00001u;
+    const bool zeros_seen = __float_as_uint(D) == PENDING_ZEROS;
     auto fits = [&](float Dc) {
         for (int t = ta; t < tb; ++t) {
             const float v = src[(size_t)(t - t0) * ld + col];
@@ -136,10 +139,13 @@ __global__ void k_encode_pet(float* petd, const float* src, const int* idx, int 
     for (int t = ta; t < tb; ++t) {
         const float v = src[(size_t)(t - t0) * ld + col], r = ratio[(t + hour0) % 24];
         if (__float_as_uint(v) != 0u) allzero = false;
-        if (v < 0.f) { if (fits(v)) *slot = v; else atomicAdd(status, 1u); return; }
+        if (v < 0.f) { if (!zeros_seen && fits(v)) *slot = v; else atomicAdd(status, 1u); return; }   // a gap day is -99 at EVERY hour
         if (r > rbest) { rbest = r; tbest = t; }
     }
-    if (tbest < 0) { if (!allzero) atomicAdd(status, 1u); return; }           // night hours only: any D >= 0 fits, stays open
+    if (tbest < 0) {                                                          // night hours only: any D >= 0 fits, stays open
+        if (!allzero) atomicAdd(status, 1u); else *slot = __uint_as_float(PENDING_ZEROS);
+        return;
+    }
     const float v = src[(size_t)(tbest - t0) * ld + col];
     const unsigned b0 = __float_as_uint(v / rbest);
     for (int j = 0; j <= 6; ++j) {
@@ -951,6 +957,8 @@ int smashx_set_forcing(smashx_plan* p, const float* prcp, const float* pet, int 
             // staged in blocks of whole days, so that a day's PET is determined from all of its hours at once; both variables of a
             // block share the staging buffer
             const long half = std::max<long>(1, p->stage_planes / 2);
+            HIPCHK(hipMemsetAsync(p->d_fstatus, 0, 2 * sizeof(unsigned), p->stream));      // a fresh data set: no gap value known yet
+            HIPCHK(hipMemsetAsync(p->d_petd, 0xFF, (size_t)p->ndays * p->npad * sizeof(float), p->stream));
             for (int t = 0; t < p->nt && ok;) {
                 int rows = (int)std::min<long>(half, p->nt - t);
                 const int to_day_end = 24 - (t + p->flay.pet_hour0) % 24;
@@ -992,6 +1000,10 @@ int smashx_set_forcing_device_block(smashx_plan* p, int t0, int t1, const float*
     if ((rc = alloc_forcing(p))) return rc;
     if (p->d_prcp16) {
         bool ok = true;
+        if (t0 == 0) {   // the forcing is being sent again from its start: forget the previous data set's gap value and daily field
+            HIPCHK(hipMemsetAsync(p->d_fstatus, 0, 2 * sizeof(unsigned), p->stream));
+            HIPCHK(hipMemsetAsync(p->d_petd, 0xFF, (size_t)p->ndays * p->npad * sizeof(float), p->stream));
+        }
         if ((rc = encode_block(p, t0, t1 - t0, d_prcp, d_pet, nullptr, (long)p->n, p->stream, &ok))) return rc;
         if (!ok) {
             HIPCHK(hipMemset(p->d_fstatus, 0, sizeof(unsigned)));

@@ -118,3 +118,34 @@ def test_gap_days_and_unaligned_device_blocks():
     with pytest.raises(smash_amd.SmashxError) as e:
         sol.set_forcing_device_block(0, 24, bad.data_ptr(), be.data_ptr())
     assert e.value.code == _lib.E_UNSUPPORTED
+
+
+def test_partial_gap_day_across_blocks_is_refused():
+    """A day whose night hours arrive as +0 in one device block and whose daytime hours arrive as -99 in the next is not of the
+    reader's form (a gap day is -99 at every hour): the decode would turn the night hours into gaps.  The second block must be
+    refused even though the first one, on its own, was acceptable."""
+    import torch
+    import smash_amd
+    from smash_amd import _lib
+    from smash_amd.solver import Solver
+    from test_gpu_parity import _types
+    g = gu.load("gr_b_16x16x96_nse_gaps")
+    pet = g.pet.copy(order="F")
+    pet[:, :, 24:30] = 0.0                          # hours 0..5 of day 1 (night: ratio 0)
+    pet[:, :, 30:48] = -99.0                        # the rest of that day marked as a gap
+    setup, mesh, inp, par, sta, out = _types(g)
+    sol = Solver(setup, mesh)
+    sol.set_forcing_layout(**SYNTH_LAYOUT)
+    rows, cols = sol.cell_order()
+    codes = []
+    for t0 in range(0, 48, 6):
+        bp = torch.from_numpy(np.ascontiguousarray(g.prcp[rows, cols, t0:t0 + 6].T)).cuda()
+        be = torch.from_numpy(np.ascontiguousarray(pet[rows, cols, t0:t0 + 6].T)).cuda()
+        torch.cuda.synchronize()
+        try:
+            sol.set_forcing_device_block(t0, t0 + 6, bp.data_ptr(), be.data_ptr())
+            codes.append(0)
+        except smash_amd.SmashxError as e:
+            codes.append(e.code)
+            break
+    assert codes[:5] == [0, 0, 0, 0, 0] and codes[-1] == _lib.E_UNSUPPORTED and len(codes) == 6, codes
