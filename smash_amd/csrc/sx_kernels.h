@@ -391,8 +391,10 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A,
     A.hi[k] = husl1; A.hp[k] = husl2; A.hft[k] = hlsl;
 }
 
+// compiled for three waves per SIMD (168 registers, a handful spilled): 160 -> 140 ms against the natural 177 registers / two waves;
+// four waves (128 registers) spill the fp64 polynomial constants of log2 / exp2 and take 236 ms
 template <bool CF>
-__global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_adj_vic(SxDeviceArrays A, int t0, int T) {
+__global__ __launch_bounds__(SX_VBLOCK, 3) void sx_k_vert_adj_vic(SxDeviceArrays A, int t0, int T) {
     SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
