@@ -725,6 +725,17 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     if (hipStreamCreate(&p->stream_j) != hipSuccess || hipEventCreate(&p->ev_j) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
     SxDeviceArrays& A = p->A;
     A.n = p->n; A.npad = p->npad; A.nt = p->nt; A.dt = cfg->dt; A.dx = cfg->dx; A.Tc = 0;
+    if (getenv("SMASHX_VERBOSE"))
+        for (int r = 0; r < p->sch.nrounds; ++r) {       // diagnostics: shape of the routing schedule
+            long slots = 0, inlets = 0, dsum = 0; int dmx = 0;
+            const int ga = p->sch.round_group_begin[r], gb = p->sch.round_group_begin[r + 1];
+            for (int g = ga; g < gb; ++g) {
+                dsum += p->sch.g_dmax[g]; dmx = std::max(dmx, p->sch.g_dmax[g]);
+                for (int q = p->sch.g_slot_begin[g]; q < p->sch.g_slot_begin[g + 1]; ++q) { ++slots; if (p->sch.s_cell[q] < 0) ++inlets; }
+            }
+            fprintf(stderr, "smashx: routing round %d: %d groups, %ld slots (%ld inlets), depth mean %.1f max %d\n", r, gb - ga, slots, inlets,
+                    gb > ga ? (double)dsum / (gb - ga) : 0.0, dmx);
+        }
     // schedule tables
     int *d1, *d2, *d3, *d4, *d5, *d6, *d7, *d8;
     TRY(p->upload_vec(&d1, p->sch.g_slot_begin)); A.g_slot_begin = d1;
