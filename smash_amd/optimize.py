@@ -74,9 +74,127 @@ def _lbfgsb_box(fg, x0, m, factr, pgtol, maxiter, maxfun, callback):
     return x, float(f), {"task": f"{msg} ({int(task[1])})", "nit": nit, "funcalls": nfev, "grad": g}
 
 
-def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose=False):
+def wjreg_range(wjreg_opt, nb_wjreg_lcurve):
+    """Regularisation weights tried by the L-curve, centred on the `fast` estimate (core/simulation/_optimize.py:911-945,
+    `_compute_wjreg_range`): five weights a third of a decade apart around it, and for nb_wjreg_lcurve > 6 whole decades
+    below and above (the extra cycles split half / half, the odd one above).  float32 like the reference's."""
+    centre = np.log10(wjreg_opt)
+    span = 0.66
+    around = np.array(10 ** np.arange(centre - span, centre + span + 0.01, span / 2), dtype=np.float32)
+    extra = int(nb_wjreg_lcurve) - 6
+    if extra <= 0:
+        return around
+    below_from = centre - span - (extra - np.ceil(extra / 2.0))
+    above_to = centre + span + 1.0 + (extra - np.floor(extra / 2.0))
+    below = np.array(10 ** np.arange(below_from, centre - span), dtype=np.float32)
+    above = np.array(10 ** np.arange(centre + span + 1.0, above_to), dtype=np.float32)
+    return np.hstack((below, around, above))
+
+
+def best_lcurve_weight(cost_jobs, cost_jreg, wjreg, jobs_min, jobs_max, jreg_min, jreg_max):
+    """The weight at the corner of the L-curve (core/simulation/_optimize.py:948-1003, `_compute_best_lcurve_weight`).  In the
+    plane x = share of the attainable misfit reduction a cycle kept, y = share of the largest regularisation term it paid,
+    the corner is the point farthest below the diagonal y = x: the reference measures hyp * sin(pi/4 - acos(x / hyp)), which
+    is (x - y) / sqrt(2).  Points on or above the diagonal get NaN, cycles that did not reduce the misfit 0; of equal
+    distances the last one wins (>=).  Returns (distance float32 array, weight or None)."""
+    cost_jobs, cost_jreg = np.asarray(cost_jobs, np.float64), np.asarray(cost_jreg, np.float64)
+    if not (cost_jobs.size > 2 and (jreg_max - jreg_min) > 0.0 and (jobs_max - jobs_min) > 0.0):
+        return np.empty(0, np.float32), None
+    x = (float(jobs_max) - cost_jobs) / (float(jobs_max) - float(jobs_min))
+    y = (cost_jreg - float(jreg_min)) / (float(jreg_max) - float(jreg_min))
+    dist = np.where(cost_jobs < jobs_max, (x - y) / np.sqrt(2.0), 0.0)
+    dist = np.where(y < x, dist, np.nan).astype(np.float32)
+    best, far = None, np.float32(0.0)
+    for i in range(dist.size):
+        if not np.isnan(dist[i]) and dist[i] >= far:
+            far, best = dist[i], wjreg[i]
+    return dist, best
+
+
+def auto_wjreg_cycles(run_cycle, restore, auto_wjreg, nb_wjreg_lcurve=6, verbose=False):
+    """The calibration cycles behind auto_wjreg = 'fast' | 'lcurve' (core/simulation/_optimize.py:257-453, the part of
+    `_optimize_lbfgsb` that chooses the weight of the regularisation term).
+    run_cycle(wjreg) -> dict(cost, cost_jobs, cost_jreg, cost_jobs_initial): one complete optimize_lbfgsb with that weight;
+    restore(): parameters / states back to the first guess.  Returns (wjreg chosen or None, lcurve dict or None): the last
+    run_cycle call made here is the final calibration with the chosen weight (no weight chosen: the caller runs the model
+    as it is, like the reference)."""
+    def say(tag, w):
+        if verbose:
+            print(f"    {tag}: wJreg = {w:.6f}\n")
+
+    say("CYCLE 1", 0.0)
+    first = run_cycle(0.0)
+    if auto_wjreg == "fast":
+        # the misfit the unregularised calibration removed, per unit of regularisation term it ended with
+        w = (first["cost_jobs_initial"] - first["cost_jobs"]) / first["cost_jreg"]
+        restore()
+        say("FINAL CYCLE", w)
+        run_cycle(w)
+        return w, None
+    if auto_wjreg != "lcurve":
+        raise ValueError(f"Unknown auto_wjreg '{auto_wjreg}'. Choices: ['fast', 'lcurve']")
+    jobs_min, jobs_max, jreg_max = first["cost_jobs"], first["cost_jobs_initial"], first["cost_jreg"]
+    if (jobs_min / jobs_max) < 0.95 and jreg_max > 0.0:
+        w_fast = (jobs_max - jobs_min) / jreg_max
+        tries = wjreg_range(w_fast, nb_wjreg_lcurve)
+    else:
+        w_fast, tries = 0.0, np.empty(0, np.float32)
+    rec = {k: np.zeros(tries.size + 1, np.float32) for k in ("cost", "cost_jobs", "cost_jreg", "wjreg")}
+    for k in ("cost", "cost_jobs", "cost_jreg"):
+        rec[k][0] = first[k]
+    for i, w in enumerate(tries):
+        restore()
+        say(f"CYCLE {i + 2}", w)
+        r = run_cycle(w)
+        for k in ("cost", "cost_jobs", "cost_jreg"):
+            rec[k][i + 1] = r[k]
+        rec["wjreg"][i + 1] = w
+    jobs_min, jobs_max = np.min(rec["cost_jobs"]), np.max(rec["cost_jobs"])
+    jreg_min, jreg_max = np.min(rec["cost_jreg"]), np.max(rec["cost_jreg"])
+    dist, w_best = best_lcurve_weight(rec["cost_jobs"], rec["cost_jreg"], rec["wjreg"], jobs_min, jobs_max, jreg_min, jreg_max)
+    lcurve = {"cost_jobs_initial": jobs_max, "cost_jreg_initial": jreg_min, "wjreg_lcurve_opt": w_best, "wjreg_fast": w_fast,
+              "wjreg": rec["wjreg"], "distance": dist, "cost": rec["cost"], "cost_jobs": rec["cost_jobs"], "cost_jreg": rec["cost_jreg"]}
+    restore()
+    if w_best is not None:
+        say("FINAL CYCLE", w_best)
+        run_cycle(w_best)
+    return w_best, lcurve
+
+
+def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose=False, auto_wjreg=None, nb_wjreg_lcurve=6,
+                    return_lcurve=False):
     """In-place like the reference: parameters / states come back calibrated (denormalised), output holds the final run.
-    Returns a dict with the cost trajectory.  setup.optimize.maxiter bounds the iterations (default 100)."""
+    Returns a dict with the cost trajectory.  setup.optimize.maxiter bounds the iterations (default 100).
+    auto_wjreg = 'fast' | 'lcurve' (only with jreg_fun set): the weight of the regularisation term is found by calibration
+    cycles first (auto_wjreg_cycles above) and left in setup.optimize.wjreg; the returned dict is the final cycle's, with
+    'wjreg' and, for return_lcurve, 'lcurve' added."""
+    if auto_wjreg is not None and setup.optimize.njr > 0:
+        o = setup.optimize
+        if auto_wjreg == "lcurve" and nb_wjreg_lcurve < 6:
+            raise ValueError("nb_wjreg_lcurve option must be greater or equal to 6")
+        par0, sta0 = parameters.copy(), states.copy()
+        last = {}
+
+        def restore():
+            for k in PARAM_NAMES:
+                setattr(parameters, k, np.asfortranarray(getattr(par0, k)).copy(order="F"))
+            for k in STATE_NAMES:
+                setattr(states, k, np.asfortranarray(getattr(sta0, k)).copy(order="F"))
+
+        def run_cycle(w):
+            o.wjreg = float(w)
+            h = optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose=verbose)
+            last["h"] = h
+            return dict(cost=output.cost, cost_jobs=output.cost_jobs, cost_jreg=output.cost_jreg, cost_jobs_initial=h["cost_jobs_initial"])
+
+        w, lcurve = auto_wjreg_cycles(run_cycle, restore, auto_wjreg, nb_wjreg_lcurve, verbose)
+        if w is None:                         # no corner found: the model is run as it is
+            o.wjreg = 0.0
+            forward(setup, mesh, input_data, parameters, parameters.copy(), states, states.copy(), output, np.float32(0))
+        h = dict(last["h"], wjreg=w)
+        if return_lcurve and lcurve is not None:
+            h["lcurve"] = lcurve
+        return h
     o = setup.optimize
     maxiter = int(getattr(o, "maxiter", 100))
     act = np.asarray(mesh.active_cell) == 1

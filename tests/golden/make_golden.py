@@ -334,7 +334,84 @@ def main_sbs_cance():
     print("sbs cance costs:", costs)
 
 
+def _reference_lcurve_helpers():
+    """The two pure-numpy helpers of the reference's L-curve (core/simulation/_optimize.py: `_compute_wjreg_range`,
+    `_compute_best_lcurve_weight`), taken from the reference at generation time: the package itself does not import here
+    (f90wrap, gdal, h5py missing), these two functions need numpy only.  Nothing of them is stored: the fixture holds
+    their inputs and outputs."""
+    import ast
+    path = "/root/reference/smash/core/simulation/_optimize.py"
+    tree = ast.parse(open(path).read())
+    ns = {"np": np}
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("_compute_wjreg_range", "_compute_best_lcurve_weight"):
+            exec(compile(ast.Module([node], []), path, "exec"), ns)
+    return ns["_compute_wjreg_range"], ns["_compute_best_lcurve_weight"]
+
+
+def main_auto_wjreg():
+    """Row f2: the calibration cycles of auto_wjreg = 'fast' / 'lcurve' (core/simulation/_optimize.py:257-453; the reference's
+    own test: tests/core/test_simu.py:143-170 -- cp, cft, lr, prior + smoothing with weights 1, 2, maxiter 2, 8 L-curve
+    cycles) with every cycle run by the reference's optimize_lbfgsb, plus input / output vectors of its two helpers."""
+    from smash_amd.optimize import auto_wjreg_cycles
+    c = [x for x in CASES if x["name"] == "gr_b_24x24x120_norm_jreg"][0]
+    mesh = synth.make_mesh(c["n"], c["n"], ng=c["ng"], mask_corner=c["mask"])
+    prcp, pet = synth.dense_forcing(mesh, c["nt"], gap_per_million=c["gaps"])
+    P, S = synth.make_parameters(c["n"], c["n"]), synth.make_states(c["n"], c["n"], warm=True)
+    Pq = synth.make_parameters(c["n"], c["n"], perturb=0.1)
+    qobs = refbind.run("gr-b", mesh, DT, prcp, pet, np.zeros((c["ng"], c["nt"]), np.float32), Pq, S)["qsim"].copy()
+    op = np.zeros(16, np.int32)
+    op[[1, 3, 15]] = 1                                   # cp, cft, lr
+    kw = dict(optim_parameters=op, jobs_fun=("nse",), wjobs_fun=(1.0,), jreg_fun=("prior", "smoothing"), wjreg_fun=(1.0, 2.0))
+    # output%cost_jobs_initial: the misfit of the first guess, from the forward run optimize_lbfgsb starts with
+    # (mw_optimize.f90:567-573: normalised control, denormalize_forward on)
+    Pn, Sn = norm(P, synth.PARAM_NAMES, GLB_P, GUB_P), norm(S, synth.STATE_NAMES, GLB_S, GUB_S)
+    jobs0 = refbind.run("gr-b", mesh, DT, prcp, pet, qobs, Pn, Sn, params_bgd=Pn, states_bgd=Sn, denormalize_forward=True,
+                        wjreg=0.0, **kw)["cost_jobs"]
+    d = dict(optim_parameters=op, qobs=qobs, maxiter=2, nb_wjreg_lcurve=8, cost_jobs_initial=np.float32(jobs0))
+    for mode in ("fast", "lcurve"):
+        log = []
+
+        def run_cycle(w):
+            r = refbind.run("gr-b", mesh, DT, prcp, pet, qobs, P, S, optimize_maxiter=2, wjreg=float(w), **kw)
+            log.append((float(w), r["cost"], r["cost_jobs"], r["cost_jreg"]))
+            run_cycle.last = r
+            return dict(cost=r["cost"], cost_jobs=r["cost_jobs"], cost_jreg=r["cost_jreg"], cost_jobs_initial=jobs0)
+
+        w, lcurve = auto_wjreg_cycles(run_cycle, lambda: None, mode, 8)
+        d[mode + "_cycles"] = np.array(log, np.float64)          # wjreg, cost, cost_jobs, cost_jreg of every cycle, in order
+        d[mode + "_wjreg"] = np.float64(w if w is not None else np.nan)
+        d[mode + "_final_cp"] = run_cycle.last["parameters"]["cp"]
+        if lcurve is not None:
+            d["lcurve_distance"] = lcurve["distance"]
+        print(mode, "wjreg", w, "cycles", len(log), "final cost", log[-1][1])
+    # helper vectors straight from the reference's functions
+    ref_range, ref_best = _reference_lcurve_helpers()
+    wo = np.array([3.7e-4, 0.0123, 1.0, 25.0, 0.5], np.float64)
+    nb = np.array([6, 7, 8, 9, 12], np.int64)
+    d["range_w_opt"], d["range_nb"] = wo, nb
+    for i in range(wo.size):
+        d[f"range_out_{i}"] = ref_range(wo[i], int(nb[i]))
+    rng = np.random.default_rng(7)
+    for i in range(6):
+        n = 5 + 2 * i
+        jreg = np.sort(rng.uniform(0.0, 3.0, n)).astype(np.float32)
+        jobs = (1.0 - 0.6 * (jreg / jreg.max()) ** rng.uniform(0.2, 2.0) + rng.normal(0, 0.03, n)).astype(np.float32)
+        wj = np.concatenate([[0.0], np.sort(rng.uniform(1e-4, 1.0, n - 1))]).astype(np.float32)
+        if i == 4:
+            jobs[2] = jobs.max()                          # a cycle that removed nothing
+        args = (jobs, jreg, wj, np.min(jobs), np.max(jobs), np.min(jreg), np.max(jreg))
+        dist, best = ref_best(*args)
+        d[f"pick_jobs_{i}"], d[f"pick_jreg_{i}"], d[f"pick_w_{i}"] = jobs, jreg, wj
+        d[f"pick_dist_{i}"], d[f"pick_best_{i}"] = np.asarray(dist, np.float32), np.float64(np.nan if best is None else best)
+    d["pick_n"] = 6
+    np.savez_compressed(os.path.join(OUT, "lbfgsb", "auto_wjreg_gr_b_24x24x120.npz"), **d)
+
+
 if __name__ == "__main__":
+    if "--auto-wjreg" in sys.argv:
+        main_auto_wjreg()
+        sys.exit(0)
     main()                              # python make_golden.py [case names...]: only those cases
     if not [a for a in sys.argv[1:] if not a.startswith("-")]:
         os.makedirs(os.path.join(OUT, "lbfgsb"), exist_ok=True)
@@ -343,3 +420,4 @@ if __name__ == "__main__":
         main_sbs_cance()
         main_tangent()
         main_hyper()
+        main_auto_wjreg()

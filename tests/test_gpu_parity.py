@@ -283,6 +283,41 @@ def test_optimize_lbfgsb_python_host():
     assert np.all(par.cp > 1.0)          # calibrated fields come back denormalised
 
 
+@pytest.mark.parametrize("mode", ["fast", "lcurve"])
+def test_auto_wjreg_cycles_vs_reference(mode):
+    """SURVEY row f2, the weight of the regularisation term found by calibration cycles (auto_wjreg, core/simulation/
+    _optimize.py:257-453; the reference's own test configuration, tests/core/test_simu.py:143-170: cp, cft, lr, prior + smoothing
+    weighted 1 and 2, two iterations per cycle, 8 L-curve cycles): every cycle a smash_amd.optimize_lbfgsb over GPU sweeps, against
+    the same cycles run by the reference's optimize_lbfgsb (tests/golden/lbfgsb/auto_wjreg_*.npz)."""
+    import os
+    import smash_amd
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "auto_wjreg_gr_b_24x24x120.npz"))
+    g = gu.load("gr_b_24x24x120_norm_jreg")
+    g.opts = dict(jobs_fun=("nse",), wjobs_fun=(1.0,), jreg_fun=("prior", "smoothing"), wjreg_fun=(1.0, 2.0), wjreg=0.0)
+    g.params, g.states, g.qobs = synth.make_parameters(24, 24), synth.make_states(24, 24, warm=True), z["qobs"]
+    setup, mesh, inp, par, sta, out = _types(g)
+    setup.optimize.optim_parameters = np.asarray(z["optim_parameters"], np.int32)
+    setup.optimize.maxiter = int(z["maxiter"])
+    h = smash_amd.optimize_lbfgsb(setup, mesh, inp, par, sta, out, auto_wjreg=mode, nb_wjreg_lcurve=int(z["nb_wjreg_lcurve"]),
+                                  return_lcurve=True)
+    rec = z[mode + "_cycles"]
+    rel = lambda a, b: abs(a - b) / abs(b)
+    assert rel(h["wjreg"], float(z[mode + "_wjreg"])) <= 2e-4, (h["wjreg"], z[mode + "_wjreg"])
+    assert setup.optimize.wjreg == pytest.approx(h["wjreg"])
+    assert rel(h["cost_jobs_initial"], float(z["cost_jobs_initial"])) <= 1e-5
+    # the final cycle: cost, its two parts and the calibrated field
+    assert rel(out.cost, rec[-1, 1]) <= 2e-4 and rel(out.cost_jobs, rec[-1, 2]) <= 2e-4 and rel(out.cost_jreg, rec[-1, 3]) <= 1e-3, \
+        (out.cost, out.cost_jobs, out.cost_jreg, rec[-1])
+    assert gu.rel_l2(par.cp, z[mode + "_final_cp"]) <= 1e-4
+    if mode == "lcurve":
+        lc = h["lcurve"]
+        assert lc["wjreg"].size == len(rec) - 1
+        assert np.allclose(lc["wjreg"], rec[:-1, 0], rtol=2e-4)
+        assert np.allclose(lc["cost_jobs"], rec[:-1, 2], rtol=2e-4) and np.allclose(lc["cost_jreg"], rec[:-1, 3], rtol=1e-3)
+        assert np.array_equal(np.isnan(lc["distance"]), np.isnan(z["lcurve_distance"]))
+        assert np.allclose(np.nan_to_num(lc["distance"]), np.nan_to_num(z["lcurve_distance"]), atol=2e-4)
+
+
 def test_optimize_lbfgsb_python_host_on_cance():
     """The same loop on the real Cance data (distributed calibration of the user guide, real_case_cance.rst:470-552)."""
     import os
