@@ -62,7 +62,7 @@ def parse(argv=None):
     ap.add_argument("--grid", type=int, default=0, help="square per-GPU tile (default: 1024 at N = 1)")
     ap.add_argument("--tile-rows", type=int, default=0, help="per-GPU tile rows (default at N > 1: 2048 x 1024, so 8 GPUs hold the 4096^2 grid)")
     ap.add_argument("--tile-cols", type=int, default=0)
-    ap.add_argument("--pipe", type=int, default=0, help="pipeline sub-chunk (default: none on 1 GPU, 1104 on tiles)")
+    ap.add_argument("--pipe", type=int, default=0, help="pipeline sub-chunk (default: none on 1 GPU; tiles: 2192 up to 4 ranks, 1104 at 8)")
     ap.add_argument("--partition", default="rect", choices=["rect", "sub", "trunk"],
                     help="N > 1: rectangles (default), sub-catchments (tiles.partition_subcatchments) or the depth-2 trunk cut (tiles.partition_trunk)")
     ap.add_argument("--trunk-share", type=float, default=1.0, help="--partition trunk: the trunk part's share of the cells relative to 1/N")
@@ -227,7 +227,10 @@ class Case:
             hbm = torch.cuda.get_device_properties(dev).total_memory
             fbytes = cells * nt * (2.0 + 4.0 / 24.0 if compact else 8.0)
             chunk = chunk_plan(nt, cells, hbm, fbytes, a.structure, chunk)
-            pipe = pipe or 1104
+            # sub-chunk length: a pass over n sub-chunks through a rank graph of depth L costs (L - 1 + n) (a / n + b), b = the fill
+            # of the chained routing rounds paid per launch: 8 sub-chunks per year at depth 5 (2 x 4 tiles), 4 at
+            # depth <= 3 (solo rank, measured: 364 ms against 380)
+            pipe = pipe or (2192 if parts <= 4 else 1104)
         if a.trace_groups:
             os.environ["SMASHX_TRACE_GROUPS"] = "1"
         sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=a.group, device=local, tile=rect, owner_mask=mine)
