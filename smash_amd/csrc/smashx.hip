@@ -485,7 +485,18 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
     if (adjoint && !p->adj_ready) {
         int rc;
         const size_t cs = (size_t)p->npad * p->Tc;
-        if ((rc = p->dmalloc(&p->A.hrT, cs))) return rc;
+        {   // the hr_imd tape is written and read by the routing kernels only: its rows are shifted by the cell's stage when the
+            // extra rows (the deepest group's stages) fit beside everything else -- decided per plan, never changes results
+            const size_t extra = (size_t)p->sch.max_stage * p->npad * 4;
+            const double ntp = 3.0 + ((st == 5 || ((st == 2 || st == 3) && p->hi_tape)) ? 1.0 : (st == 2 || st == 3) ? 1.0 / SX_HIK : 0.0) + (st == 3 ? 1.0 : 0.0);
+            size_t fr = 0, tot = 0;
+            HIPCHK(hipMemGetInfo(&fr, &tot));
+            const double need = 4.0 * ((double)cs * ntp + (double)extra + (double)p->npad * (14 + (p->nchunks > 1 ? 5.0 * p->nchunks : 0.0))
+                                       + 2.0 * (double)std::max(p->ngc, 1) * p->nt) + 3.0e9;
+            const char* e = getenv("SMASHX_HR_SKEW");
+            p->A.hr_skew = (e ? atoi(e) != 0 : true) && (double)fr > need;
+            if ((rc = p->dmalloc(&p->A.hrT, cs + (p->A.hr_skew ? extra : 0)))) return rc;
+        }
         if ((rc = p->dmalloc(&p->A.tape_hp, cs))) return rc;
         if ((rc = p->dmalloc(&p->A.tape_hft, cs))) return rc;
         if (st == 5 || ((st == 2 || st == 3) && p->hi_tape)) { if ((rc = p->dmalloc(&p->A.tape_hi, cs))) return rc; }

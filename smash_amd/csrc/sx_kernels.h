@@ -5,6 +5,8 @@
 //   forcing      prcp/pet [nt][npad]     cell index fastest  -> lanes = consecutive cells, coalesced
 //   params/state [npad] per field
 //   qtT, hrT     [Tc/4][npad][4]         "T4": one float4 = 4 consecutive steps of one cell; cell index next.
+//                hrT belongs to the routing kernels alone; with hr_skew its row index is shifted by the cell's stage in its group:
+//                [Tc/4 + max stage][npad][4]
 //                                        The marching vertical threads (lanes = consecutive cells) move
 //                                        1 KiB contiguous per wave instruction; the time-skewed routing threads
 //                                        of a group read rows tb = w - stage, and because the group's slots are
@@ -148,6 +150,7 @@ struct SxDeviceArrays {
     float *ci_b, *cp_b, *cft_b, *cst_b, *exc_b, *lr_b, *hi_b, *hp_b, *hft_b, *hst_b, *hlr_b;
     // chunk buffers
     float *qtT, *hrT;
+    int hr_skew;                  // 1: row of hrT = time block + the slot's stage (what a routing group touches in one super-step is one row)
     // tangent sweep (base_forward_d): qt_d per cell (T4 like qtT), exchange series of q_d, q_d at the gauge cells.
     // The tangents of parameters and states live in the gradient arrays (ci_b .. hlr_b) during a tangent sweep.
     float *qtdT, *xdT, *qgd;
@@ -583,6 +586,9 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
     const size_t sstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
     float4* x4 = reinterpret_cast<float4*>(TAN ? A.xdT : A.xT);
     float4* hr4 = reinterpret_cast<float4*>(A.hrT);
+    // hr_imd tape, private to the routing kernels: row = time block + stage, so the slots of a group -- which work on time block
+    // w - stage in super-step w -- all write row w, cell next to cell (measured: 64 -> 8 line requests per wave store)
+    const int hs = A.hr_skew ? stage : 0;
     float* gauge_out = TAN ? A.qgd : A.qg;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     // chained rounds: an inlet whose series is published inside this launch follows its producer's counter
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
     for (int u = 0; u < SX_MU; ++u) {
         const int tb = u - stage;
         nxt[u] = (valid && tb >= 0 && tb < nb) ? fetch(tb) : zero4;
-        nhr[u] = (TAN && valid && cell >= 0 && tb >= 0 && tb < nb) ? sx_gload4(hr4 + (size_t)tb * A.npad + cell) : zero4;
+        nhr[u] = (TAN && valid && cell >= 0 && tb >= 0 && tb < nb) ? sx_gload4(hr4 + (size_t)(tb + hs) * A.npad + cell) : zero4;
         outq[u] = zero4; outh[u] = zero4;
     }
     const int nsuper = nb + dmax;
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
                 const int tb = SX_MU * (mw - 1) + u - stage;
                 if (tb >= 0 && tb < nb) {
                     if (xout >= 0) x4[(size_t)tb * A.nx + xout] = outq[u];
-                    if (TAPE) sx_gstore4s(hr4 + (size_t)tb * A.npad + cell, outh[u]);
+                    if (TAPE) sx_gstore4s(hr4 + (size_t)(tb + hs) * A.npad + cell, outh[u]);
                     if (A.qdT) reinterpret_cast<float4*>(A.qdT)[(size_t)tb * A.npad + cell] = outq[u];
                     if (gid >= 0) {
                         const float qv[4] = {outq[u].x, outq[u].y, outq[u].z, outq[u].w};
@@ -633,7 +639,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
         for (int u = 0; u < SX_MU; ++u) {
             const int tb = SX_MU * (mw + 1) + u - stage;
             nxt[u] = (valid && tb >= 0 && tb < nb) ? fetch(tb) : zero4;
-            if (TAN) nhr[u] = (valid && cell >= 0 && tb >= 0 && tb < nb) ? sx_gload4(hr4 + (size_t)tb * A.npad + cell) : zero4;
+            if (TAN) nhr[u] = (valid && cell >= 0 && tb >= 0 && tb < nb) ? sx_gload4(hr4 + (size_t)(tb + hs) * A.npad + cell) : zero4;
         }
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
@@ -764,6 +770,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
     const SxDiv dden = sx_mkdiv(den), ddt = sx_mkdiv(dt), dlr = sx_mkdiv((lr * lr) * 60.f);
     float4* x4 = reinterpret_cast<float4*>(A.xT);
     const float4* hr4p = reinterpret_cast<const float4*>(A.hrT);
+    const int hs = A.hr_skew ? dmax - rstage : 0;     // the forward kernel's row shift: in reverse super-step w a group reads row nb - 1 - w + dmax
     float4* qt4 = reinterpret_cast<float4*>(A.qtT);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool root_in = (cell >= 0 && par < 0 && xout >= 0);   // subtree root fed by an exchange series
@@ -794,7 +801,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
         const int tbr = u - rstage;
         const int tb = nb - 1 - tbr;
         const bool ok = valid && tbr >= 0 && tbr < nb;
-        nhr[u] = (ok && cell >= 0) ? sx_gload4s(hr4p + (size_t)tb * A.npad + cell) : zero4;
+        nhr[u] = (ok && cell >= 0) ? sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell) : zero4;
         nin[u] = (ok && root_in) ? fetch_in(tb) : zero4;
         nsd[u] = ok ? load_seed(tb) : zero4;
         outq[u] = zero4;
@@ -827,7 +834,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
             const int tbr = SX_MU * (mw + 1) + u - rstage;
             const int tb = nb - 1 - tbr;
             const bool ok = valid && tbr >= 0 && tbr < nb;
-            nhr[u] = (ok && cell >= 0) ? sx_gload4s(hr4p + (size_t)tb * A.npad + cell) : zero4;
+            nhr[u] = (ok && cell >= 0) ? sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell) : zero4;
             nin[u] = (ok && root_in) ? fetch_in(tb) : zero4;
             nsd[u] = ok ? load_seed(tb) : zero4;
         }
