@@ -128,6 +128,23 @@ def test_chunking_and_grouping_do_not_change_results(name, chunk, pipe, group):
         assert np.array_equal(getattr(ref[4], k), getattr(alt[4], k)), k
 
 
+@pytest.mark.parametrize("name,chunk,pipe", [("gr_b_20x20x96_d8", 0, 0), ("gr_c_32x32x240_d8_ragged", 48, 16), ("vic_a_24x24x240_d8_kge", 64, 32)])
+def test_routing_tape_indexed_by_super_step_equals_rows_of_time_blocks(name, chunk, pipe, monkeypatch):
+    """The hr_imd tape of the routing kernels is indexed by time block + the slot's stage (one row per super-step and group,
+    DESIGN.md 8) unless the extra rows do not fit or SMASHX_HR_SKEW=0: an address change only -- every output bit-identical, also
+    across storage chunks and pipeline sub-chunks (the shifted rows of consecutive launches interleave)."""
+    g = gu.load(name)
+    monkeypatch.setenv("SMASHX_HR_SKEW", "0")
+    ref = _run_adjoint(g, chunk_steps=chunk, pipe_steps=pipe)
+    monkeypatch.setenv("SMASHX_HR_SKEW", "1")
+    alt = _run_adjoint(g, chunk_steps=chunk, pipe_steps=pipe)
+    assert np.array_equal(ref[2].qsim, alt[2].qsim) and ref[2].cost == alt[2].cost
+    for k in gu.STRUCT_PARAMS[g.structure]:
+        assert np.array_equal(getattr(ref[3], k), getattr(alt[3], k)), k
+    for k in gu.STRUCT_STATES[g.structure]:
+        assert np.array_equal(getattr(ref[4], k), getattr(alt[4], k)), k
+
+
 @pytest.mark.parametrize("name,chunk", [("gr_b_16x16x96_nse_gaps", 0), ("gr_c_16x16x96_kge_se_log_mask", 32), ("gr_b_24x24x120_norm_jreg", 48),
                                         ("gr_c_32x32x240_d8_ragged", 0)])
 def test_interception_level_rebuilt_from_checkpoints_equals_tape(name, chunk, monkeypatch):
