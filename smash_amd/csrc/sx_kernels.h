@@ -70,6 +70,11 @@ __device__ __forceinline__ void sx_gstore4s(float4* p, const float4& q) {
         __builtin_nontemporal_store(v, (__attribute__((address_space(1))) sx_f4v*)p);
         return;
     }
+    {   // global_store, never flat_store: the pointer may have been selected between two buffers (see sx_gload4)
+        sx_f4v v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
+        *(__attribute__((address_space(1))) sx_f4v*)p = v;
+        return;
+    }
 #endif
     *p = q;
 }
@@ -774,6 +779,11 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
     float4* qt4 = reinterpret_cast<float4*>(A.qtT);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool root_in = (cell >= 0 && par < 0 && xout >= 0);   // subtree root fed by an exchange series
+    // where a slot's result goes: qt_b of its cell, or -- inlet -- the adjoint series of the subtree upstream.  ONE store instruction
+    // for both kinds (per-lane base and row stride): in the chained rounds, where a third of the slots are inlets, the second store
+    // instruction of a super-step cost as much as the first whatever its lane count (anatomy of the reverse launch)
+    float4* const dst = (cell >= 0) ? qt4 + cell : x4 + (xin >= 0 ? xin : 0);
+    const size_t dstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
 
     // gauge cells also fetch their adjoint seeds (qsim_b summed per cell) with the staged loads, so the
     // super-step loop itself contains no global memory operation and no vmcnt wait
@@ -822,8 +832,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
                 const int tbr = SX_MU * (mw - 1) + u - rstage;
                 if (tbr >= 0 && tbr < nb) {
                     const int tb = nb - 1 - tbr;
-                    if (cell >= 0) sx_gstore4s(qt4 + (size_t)tb * A.npad + cell, outq[u]);
-                    else x4[(size_t)tb * A.nx + xin] = outq[u];
+                    sx_gstore4s(dst + (size_t)tb * dstride, outq[u]);
                 }
             }
         }
