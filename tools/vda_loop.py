@@ -36,9 +36,15 @@ def main():
     orig = sol.sweep
 
     def timed(adjoint=False, cost_b=1.0):
+        t = time.perf_counter()
         r = orig(adjoint, cost_b)
+        w = time.perf_counter() - t
         sweeps["n"] += 1
-        sweeps["ms"] += sol.timing()["sweep_ms"]
+        ms = sol.timing()["sweep_ms"]
+        sweeps["ms"] += ms
+        # the first reverse sweep of a plan allocates the tapes and checkpoints (once per plan): wall time beyond the device's
+        if adjoint and "alloc_s" not in sweeps:
+            sweeps["alloc_s"] = max(0.0, w - ms * 1e-3)
         return r
     sol.sweep = timed
     # where the host time goes: the packing calls and L-BFGS-B itself (scipy's setulb)
@@ -70,7 +76,9 @@ def main():
     print(json.dumps({"grid": a.grid, "nt": a.nt, "control_variables": int(4 * sol.ncells), "iterations": len(h["cost"]),
                       "nfg": h["nfg"], "cost": h["cost"], "final_cost": h["final_cost"], "loop_s": wall, "setup_s": t_setup,
                       "gpu_sweeps": sweeps["n"], "gpu_sweep_s": sweeps["ms"] * 1e-3,
-                      "host_s": wall - sweeps["ms"] * 1e-3, "host_lbfgsb_setulb_s": host["setulb_s"],
+                      "host_s": wall - sweeps["ms"] * 1e-3, "one_off_tape_allocation_s": sweeps.get("alloc_s", 0.0),
+                      "host_s_without_allocation": wall - sweeps["ms"] * 1e-3 - sweeps.get("alloc_s", 0.0),
+                      "host_lbfgsb_setulb_s": host["setulb_s"],
                       "host_control_vector_transfers_s": host["pack_s"], "forcing": sol.forcing_info()}))
 
 
