@@ -32,7 +32,9 @@
 // global data written here is only read by later kernels.
 __device__ __forceinline__ void sx_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+#ifndef SX_ABL_NOBAR
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
@@ -125,7 +127,9 @@ __device__ __forceinline__ void sx_wait_prog(const int* prog, int need, int& see
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 __device__ __forceinline__ void sx_publish(int* prog, int blocks) {
+#ifndef SX_ABL_NOREL
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
     __hip_atomic_store((sx_gint*)prog, blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -535,6 +539,25 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
 #ifndef SX_MU
 #define SX_MU 4
 #endif
+// Timing-only builds for the anatomy of a routing super-step (tools/anatomy.sh -> profiles/r2_routing_anatomy*.json): each switch
+// removes one ingredient; results are void, the schedule and the progress protocol are not touched (no switch can hang a launch).
+//   SX_ABL_NOBAR (no workgroup barrier)  SX_ABL_NOREL (publications without release fence)  SX_ABL_NOLDS (children not read from LDS)
+//   SX_ABL_NOST / SX_ABL_NOLD (forward: no global stores / loads)   SX_ABL_A_NOQ / _NOX / _NOHR (reverse: no qt_b / series stores, no tape loads)
+#ifndef SX_ABL_NOST
+#define SX_ABL_NOST 0
+#endif
+#ifndef SX_ABL_NOLD
+#define SX_ABL_NOLD 0
+#endif
+#ifndef SX_ABL_A_NOQ
+#define SX_ABL_A_NOQ 0
+#endif
+#ifndef SX_ABL_A_NOX
+#define SX_ABL_A_NOX 0
+#endif
+#ifndef SX_ABL_A_NOHR
+#define SX_ABL_A_NOHR 0
+#endif
 #define SX_MAXGROUP 512   // largest routing workgroup (group_size): 8 waves = 2 per SIMD
 // Occupancy of the routing kernels: 132 (forward) / 154 (adjoint) registers = ONE resident group per CU.  Measured at
 // 1024^2 x 8760: compiling them for two groups per CU (128 registers) makes round 0 slower (route_fwd 26.0 -> 27.7 ms; the
@@ -620,7 +643,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
         // chained: the stores of the previous macro-step (four super-steps old) have completed past this point
         if (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // results of the previous macro-step leave now
-        if (mw > 0 && cell >= 0) {
+        if (mw > 0 && cell >= 0 && !SX_ABL_NOST) {
 #pragma unroll
             for (int u = 0; u < SX_MU; ++u) {
                 const int tb = SX_MU * (mw - 1) + u - stage;
@@ -643,7 +666,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
             const int tb = SX_MU * (mw + 1) + u - stage;
-            nxt[u] = (valid && tb >= 0 && tb < nb) ? fetch(tb) : zero4;
+            nxt[u] = (valid && tb >= 0 && tb < nb && !SX_ABL_NOLD) ? fetch(tb) : zero4;
             if (TAN) nhr[u] = (valid && cell >= 0 && tb >= 0 && tb < nb) ? sx_gload4(hr4 + (size_t)(tb + hs) * A.npad + cell) : zero4;
         }
 #pragma unroll
@@ -660,12 +683,20 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
                     // together so their LDS latencies overlap; "+ 0" for an absent child is exact
                     float s[SX_BT];
                     {
+#ifdef SX_ABL_NOLDS
+                        const float4 v0 = cur[u], v1 = cur[u];
+#else
                         const float4 v0 = prev[min(cstart, M - 1)], v1 = prev[min(cstart + 1, M - 1)];
+#endif
                         const bool h0 = ccount > 0, h1 = ccount > 1;
                         s[0] = (h0 ? v0.x : 0.f) + (h1 ? v1.x : 0.f); s[1] = (h0 ? v0.y : 0.f) + (h1 ? v1.y : 0.f);
                         s[2] = (h0 ? v0.z : 0.f) + (h1 ? v1.z : 0.f); s[3] = (h0 ? v0.w : 0.f) + (h1 ? v1.w : 0.f);
                     }
+#ifdef SX_ABL_NOLDS
+                    for (int c = 2; c < 0; ++c) {
+#else
                     for (int c = 2; c < ccount; ++c) {
+#endif
                         const float4 v = prev[cstart + c];
                         s[0] = s[0] + v.x; s[1] = s[1] + v.y; s[2] = s[2] + v.z; s[3] = s[3] + v.w;
                     }
@@ -811,7 +842,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
         const int tbr = u - rstage;
         const int tb = nb - 1 - tbr;
         const bool ok = valid && tbr >= 0 && tbr < nb;
-        nhr[u] = (ok && cell >= 0) ? sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell) : zero4;
+        nhr[u] = (ok && cell >= 0) ? (SX_ABL_A_NOHR ? zero4 : sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell)) : zero4;
         nin[u] = (ok && root_in) ? fetch_in(tb) : zero4;
         nsd[u] = ok ? load_seed(tb) : zero4;
         outq[u] = zero4;
@@ -832,7 +863,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
                 const int tbr = SX_MU * (mw - 1) + u - rstage;
                 if (tbr >= 0 && tbr < nb) {
                     const int tb = nb - 1 - tbr;
-                    sx_gstore4s(dst + (size_t)tb * dstride, outq[u]);
+                    if (!(cell >= 0 ? SX_ABL_A_NOQ : SX_ABL_A_NOX)) sx_gstore4s(dst + (size_t)tb * dstride, outq[u]);
                 }
             }
         }
@@ -843,7 +874,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
             const int tbr = SX_MU * (mw + 1) + u - rstage;
             const int tb = nb - 1 - tbr;
             const bool ok = valid && tbr >= 0 && tbr < nb;
-            nhr[u] = (ok && cell >= 0) ? sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell) : zero4;
+            nhr[u] = (ok && cell >= 0) ? (SX_ABL_A_NOHR ? zero4 : sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell)) : zero4;
             nin[u] = (ok && root_in) ? fetch_in(tb) : zero4;
             nsd[u] = ok ? load_seed(tb) : zero4;
         }

@@ -78,6 +78,9 @@ SX_HD float sx_seed_sqrt(float x) {
 struct SxDiv { float d, r; };
 SX_HD SxDiv sx_mkdiv(float d) { SxDiv D; D.d = d; D.r = 1.0f / d; return D; }
 SX_HD float sx_div(float a, const SxDiv& D) {
+#if defined(SX_ABL_DIV)
+    return a * D.r;      // timing-only build (tools/anatomy.sh): what the exact divisions cost; results void
+#endif
     const float q = a * D.r;
     const float e = fmaf(-D.d, q, a);
     const float q2 = fmaf(e, D.r, q);
@@ -97,6 +100,9 @@ SX_HD float sx_div(float a, const SxDiv& D) {
 // boundary, and then q is the correctly rounded quotient.  6 instructions; mismatches against a/b are counted on
 // the device by smashx_selftest_math (tests/test_gpu_parity.py: < 1e-6 of calls, 1 ulp).
 SX_HD float sx_fdiv(float a, float b) {
+#if defined(SX_ABL_DIV) && defined(__HIP_DEVICE_COMPILE__)
+    return a * __builtin_amdgcn_rcpf(b);      // timing-only build
+#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !SX_EXACT_LIBM
     float r = __builtin_amdgcn_rcpf(b);
     r = fmaf(fmaf(-b, r, 1.0f), r, r);
@@ -156,6 +162,14 @@ SX_HD double sx_sqrt_d(float h) {
     return fma(e, 0.5 * r, s);
 }
 
+#if defined(SX_ABL_POW) && defined(__HIP_DEVICE_COMPILE__)      // timing-only build: fp32 hardware seeds, no fp64 refinement
+SX_HD float sx_pow_m4(float x) { const float u = __builtin_amdgcn_rcpf(x), u2 = u * u; return u2 * u2; }
+SX_HD void sx_pow_m4_m5(float x, float* m4, float* m5) { const float u = __builtin_amdgcn_rcpf(x), u2 = u * u, u4 = u2 * u2; *m4 = u4; *m5 = u4 * u; }
+SX_HD float sx_pow_m025(float y) { return __builtin_amdgcn_rsqf(__builtin_amdgcn_sqrtf(y)); }
+SX_HD void sx_pow_m025_m125(float y, float* a, float* b) { const float r = __builtin_amdgcn_rsqf(__builtin_amdgcn_sqrtf(y)), r2 = r * r; *a = r; *b = r2 * r2 * r; }
+SX_HD float sx_pow_3p5(float h) { return h * h * h * __builtin_amdgcn_sqrtf(h); }
+SX_HD void sx_pow_3p5_2p5(float h, float* a, float* b) { const float s = __builtin_amdgcn_sqrtf(h), d2 = h * h; *a = d2 * h * s; *b = d2 * s; }
+#else
 // powf(x, -4), powf(x, -5)   [x > 0]   (gr_transfer, md_gr_operator.f90:94-106; GR_TRANSFER_B forward_db.f90:6349-6368)
 SX_HD float sx_pow_m4(float x) { const double u = sx_rcp_d(x); const double u2 = u * u; return (float)(u2 * u2); }
 SX_HD void sx_pow_m4_m5(float x, float* m4, float* m5) {
@@ -179,6 +193,7 @@ SX_HD void sx_pow_3p5_2p5(float h, float* p35, float* p25) {
     *p35 = (float)((d2 * d) * s); *p25 = (float)(d2 * s);
 }
 
+#endif   // SX_ABL_POW
 // expf: fp64 evaluation, one rounding (glibc's float version is correctly rounded in 99.94 %)
 SX_HD float sx_expf(float x) { return (float)exp((double)x); }
 
@@ -343,6 +358,9 @@ SX_HD float sx_expm1f(float x) {
 }
 
 SX_HD float sx_tanhf(float x) {
+#if defined(SX_ABL_TANH) && defined(__HIP_DEVICE_COMPILE__)
+    { const float e = __builtin_amdgcn_exp2f(2.885390082f * x); return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f); }   // timing-only build
+#endif
     const uint32_t jx = sx_f2u(x), ix = jx & 0x7fffffffu;
     float t, z;
     if (ix < 0x41b00000u) {             // |x| < 22
