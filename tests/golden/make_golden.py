@@ -349,31 +349,29 @@ def _reference_lcurve_helpers():
     return ns["_compute_wjreg_range"], ns["_compute_best_lcurve_weight"]
 
 
-def main_auto_wjreg():
-    """Row f2: the calibration cycles of auto_wjreg = 'fast' / 'lcurve' (core/simulation/_optimize.py:257-453; the reference's
-    own test: tests/core/test_simu.py:143-170 -- cp, cft, lr, prior + smoothing with weights 1, 2, maxiter 2, 8 L-curve
-    cycles) with every cycle run by the reference's optimize_lbfgsb, plus input / output vectors of its two helpers."""
+def _auto_wjreg_case(tag, structure, mesh, prcp, pet, qobs, P, S, base_opts):
+    """One fixture of the auto_wjreg cycles: the reference's own test configuration (tests/core/test_simu.py:143-170 -- control
+    cp, cft, lr; prior + smoothing with weights 1, 2; maxiter 2; 8 L-curve cycles), every cycle run by the reference's
+    optimize_lbfgsb."""
     from smash_amd.optimize import auto_wjreg_cycles
-    c = [x for x in CASES if x["name"] == "gr_b_24x24x120_norm_jreg"][0]
-    mesh = synth.make_mesh(c["n"], c["n"], ng=c["ng"], mask_corner=c["mask"])
-    prcp, pet = synth.dense_forcing(mesh, c["nt"], gap_per_million=c["gaps"])
-    P, S = synth.make_parameters(c["n"], c["n"]), synth.make_states(c["n"], c["n"], warm=True)
-    Pq = synth.make_parameters(c["n"], c["n"], perturb=0.1)
-    qobs = refbind.run("gr-b", mesh, DT, prcp, pet, np.zeros((c["ng"], c["nt"]), np.float32), Pq, S)["qsim"].copy()
     op = np.zeros(16, np.int32)
     op[[1, 3, 15]] = 1                                   # cp, cft, lr
-    kw = dict(optim_parameters=op, jobs_fun=("nse",), wjobs_fun=(1.0,), jreg_fun=("prior", "smoothing"), wjreg_fun=(1.0, 2.0))
+    kw = dict(base_opts)
+    kw.update(optim_parameters=op, jreg_fun=("prior", "smoothing"), wjreg_fun=(1.0, 2.0))
     # output%cost_jobs_initial: the misfit of the first guess, from the forward run optimize_lbfgsb starts with
     # (mw_optimize.f90:567-573: normalised control, denormalize_forward on)
     Pn, Sn = norm(P, synth.PARAM_NAMES, GLB_P, GUB_P), norm(S, synth.STATE_NAMES, GLB_S, GUB_S)
-    jobs0 = refbind.run("gr-b", mesh, DT, prcp, pet, qobs, Pn, Sn, params_bgd=Pn, states_bgd=Sn, denormalize_forward=True,
-                        wjreg=0.0, **kw)["cost_jobs"]
+    kf = dict(kw)
+    kf.update(params_bgd=Pn, states_bgd=Sn, denormalize_forward=True, wjreg=0.0)
+    jobs0 = refbind.run(structure, mesh, DT, prcp, pet, qobs, Pn, Sn, **kf)["cost_jobs"]
     d = dict(optim_parameters=op, qobs=qobs, maxiter=2, nb_wjreg_lcurve=8, cost_jobs_initial=np.float32(jobs0))
     for mode in ("fast", "lcurve"):
         log = []
 
         def run_cycle(w):
-            r = refbind.run("gr-b", mesh, DT, prcp, pet, qobs, P, S, optimize_maxiter=2, wjreg=float(w), **kw)
+            kc = dict(kw)
+            kc.update(optimize_maxiter=2, wjreg=float(w))
+            r = refbind.run(structure, mesh, DT, prcp, pet, qobs, P, S, **kc)
             log.append((float(w), r["cost"], r["cost_jobs"], r["cost_jreg"]))
             run_cycle.last = r
             return dict(cost=r["cost"], cost_jobs=r["cost_jobs"], cost_jreg=r["cost_jreg"], cost_jobs_initial=jobs0)
@@ -384,7 +382,21 @@ def main_auto_wjreg():
         d[mode + "_final_cp"] = run_cycle.last["parameters"]["cp"]
         if lcurve is not None:
             d["lcurve_distance"] = lcurve["distance"]
-        print(mode, "wjreg", w, "cycles", len(log), "final cost", log[-1][1])
+        print(tag, mode, "wjreg", w, "cycles", len(log), "final cost", log[-1][1])
+    return d
+
+
+def main_auto_wjreg():
+    """Row f2: the calibration cycles of auto_wjreg = 'fast' / 'lcurve' (core/simulation/_optimize.py:257-453) on the synthetic
+    gr-b case and on the real Cance data (the catchment of the reference's own test), plus input / output vectors of its two
+    helpers."""
+    c = [x for x in CASES if x["name"] == "gr_b_24x24x120_norm_jreg"][0]
+    mesh = synth.make_mesh(c["n"], c["n"], ng=c["ng"], mask_corner=c["mask"])
+    prcp, pet = synth.dense_forcing(mesh, c["nt"], gap_per_million=c["gaps"])
+    P, S = synth.make_parameters(c["n"], c["n"]), synth.make_states(c["n"], c["n"], warm=True)
+    Pq = synth.make_parameters(c["n"], c["n"], perturb=0.1)
+    qobs = refbind.run("gr-b", mesh, DT, prcp, pet, np.zeros((c["ng"], c["nt"]), np.float32), Pq, S)["qsim"].copy()
+    d = _auto_wjreg_case("gr-b 24x24", "gr-b", mesh, prcp, pet, qobs, P, S, dict(jobs_fun=("nse",), wjobs_fun=(1.0,)))
     # helper vectors straight from the reference's functions
     ref_range, ref_best = _reference_lcurve_helpers()
     wo = np.array([3.7e-4, 0.0123, 1.0, 25.0, 0.5], np.float64)
@@ -406,6 +418,19 @@ def main_auto_wjreg():
         d[f"pick_dist_{i}"], d[f"pick_best_{i}"] = np.asarray(dist, np.float32), np.float64(np.nan if best is None else best)
     d["pick_n"] = 6
     np.savez_compressed(os.path.join(OUT, "lbfgsb", "auto_wjreg_gr_b_24x24x120.npz"), **d)
+    # the real Cance data (60 days, hourly): from the model's default parameters (mwd_parameters.f90:150-167), as the reference's
+    # test does, and from the fixture's first guess (the uniform SBS optimum), where two iterations remove less than 5 % of the
+    # misfit and the L-curve has nothing to choose from (core/simulation/_optimize.py:332-341, 425-450)
+    sys.path.insert(0, os.path.dirname(OUT))
+    import golden_util as gu
+    g = gu.load("gr_a_cance_28x28x1440")
+    Pd = {k: np.asfortranarray(np.full((g.mesh.nrow, g.mesh.ncol), synth.PARAM_DEFAULTS[k], np.float32)) for k in synth.PARAM_NAMES}
+    dc = _auto_wjreg_case("cance defaults", g.structure, g.mesh, g.prcp, g.pet, g.qobs, Pd, g.states, dict(g.opts))
+    del dc["qobs"]
+    np.savez_compressed(os.path.join(OUT, "lbfgsb", "auto_wjreg_gr_a_cance.npz"), **dc)
+    dc = _auto_wjreg_case("cance sbs optimum", g.structure, g.mesh, g.prcp, g.pet, g.qobs, g.params, g.states, dict(g.opts))
+    del dc["qobs"]
+    np.savez_compressed(os.path.join(OUT, "lbfgsb", "auto_wjreg_gr_a_cance_flat.npz"), **dc)
 
 
 if __name__ == "__main__":

@@ -300,6 +300,44 @@ def test_optimize_lbfgsb_python_host():
     assert np.all(par.cp > 1.0)          # calibrated fields come back denormalised
 
 
+@pytest.mark.parametrize("start", ["defaults", "sbs"])
+@pytest.mark.parametrize("mode", ["fast", "lcurve"])
+def test_auto_wjreg_cycles_on_cance_vs_reference(mode, start):
+    """The reference's own auto_wjreg test (tests/core/test_simu.py:143-170) on its own catchment: the real Cance data, control cp,
+    cft, lr, prior + smoothing weighted 1 and 2, two iterations per cycle, 8 L-curve cycles -- from the model's default parameters
+    and from the uniform SBS optimum (there two iterations remove < 5 % of the misfit: the L-curve tries nothing, chooses nothing and
+    the model is left as it was).  Every cycle a smash_amd.optimize_lbfgsb over GPU sweeps, against the same cycles run by the
+    reference's optimize_lbfgsb (tests/golden/lbfgsb/auto_wjreg_gr_a_cance*.npz)."""
+    import os
+    import smash_amd
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "auto_wjreg_gr_a_cance" + ("" if start == "defaults" else "_flat") + ".npz"))
+    g = gu.load("gr_a_cance_28x28x1440")
+    g.opts = dict(g.opts, jreg_fun=("prior", "smoothing"), wjreg_fun=(1.0, 2.0), wjreg=0.0)
+    if start == "defaults":
+        g.params = {k: np.asfortranarray(np.full((g.mesh.nrow, g.mesh.ncol), synth.PARAM_DEFAULTS[k], np.float32)) for k in synth.PARAM_NAMES}
+    setup, mesh, inp, par, sta, out = _types(g)
+    setup.optimize.optim_parameters = np.asarray(z["optim_parameters"], np.int32)
+    setup.optimize.maxiter = int(z["maxiter"])
+    cp0 = par.cp.copy()
+    h = smash_amd.optimize_lbfgsb(setup, mesh, inp, par, sta, out, auto_wjreg=mode, nb_wjreg_lcurve=int(z["nb_wjreg_lcurve"]),
+                                  return_lcurve=True)
+    rec = z[mode + "_cycles"]
+    rel = lambda a, b: abs(a - b) / abs(b)
+    if np.isnan(z[mode + "_wjreg"]):
+        assert h["wjreg"] is None and h["lcurve"]["wjreg"].size == 1 and np.array_equal(par.cp, cp0)
+        assert rel(h["lcurve"]["cost_jobs"][0], rec[0, 2]) <= 2e-4
+        return
+    assert rel(h["wjreg"], float(z[mode + "_wjreg"])) <= 1e-3, (h["wjreg"], z[mode + "_wjreg"])
+    assert rel(out.cost, rec[-1, 1]) <= 5e-4 and rel(out.cost_jobs, rec[-1, 2]) <= 5e-4 and rel(out.cost_jreg, rec[-1, 3]) <= 2e-3, \
+        (out.cost, out.cost_jobs, out.cost_jreg, rec[-1])
+    assert gu.rel_l2(par.cp, z[mode + "_final_cp"]) <= 1e-4
+    if mode == "lcurve":
+        lc = h["lcurve"]
+        assert lc["wjreg"].size == len(rec) - 1 and np.allclose(lc["wjreg"], rec[:-1, 0], rtol=1e-3)
+        assert np.allclose(lc["cost_jobs"], rec[:-1, 2], rtol=5e-4) and np.allclose(lc["cost_jreg"], rec[:-1, 3], rtol=2e-3, atol=1e-9)
+        assert np.array_equal(np.isnan(lc["distance"]), np.isnan(z["lcurve_distance"]))
+
+
 @pytest.mark.parametrize("mode", ["fast", "lcurve"])
 def test_auto_wjreg_cycles_vs_reference(mode):
     """SURVEY row f2, the weight of the regularisation term found by calibration cycles (auto_wjreg, core/simulation/
