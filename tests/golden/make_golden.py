@@ -312,6 +312,24 @@ def main_lbfgsb_cance():
     print("lbfgsb cance costs:", costs)
 
 
+def main_lbfgsb_bounds_cance():
+    """The reference's "adjust bounds" test (tests/core/test_simu.py:128-140) on its own catchment: distributed L-BFGS-B over cp and
+    cft with cp bounded to [1, 300], one iteration from the model's default parameters; cost and the two calibrated fields."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import golden_util as gu
+    g = gu.load("gr_a_cance_28x28x1440")
+    Pd = {k: np.asfortranarray(np.full((g.mesh.nrow, g.mesh.ncol), synth.PARAM_DEFAULTS[k], np.float32)) for k in synth.PARAM_NAMES}
+    op = np.zeros(16, np.int32)
+    op[[1, 3]] = 1                                       # cp, cft
+    lb, ub = GLB_P.copy(), GUB_P.copy()
+    lb[1], ub[1] = 1.0, 300.0
+    r = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, Pd, g.states, optimize_maxiter=1, optim_parameters=op,
+                    lb_parameters=lb, ub_parameters=ub, **g.opts)
+    np.savez_compressed(os.path.join(OUT, "lbfgsb", "bounds_gr_a_cance.npz"), optim_parameters=op, lb_parameters=lb, ub_parameters=ub,
+                        cost=np.float32(r["cost"]), final_cp=r["parameters"]["cp"], final_cft=r["parameters"]["cft"], maxiter=1)
+    print("bounds cance: cost", r["cost"], "cp range", float(r["parameters"]["cp"].min()), float(r["parameters"]["cp"].max()))
+
+
 def main_sbs_cance():
     """The user guide's first calibration (real_case_cance.rst:396-430): mw_optimize::optimize_sbs, uniform cp, cft, exc, lr from
     the Model() defaults on the real Cance data, nse at the downstream gauge: cost after 0, 1, 2 iterations of the all-CPU
@@ -437,6 +455,9 @@ if __name__ == "__main__":
     if "--auto-wjreg" in sys.argv:
         main_auto_wjreg()
         sys.exit(0)
+    if "--bounds" in sys.argv:
+        main_lbfgsb_bounds_cance()
+        sys.exit(0)
     main()                              # python make_golden.py [case names...]: only those cases
     if not [a for a in sys.argv[1:] if not a.startswith("-")]:
         os.makedirs(os.path.join(OUT, "lbfgsb"), exist_ok=True)
@@ -446,3 +467,4 @@ if __name__ == "__main__":
         main_tangent()
         main_hyper()
         main_auto_wjreg()
+        main_lbfgsb_bounds_cance()

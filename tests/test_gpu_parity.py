@@ -300,6 +300,30 @@ def test_optimize_lbfgsb_python_host():
     assert np.all(par.cp > 1.0)          # calibrated fields come back denormalised
 
 
+def test_optimize_lbfgsb_with_adjusted_bounds_on_cance():
+    """The reference's "adjust bounds" test (tests/core/test_simu.py:128-140): distributed L-BFGS-B over cp and cft on the Cance
+    data with cp bounded to [1, 300], one iteration from the default parameters; cost and both calibrated fields against the
+    reference's optimize_lbfgsb (tests/golden/lbfgsb/bounds_gr_a_cance.npz).  The bounds enter through the normalisation of the
+    control (mwd_parameters_manipulation.f90:154-178), so a wrong bound moves every cell."""
+    import os
+    import smash_amd
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "bounds_gr_a_cance.npz"))
+    g = gu.load("gr_a_cance_28x28x1440")
+    g.params = {k: np.asfortranarray(np.full((g.mesh.nrow, g.mesh.ncol), synth.PARAM_DEFAULTS[k], np.float32)) for k in synth.PARAM_NAMES}
+    setup, mesh, inp, par, sta, out = _types(g)
+    o = setup.optimize
+    o.optim_parameters = np.asarray(z["optim_parameters"], np.int32)
+    o.lb_parameters, o.ub_parameters = np.asarray(z["lb_parameters"], np.float32), np.asarray(z["ub_parameters"], np.float32)
+    o.maxiter = int(z["maxiter"])
+    h = smash_amd.optimize_lbfgsb(setup, mesh, inp, par, sta, out)
+    assert abs(h["final_cost"] - float(z["cost"])) <= 1e-5 * abs(float(z["cost"])), (h["final_cost"], z["cost"])
+    act = np.asarray(g.mesh.active_cell) == 1
+    assert np.max(np.abs(par.cp[act] - z["final_cp"][act])) <= 1e-4 * 200.0, np.max(np.abs(par.cp[act] - z["final_cp"][act]))
+    assert np.max(np.abs(par.cft[act] - z["final_cft"][act])) <= 1e-4 * 500.0
+    assert np.ptp(par.cp[act]) > 0.5                    # the step really moved the field
+    assert np.all(par.cp[act] <= 300.0) and np.all(par.cp[act] >= 1.0)
+
+
 @pytest.mark.parametrize("start", ["defaults", "sbs"])
 @pytest.mark.parametrize("mode", ["fast", "lcurve"])
 def test_auto_wjreg_cycles_on_cance_vs_reference(mode, start):
