@@ -6,8 +6,10 @@ hourly x 1 yr forcing resident in HBM (BASELINE.json metric; SURVEY.md section 8
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one forward+adjoint sweep of the hot path over the whole (grid x nt) batch.
-  N = 1   BASELINE.json configs[2]: 1024 x 1024 grid, 8760 steps, gr-b, store-all adjoint.  The same line carries a
-          "secondary" object: the 2048 x 2048 grid of configs[3] on the one GPU (checkpointed adjoint).
+  N = 1   the largest single-GPU configuration of BASELINE.json: the 2048 x 2048 grid of configs[3], 8760 steps, gr-b, compact
+          forcing resident, adjoint checkpointed in storage chunks.  The same line carries "secondary" (configs[2]: 1024 x 1024,
+          store-all adjoint), "tile_solo" (the 2048 x 1024 tile one GPU owns in the 8-GPU decomposition of configs[4], alone:
+          the like-for-like base of the N > 1 lines), "exact_libm" (the bit-exact build) and "cpu_baseline".
   N > 1   one process per GPU, every GPU owns a 2048 x 1024 tile: 1x2, 2x2, 2x4 tiles = 2048x2048, 4096x2048 and, at
           N = 8, the 4096 x 4096 grid the metric is quoted on (configs[4]).  Boundary discharge series move between the
           tiles with grouped ncclSend / ncclRecv posted by the library itself on its routing stream (RCCL over xGMI);
@@ -36,22 +38,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 N_SIMD, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs
 VALU_CYCLES = 2.0                # a wave64 fp32 instruction on the 32-lane SIMD when another wave is ready (MI355X_MICROARCH.md "Per-instruction
-                                 # cycle constants"; one wave alone issues every 4 cycles; fp64 4, transcendentals 8: the true ceiling is lower)
+                                 # cycle constants"; one wave alone issues every 4 cycles)
+VALU_CYCLES_F64, VALU_CYCLES_TRANS = 4.0, 8.0    # fp64 at half rate; v_rcp / v_rsq / v_sqrt / v_exp / v_log at quarter rate (same table)
 KERNELS = ("vert_fwd", "route_fwd", "route_adj", "vert_adj")
 
 
-def pmc_profile():
+def pmc_profile(grid, n_chunks):
     """Counters of the committed rocprofv3 --pmc passes over this very command (tools/profile_round.sh): bench.py cannot
     collect PMC itself.  Per kernel: HBM bytes per cell-step (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md)
-    and VALU wave-instructions per cell-step (SQ_INSTS_VALU).  The newest profiles/r*_pmc_traffic.json wins."""
+    and VALU wave-instructions per cell-step (SQ_INSTS_VALU).  The newest profiles/r*_pmc_traffic*.json taken on THIS workload
+    (same grid, same number of storage chunks: a checkpointed adjoint moves other bytes than a store-all one) wins; files
+    without a workload tag are the 1024 x 1024 store-all case of rounds 1-2."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files:
-        return None, {}
-    try:
-        return os.path.relpath(files[-1], ROOT), json.load(open(files[-1]))
-    except Exception:
-        return None, {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        w = d.get("workload", {"grid": [1024, 1024], "n_chunks": 1})
+        if list(w.get("grid", [])) == list(grid) and int(w.get("n_chunks", 0)) == int(n_chunks):
+            return os.path.relpath(f, ROOT), d
+    return None, {}
 
 
 def parse(argv=None):
@@ -59,7 +66,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--grid", type=int, default=0, help="square per-GPU tile (default: 1024 at N = 1)")
+    ap.add_argument("--grid", type=int, default=0, help="square per-GPU tile (default at N = 1: 2048, the largest single-GPU configuration)")
     ap.add_argument("--tile-rows", type=int, default=0, help="per-GPU tile rows (default at N > 1: 2048 x 1024, so 8 GPUs hold the 4096^2 grid)")
     ap.add_argument("--tile-cols", type=int, default=0)
     ap.add_argument("--pipe", type=int, default=0, help="pipeline sub-chunk (default: none on 1 GPU; tiles: 2192 up to 4 ranks, 1104 at 8)")
@@ -82,13 +89,24 @@ def parse(argv=None):
     ap.add_argument("--raw-forcing", action="store_true", help="keep the forcing as fp32 (no lossless compaction)")
     ap.add_argument("--trace-groups", default="", help="diagnostics: write per-round start/end times of the routing groups (JSON) here")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the 2048 x 2048 measurement attached to the line")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip the 1024 x 1024 store-all measurement attached to the line")
+    ap.add_argument("--no-tile-solo", action="store_true", help="N = 1: skip the 2048 x 1024 tile of the 8-GPU decomposition timed alone")
+    ap.add_argument("--no-inclusive", action="store_true", help="N = 1: skip the upload + sweep + download calls (inclusive_ms_per_step)")
+    ap.add_argument("--profile", action="store_true", help="the headline case only, nothing attached and no child process: what "
+                    "tools/profile_round.sh runs under rocprofv3")
     ap.add_argument("--no-exact", action="store_true", help="N = 1: skip the run of the exact-libm build attached to the line")
-    ap.add_argument("--secondary-grid", type=int, default=2048)
+    ap.add_argument("--secondary-grid", type=int, default=1024)
     ap.add_argument("--cpu-grid", type=int, default=256)
     ap.add_argument("--cpu-nt", type=int, default=360)
     ap.add_argument("--cpu-cores", type=int, default=0, help="replicas of the CPU baseline (default: the box's CPU share, at most 16)")
-    return ap.parse_args(argv)
+    ap.add_argument("--cpu-solo-grid", type=int, default=512, help="the one-replica CPU measurement: grid (its tape leaves every cache level)")
+    ap.add_argument("--cpu-solo-nt", type=int, default=160)
+    a = ap.parse_args(argv)
+    if a.profile:
+        a.no_secondary = a.no_tile_solo = a.no_exact = a.no_cpu_baseline = a.no_inclusive = True
+        if a.gpus != 1:
+            ap.error("--profile is a single-process run")
+    return a
 
 
 def _cpu_replica(structure, n, nt, barrier, q):
@@ -113,16 +131,8 @@ def _cpu_replica(structure, n, nt, barrier, q):
     q.put((kind, m.nac * nt, time.perf_counter() - t0))
 
 
-def cpu_baseline(structure, n, nt, cores=0):
-    """The reference path timed on the host cores of this box, on a bounded sample of the same synthetic workload:
-    forward_b (cost + gradient) on an n x n catchment over nt steps.  forward_b is single-threaded
-    (mw_forward.f90:41-68; no OpenMP in it), so the host is filled the way the reference fills it
-    (mw_multiple_run.f90:96-107): one independent replica per core, started together; value = all replicas' work /
-    the slowest replica's time."""
+def _cpu_replicas(structure, n, nt, cores):
     import multiprocessing as mp
-    # the CPU share of a one-GPU box is 16 cores whatever the affinity mask says; a replica holds ~2 GB (the reference's
-    # tape is 40 B per cell-step), so the pool is sized to that share and never to the machine
-    cores = cores or max(1, min(len(os.sched_getaffinity(0)), 16))
     ctx = mp.get_context("spawn")                       # no fork of a process that holds a HIP context
     barrier, q = ctx.Barrier(cores), ctx.Queue()
     procs = [ctx.Process(target=_cpu_replica, args=(structure, n, nt, barrier, q)) for _ in range(cores)]
@@ -131,14 +141,38 @@ def cpu_baseline(structure, n, nt, cores=0):
     res = [q.get(timeout=900) for _ in procs]
     for p in procs:
         p.join()
+    return res
+
+
+def cpu_baseline(structure, n, nt, cores=0, solo_n=512, solo_nt=160):
+    """The reference path timed on the host cores of this box, on bounded samples of the same synthetic workload:
+    forward_b (cost + gradient) on an n x n catchment over nt steps.  forward_b is single-threaded
+    (mw_forward.f90:41-68; no OpenMP in it), so SURVEY.md 8d asks for both ways of using the host:
+      (ii) filled the way the reference fills it (mw_multiple_run.f90:96-107): one independent replica per core, started
+           together; value = all replicas' work / the slowest replica's time (the line's `value`);
+      (i)  `solo_core`: ONE replica on an otherwise idle box share, on a window whose tape (40 B per cell-step, adStack.c)
+           is far beyond the last-level cache."""
+    # the CPU share of a one-GPU box is 16 cores whatever the affinity mask says; a replica holds ~2 GB (the reference's
+    # tape is 40 B per cell-step), so the pool is sized to that share and never to the machine
+    cores = cores or max(1, min(len(os.sched_getaffinity(0)), 16))
+    res = _cpu_replicas(structure, n, nt, cores)
     kind = res[0][0]
     work, slow = sum(r[1] for r in res), max(r[2] for r in res)
     what = ("reference Fortran (flang -O3, libsmash_ref_fast.so) forward_b" if kind == "reference"
             else "plain-C oracle (gcc -O2) forward_b")
-    return {"value": work / slow, "unit": "cell-timesteps/s", "cores": cores, "kind": kind,
-            "per_core_value": float(np.mean([r[1] / r[2] for r in res])),
-            "sample": f"{what}, {structure}, {cores} independent replicas (one per core) of a {n}x{n} synthetic catchment x {nt} "
-                      f"hourly steps, slowest replica {slow:.1f} s"}
+    out = {"value": work / slow, "unit": "cell-timesteps/s", "cores": cores, "kind": kind,
+           "per_core_value": float(np.mean([r[1] / r[2] for r in res])),
+           "sample": f"{what}, {structure}, {cores} independent replicas (one per core) of a {n}x{n} synthetic catchment x {nt} "
+                     f"hourly steps, slowest replica {slow:.1f} s"}
+    if solo_n > 0 and solo_nt > 0:
+        try:
+            k1, w1, s1 = _cpu_replicas(structure, solo_n, solo_nt, 1)[0]
+            out["solo_core"] = {"value": w1 / s1, "unit": "cell-timesteps/s", "cores": 1, "kind": k1,
+                                "sample": f"{what}, {structure}, ONE replica alone on the box share: {solo_n}x{solo_n} cells x {solo_nt} hourly "
+                                          f"steps ({w1 * 40e-9:.1f} GB of adStack tape, {w1 * 8e-9:.2f} GB of forcing: nothing stays in cache), {s1:.1f} s"}
+        except Exception as e:  # pragma: no cover
+            out["solo_core"] = {"value": None, "error": str(e)}
+    return out
 
 
 def self_launch(a, argv):
@@ -320,9 +354,10 @@ def inclusive_call_ms(case, adjoint, reps=3):
     return (time.perf_counter() - t0) * 1e3 / reps
 
 
-def roofline(tm, adjoint, structure):
+def roofline(tm, adjoint, structure, grid):
     """Dominant kernel against both ceilings: HBM (algorithmic bytes: prcp + pet = 8 B per cell-step per vertical pass,
-    SURVEY.md 8d) and VALU issue (wave-instructions per cell-step from the committed PMC pass x 4 cycles on 1024 SIMDs)."""
+    SURVEY.md 8d) and VALU issue (wave-instructions per cell-step from the committed PMC pass of THIS workload, priced at
+    2 cycles per wave64 fp32 instruction on 1024 SIMDs and -- `weighted` -- at the 2 / 4 / 8-cycle mix of the kernel's loop)."""
     ms = {k: tm[k + "_ms"] for k in KERNELS}
     dom = max(ms, key=ms.get)
     n_launch = max(tm[dom + "_launches"], 1.0)
@@ -331,24 +366,53 @@ def roofline(tm, adjoint, structure):
     per_cs = 8.0 if dom.startswith("vert") else 4.0               # routing reads qt once: it is not a streaming kernel of the forcing
     alg_bytes = per_cs * cs_launch
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    src, prof = pmc_profile()
+    src, prof = pmc_profile(grid, tm["n_chunks"])
     pk = prof.get("sx_k_" + dom) if structure == "gr-b" else None
     traffic = pk["hbm_bytes_per_cellstep_corrected"] * cs_launch if pk and "hbm_bytes_per_cellstep_corrected" in pk else None
     r = {"bound": "hbm", "kernel": "sx_k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-         "traffic_source": (f"{src}: rocprofv3 --pmc passes of this command, bytes per cell-step scaled to this run's launch" if traffic else None),
+         "traffic_source": (f"{src}: rocprofv3 --pmc passes of this command (FETCH_SIZE x2 + WRITE_SIZE over every launch of the kernel, "
+                            "per cell-step), times the cell-steps of one launch" if traffic else None),
          "avg_launch_ms": avg_ms, "launches_per_step": n_launch, "cellsteps_per_launch": cs_launch,
          "algorithmic_bytes_per_launch": alg_bytes,
          "sweep_frac": (16.0 if adjoint else 8.0) * tm["vert_adj_cellsteps" if adjoint else "vert_fwd_cellsteps"] / (tm["sweep_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
     if pk and "valu_per_cellstep" in pk:
-        issue_ms = pk["valu_per_cellstep"] * cs_launch / 64.0 * VALU_CYCLES / (N_SIMD * CLOCK_HZ) * 1e3
+        waves = pk["valu_per_cellstep"] * cs_launch / 64.0
+        issue_ms = waves * VALU_CYCLES / (N_SIMD * CLOCK_HZ) * 1e3
         r["valu"] = {"instr_per_cellstep": pk["valu_per_cellstep"], "issue_bound_ms": issue_ms, "frac": issue_ms / avg_ms,
                      "wave_cycles_share": pk.get("wave_cycles_share"),
                      "note": "SQ_INSTS_VALU per cell-step (committed PMC pass) x 2 cycles per wave64 fp32 instruction on 1024 SIMDs at 2.4 GHz "
-                             "= the time the vector units need at their fp32 peak rate; frac = that time / the launch time.  fp64 and "
-                             "transcendental instructions (a fifth of the mix) take 4 and 8 cycles: this ceiling, not HBM, is the one the "
-                             "reverse kernel runs against"}
+                             "= the time the vector units need at their fp32 peak rate; frac = that time / the launch time"}
+        mix = pk.get("valu_mix_per_cellstep")
+        if mix:       # dynamic mix from the SQ_INSTS_VALU_{ADD,MUL,FMA}_F64 / _TRANS_F32 / _TRANS_F64 counters of the same profile
+            n64, ntr = mix.get("f64", 0.0), mix.get("trans", 0.0)
+            n32 = max(pk["valu_per_cellstep"] - n64 - ntr, 0.0)
+            cyc = (n32 * VALU_CYCLES + n64 * VALU_CYCLES_F64 + ntr * VALU_CYCLES_TRANS) / pk["valu_per_cellstep"]
+            w_ms = waves * cyc / (N_SIMD * CLOCK_HZ) * 1e3
+            r["valu"]["weighted"] = {"issue_bound_ms": w_ms, "frac": w_ms / avg_ms, "cycles_per_instr": cyc,
+                                     "mix_per_cellstep": {"fp32_and_int": n32, "fp64": n64, "transcendental": ntr},
+                                     "note": "the same count priced at the executed mix (PMC): fp32 / integer 2, fp64 add / mul / fma 4, "
+                                             "transcendental (v_rcp / v_rsq / v_sqrt / v_exp / v_log) 8 cycles per wave64 instruction "
+                                             "(MI355X_MICROARCH.md, per-instruction cycle constants): the ceiling this kernel runs against"}
     return r
+
+
+def attached_case(a, torch, dev, local, barrier, adjoint, grid_rc, parts, me, solo, steps, warmup, what):
+    """One more workload measured in this process after the headline case has been closed: returns the object attached to the line."""
+    try:
+        c = Case(a, torch, dev, local, parts, me, 1, grid_rc[0], grid_rc[1], solo, False)
+        secs, tm = timed_sweeps(c, steps, warmup, adjoint, barrier)
+        o = {"workload": what, "value": float(c.sol.ncells) * a.nt * steps / secs, "unit": "cell-timesteps/s", "steps": steps, "warmup": warmup,
+             "ms_per_step": secs * 1e3 / steps, "grid": [c.nrow, c.ncol], "tile": list(grid_rc), "active_cells": int(c.sol.ncells),
+             "n_chunks": int(tm["n_chunks"]), "chunk_steps": int(tm["chunk_steps"]), "pipe_steps": int(tm["pipe_steps"]),
+             "routing_rounds": int(tm["n_rounds"]), "hbm_plan_gb": tm["device_bytes"] / 1e9, "forcing": c.forcing,
+             "kernel_ms_per_step": {"sx_k_" + k: round(tm[k + "_ms"], 3) for k in KERNELS},
+             "kernel_launches_per_step": {"sx_k_" + k: int(tm[k + "_launches"]) for k in KERNELS},
+             "roofline": roofline(tm, adjoint, a.structure, [c.nrow, c.ncol]) if parts == 1 else None, "setup_s": c.setup_s}
+        c.close()
+        return o
+    except Exception as e:  # pragma: no cover
+        return {"workload": what, "value": None, "error": str(e)}
 
 
 def main():
@@ -363,7 +427,7 @@ def main():
     cpu = None
     if not a.no_cpu_baseline and world == 1:
         try:
-            cpu = cpu_baseline(a.structure, a.cpu_grid, a.cpu_nt, a.cpu_cores)
+            cpu = cpu_baseline(a.structure, a.cpu_grid, a.cpu_nt, a.cpu_cores, a.cpu_solo_grid, a.cpu_solo_nt)
         except Exception as e:  # pragma: no cover
             cpu = {"value": None, "unit": "cell-timesteps/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     import torch
@@ -397,7 +461,9 @@ def main():
     elif a.grid:
         trows = tcols = a.grid
     else:
-        trows, tcols = (1024, 1024) if parts == 1 else (2048, 1024)
+        # N = 1: the largest configuration of BASELINE.json that one GPU holds (configs[3]'s 2048^2 grid: compact forcing +
+        # checkpointed adjoint, 258 of the 288 GB); N > 1: the 2048 x 1024 tile of configs[4]'s 2 x 4 decomposition
+        trows, tcols = (2048, 2048) if parts == 1 else (2048, 1024)
     adjoint = not a.forward_only
     nt = a.nt
 
@@ -428,7 +494,7 @@ def main():
             ct = torch.tensor([cost], dtype=torch.float64, device=cdev)
             dist.all_reduce(ct, op=dist.ReduceOp.SUM)
             cost = float(ct.item())
-    inclusive = inclusive_call_ms(case, adjoint) if world == 1 and not solo else None
+    inclusive = inclusive_call_ms(case, adjoint) if world == 1 and not solo and not a.no_inclusive else None
 
     if rank == 0 and a.trace_groups:
         ticks, rnd = sol.group_times()
@@ -460,7 +526,10 @@ def main():
             "config": {"workload": f"{nrow}x{ncol} synthetic catchment ({trows}x{tcols} cells per GPU, D8 E/SE/S, all cells active), "
                                    f"hourly x {nt} steps, {a.structure}, nse cost at {a.ng} gauges, one forward+adjoint sweep = cost + "
                                    "gradient of all distributed parameters and initial states "
-                                   + ("(BASELINE.json configs[2])" if world == 1 else
+                                   + ("(the grid of BASELINE.json configs[3], the largest configuration one GPU holds: compact forcing resident, "
+                                      "adjoint checkpointed in storage chunks)" if world == 1 and (nrow, ncol) == (2048, 2048) else
+                                      "(BASELINE.json configs[2])" if world == 1 and (nrow, ncol) == (1024, 1024) else
+                                      "" if world == 1 else
                                       "(BASELINE.json configs[4]: the metric's 4096^2 grid)" if (nrow, ncol) == (4096, 4096) else
                                       "(the per-GPU tile of BASELINE.json configs[4], fewer tiles)"),
                        "grid": [nrow, ncol], "tile": [trows, tcols], "nt": nt, "structure": a.structure, "active_cells": int(cellsteps / nt),
@@ -471,38 +540,52 @@ def main():
                                        ((f"tiles {pr}x{pc}" if a.partition == "rect" else f"{parts} {a.partition} parts of the river tree") +
                                         f", boundary discharge series by {xch}" + (", ranks share GPUs (rehearsal)" if shared else ""))
                                        if world > 1 else "single")},
-            "roofline": roofline(tm, adjoint, a.structure),
+            "roofline": roofline(tm, adjoint, a.structure, [nrow, ncol]),
             "kernel_ms_per_step": {"sx_k_" + k: round(tm[k + "_ms"], 3) for k in KERNELS},
+            "kernel_launches_per_step": {"sx_k_" + k: int(tm[k + "_launches"]) for k in KERNELS},
+            "kernel_cellsteps_per_step": {"sx_k_" + k: tm[k + "_cellsteps"] for k in KERNELS},
             "device_sweep_ms": tm["sweep_ms"], "cost": cost, "setup_s": case.setup_s,
             "hbm_plan_gb": tm["device_bytes"] / 1e9,
         }
+        if a.profile:
+            # what tools/pmc_summary.py divides the counters by: every sweep this process ran, and the cell-steps each kernel
+            # family processed in them (a storage chunk but the last is swept forward twice: untaped, then taped for the reverse sweep)
+            C_, Tc_ = int(tm["n_chunks"]), int(tm["chunk_steps"])
+            ncell = cellsteps / nt
+            untaped = ncell * (C_ - 1) * Tc_ if adjoint else cellsteps
+            line["profile_accounting"] = {
+                "adjoint_sweeps": (a.warmup + K) if adjoint else 0, "forward_sweeps": 1 + (0 if adjoint else a.warmup + K),
+                "cellsteps": cellsteps, "grid": [nrow, ncol], "n_chunks": C_, "chunk_steps": Tc_,
+                "per_adjoint_sweep": {"taped_forward": cellsteps, "untaped_forward": untaped, "reverse": cellsteps},
+                "per_forward_sweep": {"untaped_forward": cellsteps}}
         if inclusive is not None:
             line["inclusive_ms_per_step"] = inclusive
             line["inclusive_note"] = ("one smashx_forward_b-style call: host parameter/state planes uploaded, sweep, cost + discharge + every "
                                       "gradient plane downloaded; `value` is the resident-input rate (forcing upload is one-off set-up)")
         if cpu is not None:
             line["cpu_baseline"] = cpu
-    # N = 1: the 2048 x 2048 grid of configs[3] on the same GPU, attached to the line (checkpointed adjoint; needs the compact forcing)
-    if world == 1 and not solo and not a.no_secondary and not a.raw_forcing and (trows, tcols) == (1024, 1024) and nt == 8760 and a.secondary_grid > 0:
+    # N = 1, default workload: two more cases measured on the same GPU and attached to the line
+    default_case = world == 1 and not solo and not a.raw_forcing and (trows, tcols) == (2048, 2048) and nt == 8760 and line is not None
+    if default_case and not (a.no_secondary and a.no_tile_solo):
         case.close()
         del case, sol
-        g = a.secondary_grid
-        try:
-            c2 = Case(a, torch, dev, local, 1, 0, 1, g, g, False, False)
-            s2, tm2 = timed_sweeps(c2, 2, 1, adjoint, barrier)
-            line["secondary"] = {
-                "workload": f"{g}x{g} synthetic catchment on ONE GPU (the grid of BASELINE.json configs[3]), hourly x {nt} steps, {a.structure}, "
-                            "one forward+adjoint sweep; forcing compact and resident, adjoint checkpointed in storage chunks",
-                "value": float(c2.sol.ncells) * nt * 2 / s2, "unit": "cell-timesteps/s", "steps": 2, "warmup": 1, "ms_per_step": s2 * 1e3 / 2,
-                "n_chunks": int(tm2["n_chunks"]), "chunk_steps": int(tm2["chunk_steps"]), "hbm_plan_gb": tm2["device_bytes"] / 1e9,
-                "forcing": c2.forcing, "kernel_ms_per_step": {"sx_k_" + k: round(tm2[k + "_ms"], 3) for k in KERNELS},
-                "roofline": roofline(tm2, adjoint, a.structure), "setup_s": c2.setup_s}
-            c2.close()
-        except Exception as e:  # pragma: no cover
-            line["secondary"] = {"workload": f"{g}x{g}", "value": None, "error": str(e)}
+        if not a.no_secondary and a.secondary_grid > 0:
+            g = a.secondary_grid
+            line["secondary"] = attached_case(
+                a, torch, dev, local, barrier, adjoint, (g, g), 1, 0, False, min(a.steps, 5), 1,
+                f"{g}x{g} synthetic catchment (BASELINE.json configs[2]), hourly x {nt} steps, {a.structure}, one forward+adjoint sweep; "
+                "store-all adjoint (one storage chunk, nothing recomputed)")
+        if not a.no_tile_solo:
+            o = attached_case(
+                a, torch, dev, local, barrier, adjoint, (2048, 1024), 8, 0, True, min(a.steps, 5), 1,
+                "rank 0's 2048x1024 tile of the 2x4 decomposition of the 4096x4096 grid (BASELINE.json configs[4]), alone on this GPU: "
+                "no-op exchange, zero inflow, the chunking and sub-chunk pipeline of the 8-rank run -- the per-GPU work of every "
+                "`--gpus N` line, so value(N) / (N x this value) is the price of the decomposition's pipeline and exchange")
+            o["per_gpu_value"] = o.get("value")
+            line["tile_solo"] = o
     # N = 1: the same workload on the exact-libm build (libsmashx_exact.so: bit-identical to the reference on every golden vector),
     # in a child process -- the library is chosen when smash_amd is imported
-    if (world == 1 and not solo and not a.no_exact and line is not None and (trows, tcols) == (1024, 1024) and nt == 8760
+    if (default_case and not a.no_exact
             and os.environ.get("SMASHX_EXACT_LIBM", "0") in ("", "0") and os.path.exists(os.path.join(ROOT, "smash_amd", "libsmashx_exact.so"))):
         import subprocess
         if "case" in locals():                       # the child needs the HBM this process still holds
@@ -510,11 +593,11 @@ def main():
             del case, sol
         torch.cuda.empty_cache()
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary",
-                                "--no-exact", "--structure", a.structure], env=dict(os.environ, SMASHX_EXACT_LIBM="1"), capture_output=True,
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--profile", "--grid", "1024",
+                                "--structure", a.structure], env=dict(os.environ, SMASHX_EXACT_LIBM="1"), capture_output=True,
                                text=True, timeout=600)
             e = json.loads(r.stdout.strip().splitlines()[-1])
-            line["exact_libm"] = {"what": "same workload on libsmashx_exact.so (-DSX_EXACT_LIBM=1: glibc 2.35 expf/logf/powf/tanhf restated, IEEE divisions): "
+            line["exact_libm"] = {"what": "the 1024x1024 workload of `secondary` on libsmashx_exact.so (-DSX_EXACT_LIBM=1: glibc 2.35 expf/logf/powf/tanhf restated, IEEE divisions): "
                                           "bit-identical to the reference Fortran on all 318 golden outputs (profiles/r2_parity_exact.md); the "
                                           "default build differs from it by libm rounding only (profiles/r2_parity_default.md)",
                                   "value": e["value"], "ms_per_step": e["ms_per_step"], "steps": 2, "warmup": 1, "cost": e["cost"],

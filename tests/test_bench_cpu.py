@@ -31,14 +31,34 @@ def test_roofline_uses_the_cell_steps_one_launch_processes():
     cs = 1024.0 * 1024 * 8760
     tm = {"vert_fwd_ms": 40.0, "route_fwd_ms": 25.0, "route_adj_ms": 28.0, "vert_adj_ms": 72.0, "sweep_ms": 170.0,
           "vert_fwd_launches": 8, "route_fwd_launches": 16, "route_adj_launches": 16, "vert_adj_launches": 8,
-          "vert_fwd_cellsteps": cs, "route_fwd_cellsteps": cs, "route_adj_cellsteps": cs, "vert_adj_cellsteps": cs}
-    r = bench.roofline(tm, True, "gr-b")
+          "vert_fwd_cellsteps": cs, "route_fwd_cellsteps": cs, "route_adj_cellsteps": cs, "vert_adj_cellsteps": cs, "n_chunks": 1}
+    r = bench.roofline(tm, True, "gr-b", [1024, 1024])
     assert r["kernel"] == "sx_k_vert_adj" and r["launches_per_step"] == 8
     assert abs(r["cellsteps_per_launch"] - cs / 8) < 1 and abs(r["algorithmic_bytes_per_launch"] - 8 * cs / 8) < 8
     assert abs(r["achieved"] - 8 * cs / 72e-3 / 1e9) < 1e-6 * r["achieved"]          # same GB/s as one whole-period launch of 72 ms
     assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
     if "valu" in r:
         assert 0 < r["valu"]["frac"] < 1.5
+        if "weighted" in r["valu"]:          # fp64 / transcendental instructions only ever raise the ceiling's time
+            assert r["valu"]["weighted"]["issue_bound_ms"] >= r["valu"]["issue_bound_ms"]
+
+
+def test_pmc_profile_is_matched_to_the_workload():
+    """A committed counter file is only attached to a run of the workload it was taken on (the 2048^2 line carried the
+    1024^2 store-all traffic figure)."""
+    import bench
+    src, prof = bench.pmc_profile([1024, 1024], 1)
+    assert src is not None and "sx_k_vert_adj" in prof
+    src2, prof2 = bench.pmc_profile([4096, 4096], 1)
+    assert src2 is None and prof2 == {}
+
+
+def test_default_single_gpu_workload_is_the_largest_configuration():
+    import bench
+    a = bench.parse([])
+    assert a.gpus == 1 and a.grid == 0 and a.secondary_grid == 1024
+    p = bench.parse(["--profile"])
+    assert p.no_secondary and p.no_tile_solo and p.no_exact and p.no_cpu_baseline and p.no_inclusive
 
 
 def test_bench_self_launch_reaches_the_rendezvous_without_a_gpu():
