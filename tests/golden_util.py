@@ -66,21 +66,43 @@ def load(name):
     return g
 
 
+CAP = 1e-4                      # no default-build assertion has a bar above this
+UNASSERTED = float("inf")       # bar of an output that only the exact-libm build is held to (bit-identity, tests/test_gpu_exact.py)
+
+
 def tol(noise, base=1e-6, k=3.0):
     """Parity bar for one output: 1e-6 relative (BASELINE.json north_star), relaxed -- only where the
     reference cannot do better itself -- to k = 3 times the reference's own flag-to-flag noise on that very
     output (its makefile's -O3 + FMA build against the -O2 -ffp-contract=off parity build, stored by
-    make_golden.py; the factor covers that the stored noise is a single sample of a random quantity)."""
-    return max(base, k * float(noise))
+    make_golden.py; the factor covers that the stored noise is a single sample of a random quantity).
+    The bar is capped: where 3x the reference's own noise exceeds CAP = 1e-4 the output is ill-conditioned in fp32 (cold-start
+    stores, run-time exponents of vic-a: the reference's two builds disagree by 3e-5 .. 9e-1 there, and both are 1e-3 .. 3e+1
+    away from the fp64 truth, profiles/r3_accuracy_vs_fp64.md) and a relative bar says nothing about the default build; such
+    an output is NOT asserted in the default build (UNASSERTED) and is held to BIT-IDENTITY with the reference in the exact-libm
+    build instead (tests/test_gpu_exact.py asserts all 318 outputs).  tests/test_oracle_golden.py pins the list of such outputs."""
+    bar = max(base, k * float(noise))
+    return bar if bar <= CAP else UNASSERTED
+
+
+def unasserted_outputs(g):
+    """Names of the outputs of fixture g whose default-build bar is UNASSERTED (see tol)."""
+    out = [f"qsim[{i}]" for i, v in enumerate(g.noise["qsim"]) if tol(v) == UNASSERTED]
+    if tol(g.noise["cost"]) == UNASSERTED:
+        out.append("cost")
+    for grp in ("fstates", "parameters_b", "states_b"):
+        names = STRUCT_PARAMS[g.structure] if grp == "parameters_b" else STRUCT_STATES[g.structure]
+        out += [f"{grp}.{k}" for k in names if tol(g.noise[grp][k]) == UNASSERTED]
+    return out
 
 
 # On noise-dominated outputs (cold-start fixtures: the reference's two builds differ by 1e-2..1e-1 on a few cells whose transfer
-# store is nearly empty) this bar is wide, and a ceiling does not help: the default build of the kernels differs from the reference
-# there by 5e-2 on two cells of one field, for the same reason the reference differs from itself (a last-bit difference in powf,
-# amplified).  What makes the bar non-vacuous is the exact-libm build: with glibc's float functions restated it is held to
-# BIT-IDENTITY with the reference on every output of every fixture, forward and adjoint (tests/test_gpu_exact.py;
-# profiles/r2_parity_exact.md: 160 / 160 forward outputs and 158 / 158 gradient fields identical), so every difference the default
-# build shows (profiles/r2_parity_default.md) is libm rounding and nothing else.
+# store is nearly empty) the default build differs from the reference by up to 5e-2 on two cells of one field, for the same reason
+# the reference differs from itself (a last-bit difference in powf, amplified).  Those outputs are checked where a check means
+# something: the exact-libm build, with glibc's float functions restated, is held to BIT-IDENTITY with the reference on every
+# output of every fixture, forward and adjoint (tests/test_gpu_exact.py; profiles/r2_parity_exact.md: 160 / 160 forward outputs and
+# 158 / 158 gradient fields identical), so every difference the default build shows is libm rounding and nothing else -- and the
+# fp64 truth (oracle/liboracle64.so, profiles/r3_accuracy_vs_fp64.md) shows the default build no farther from the exact answer
+# than the reference itself.
 
 
 def tol_cost(noise, cost):

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Accuracy of the fp32 builds against a common fp64 truth, every output field of every golden fixture.
+
+    python tools/accuracy_report.py [--out FILE.md] [--json FILE.json] [--no-gpu] [name-substring ...]
+
+truth     = oracle/liboracle64.so: the reference's statements evaluated in double on the same fp32 inputs (oracle/Makefile FP64_DEFS)
+reference = the golden vectors: the unmodified reference Fortran, flang -O2 -ffp-contract=off (tests/golden/*.npz)
+ref -O3   = the reference built the way its own makefile builds it (-O3 + FMA contraction), oracle/_ref/libsmash_ref_fast.so, when present
+HIP       = libsmashx through the C ABI, in whichever build smash_amd loads (default, or SMASHX_EXACT_LIBM=1)
+
+Error = rel-L2 over the field against the truth.  The question the table answers: is the timed default build at
+least as close to the exact gradient as the reference itself is?  TEST / REPORT INFRASTRUCTURE: imports oracle/."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import golden_util as gu  # noqa: E402
+from oracle import pyoracle, refbind  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="")
+    ap.add_argument("--json", default="")
+    ap.add_argument("--no-gpu", action="store_true")
+    ap.add_argument("names", nargs="*")
+    a = ap.parse_args()
+    hip = not a.no_gpu
+    if hip:
+        from smash_amd import _lib
+        from test_gpu_parity import _run_adjoint, _run_forward
+    fast = refbind.available(fast=True)
+    rows = []
+    for name in gu.names():
+        if a.names and not any(s in name for s in a.names):
+            continue
+        g = gu.load(name)
+        kw = dict(g.opts)
+        t_f = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, fp64=True, **kw)
+        t_b = pyoracle.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, adjoint=True, fp64=True, **kw)
+        f_f = f_b = None
+        if fast:
+            f_f = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, fast=True, **kw)
+            f_b = refbind.run(g.structure, g.mesh, g.dt, g.prcp, g.pet, g.qobs, g.params, g.states, adjoint=True, fast=True, **kw)
+        h_out = h_pb = h_sb = h_outb = None
+        if hip:
+            _, _, h_out = _run_forward(g)
+            _, _, h_outb, h_pb, h_sb = _run_adjoint(g)
+
+        def add(kind, field, truth, ref, fastv, hipv):
+            e = lambda x: None if x is None else float(gu.rel_l2(x, truth))
+            rows.append(dict(fixture=name, sweep=kind, field=field, ref=e(ref), ref_o3=e(fastv), hip=e(hipv),
+                             hip_vs_ref=None if hipv is None else float(gu.rel_l2(hipv, ref))))
+        for i in range(g.mesh.ng):
+            add("forward", f"qsim[{i}]", t_f["qsim"][i], g.fwd["qsim"][i], None if f_f is None else f_f["qsim"][i], None if h_out is None else h_out.qsim[i])
+        add("forward", "cost", np.float64(t_f["cost"]), np.float32(g.fwd["cost"]), None if f_f is None else np.float32(f_f["cost"]),
+            None if h_out is None else np.float32(h_out.cost))
+        for k in gu.STRUCT_STATES[g.structure]:
+            add("forward", "fstates." + k, t_f["fstates"][k], g.fwd["fstates"][k], None if f_f is None else f_f["fstates"][k],
+                None if h_out is None else getattr(h_out.fstates, k))
+        add("adjoint", "qsim", t_b["qsim"], g.adj["qsim"], None if f_b is None else f_b["qsim"], None if h_outb is None else h_outb.qsim)
+        for k in gu.STRUCT_PARAMS[g.structure]:
+            add("adjoint", k + "_b", t_b["parameters_b"][k], g.adj["parameters_b"][k], None if f_b is None else f_b["parameters_b"][k],
+                None if h_pb is None else getattr(h_pb, k))
+        for k in gu.STRUCT_STATES[g.structure]:
+            add("adjoint", k + "_b", t_b["states_b"][k], g.adj["states_b"][k], None if f_b is None else f_b["states_b"][k],
+                None if h_sb is None else getattr(h_sb, k))
+        print(name, "done", flush=True)
+    fmt = lambda x: "-" if x is None else f"{x:.2e}"
+    mode = "-" if not hip else ("exact-libm build" if _lib.EXACT else "default build")
+    lines = [f"# Accuracy against the fp64 truth: reference Fortran vs the HIP path ({mode})", "",
+             "error = rel-L2 of the field against `oracle/liboracle64.so` (the reference's statements in double on the same fp32 inputs).",
+             "`ref` = golden vectors (flang -O2 -ffp-contract=off), `ref -O3` = the reference as its makefile builds it, `HIP` = libsmashx; "
+             "`HIP vs ref` = the parity figure of profiles/*_parity_*.md for comparison.", "",
+             "| fixture | sweep | field | ref | ref -O3 | HIP | HIP vs ref | HIP <= ref |", "|---|---|---|---|---|---|---|---|"]
+    for r in rows:
+        better = "-" if r["hip"] is None else ("yes" if r["hip"] <= r["ref"] else ("~" if r["hip"] <= 1.25 * r["ref"] or r["hip"] <= 2e-7 else "NO"))
+        lines.append(f"| {r['fixture']} | {r['sweep']} | {r['field']} | {fmt(r['ref'])} | {fmt(r['ref_o3'])} | {fmt(r['hip'])} | {fmt(r['hip_vs_ref'])} | {better} |")
+    summ = f"{len(rows)} outputs"
+    if hip:
+        n = len(rows)
+        le = sum(r["hip"] <= r["ref"] for r in rows)
+        near = sum(r["hip"] <= 1.25 * r["ref"] or r["hip"] <= 2e-7 for r in rows)
+        med = float(np.median([r["hip"] / r["ref"] for r in rows if r["ref"] > 0]))
+        summ += (f": HIP error <= the reference's own error on {le} ({100.0 * le / n:.0f} %), within 1.25x of it (or below 2e-7) on {near} "
+                 f"({100.0 * near / n:.0f} %); median HIP / ref error ratio {med:.2f}")
+        if fast:
+            o3 = sum(r["hip"] <= r["ref_o3"] for r in rows if r["ref_o3"] is not None)
+            summ += f"; HIP <= the -O3 reference's error on {o3}"
+    lines += ["", "**Summary.** " + summ, ""]
+    txt = "\n".join(lines)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        open(a.out, "w").write(txt)
+    if a.json:
+        json.dump(rows, open(a.json, "w"), indent=0)
+    print(summ)
+
+
+if __name__ == "__main__":
+    main()
