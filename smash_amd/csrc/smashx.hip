@@ -443,7 +443,15 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
             const double avail = (double)fr * 0.85 - 1.0e9;
             auto fit = [&](double nt_) { return (long)(avail / (4.0 * ((double)p->npad * (2 + nt_) + (double)std::max(p->sch.nxslots, 1)))) / 16 * 16; };
             long t = fit(ntape_full);
-            if (has_hi && t < nt16) { p->hi_tape = false; t = fit(ntape_lean); }
+            if (has_hi && t < nt16) {
+                // Dropping the hi tape costs the reverse kernel ~14 % (levels rebuilt block by block: 78.5 against 69 ms per 9.2e9
+                // cell-steps, profiles/r3_*_2048*), one more storage chunk costs 1/C of a forward pass (~0.67 of a reverse pass): lean
+                // only where it saves enough recomputation -- always when it lets the whole period fit one chunk (gr-c at 1024^2:
+                // 230 -> 204 ms), not at 2048^2 where 4 lean chunks lose to 5 taped ones (784 -> see DESIGN.md 8)
+                const long tl = fit(ntape_lean);
+                auto nch = [&](long tc) { tc = std::max<long>(16, std::min<long>(nt16, tc)); return (double)((p->nt + tc - 1) / tc); };
+                if (0.67 * (1.0 / nch(tl) - 1.0 / nch(t)) > 0.14) { p->hi_tape = false; t = tl; }
+            }
             Tc = (int)std::max<long>(16, std::min<long>(nt16, t));
         }
         if (const char* e = getenv("SMASHX_HI_TAPE")) p->hi_tape = atoi(e) != 0;
