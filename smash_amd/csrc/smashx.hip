@@ -304,6 +304,11 @@ struct smashx_plan {
     std::vector<float> wgauge;
     hipStream_t stream = nullptr;    // vertical kernels, uploads/downloads ("V stream")
     hipStream_t stream_r = nullptr;  // routing + cost kernels ("R stream"); overlaps the V stream chunk by chunk
+    hipStream_t stream_c = nullptr;  // the chained routing launch of a storage chunk cut into sub-chunks (persistent, gated: sx_kernels.h)
+    hipStream_t stream_x = nullptr;  // pack + send of a sub-chunk's boundary series beside that launch
+    int persist_wgs = 160;           // workgroups of such a launch (SMASHX_PERSIST_WGS): the other compute units stay free for round 0,
+                                     // the vertical kernels and the exchange kernels it waits for
+    int* d_out_prod = nullptr; int n_out_prod = 0;   // chained groups that publish a boundary series of this tile
     int Tp = 0;                      // pipeline sub-chunk length inside a storage chunk
     bool hi_tape = true;             // gr-b / gr-c: full tape of the interception level (false: sparse checkpoints, rebuilt in the reverse kernel)
     int Tpa = 0;                     // ... of the reverse sweep (routing adjoint of sub-chunk j-1 under the vertical adjoint of j)
@@ -594,62 +599,91 @@ void vert_adj(smashx_plan* p, int off, int t0, int T, int k0 = 0, int k1 = -1) {
 #undef SX_VADJ
     p->mark_end();
 }
-// Routing launches of one pass.  Rounds below p->chain_from keep one launch per round (they are wide and
-// HBM-bound); the narrow, latency-bound rounds from chain_from on run chained inside a single launch
-// (sx_kernels.h "rounds chained inside one launch"), which turns their sum into roughly the longest of them.
-// wait_rest: event the launches after round 0 have to wait for (the vertical kernel of the cells outside round 0)
 double round_cells(const smashx_plan* p, int r0, int r1) {   // cells (inlets excluded) of the groups of rounds [r0, r1)
     double c = 0.0;
     for (int r = r0; r < r1; ++r) c += p->round_ncells[r];
     return c;
 }
-void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T, hipEvent_t wait_rest = nullptr) {
+int chain_first(const smashx_plan* p) {       // first chained round (nrounds: none)
+    const int nr = p->sch.nrounds;
+    return (p->chain && nr - p->chain_from >= 2) ? p->chain_from : nr;
+}
+// counters of a chained launch: the groups' progress, the ticket counter and the gate (the stall flag lives for the whole sweep)
+void reset_chain_counters(smashx_plan* p, hipStream_t st) {
+    (void)hipMemsetAsync(p->A.prog, 0, (size_t)p->sch.ngroups * sizeof(int), st);
+    (void)hipMemsetAsync(p->A.prog + p->sch.ngroups + 1, 0, 2 * sizeof(int), st);
+}
+// the un-chained rounds [0, chain_first) of one forward pass over [t0, t0 + T): one launch per round on stream st
+void route_fwd_rounds(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st, hipEvent_t wait_rest = nullptr) {
     SxDeviceArrays B = view_at(p, off);
     if (!p->dom_q_active) B.qdT = nullptr;
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
-    const int nr = p->sch.nrounds;
-    const int cf = (p->chain && nr - p->chain_from >= 2) ? p->chain_from : nr;
+    const int cf = chain_first(p);
     for (int r = 0; r < cf; ++r) {
-        if (r == 1 && wait_rest) (void)hipStreamWaitEvent(p->stream_r, wait_rest, 0);
+        if (r == 1 && wait_rest) (void)hipStreamWaitEvent(st, wait_rest, 0);
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
-        p->mark_begin(1, p->stream_r, round_cells(p, r, r + 1) * T);
-        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
-        else      hipLaunchKernelGGL((sx_k_route_fwd<false, false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
+        p->mark_begin(1, st, round_cells(p, r, r + 1) * T);
+        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T, 0);
+        else      hipLaunchKernelGGL((sx_k_route_fwd<false, false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T, 0);
         p->mark_end();
-    }
-    if (cf < nr) {
-        const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
-        if (cf <= 1 && wait_rest) (void)hipStreamWaitEvent(p->stream_r, wait_rest, 0);
-        (void)hipMemsetAsync(p->A.prog, 0, (size_t)p->sch.ngroups * sizeof(int), p->stream_r);
-        p->mark_begin(1, p->stream_r, round_cells(p, cf, nr) * T);
-        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(g1 - g0), dim3(p->M), lds, p->stream_r, B, g0, g1, t0, T);
-        else      hipLaunchKernelGGL((sx_k_route_fwd<false, true>), dim3(g1 - g0), dim3(p->M), lds, p->stream_r, B, g0, g1, t0, T);
-        p->mark_end();
-        p->chain_used = true;
     }
 }
-// after_rest: recorded once every round but round 0 has run (their cells' qt_b is final)
-void route_adj(smashx_plan* p, int off, int t0, int T, hipEvent_t after_rest = nullptr) {
+// the chained rounds in ONE launch (tickets: sx_kernels.h).  gated: the launch spans several sub-chunks whose external inputs arrive
+// while it runs and is confined to persist_wgs workgroups; the caller has reset the counters on a stream this one waits for
+void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st, bool gated, hipEvent_t wait_rest = nullptr) {
+    const int nr = p->sch.nrounds, cf = chain_first(p);
+    if (cf >= nr) return;
+    SxDeviceArrays B = view_at(p, off);
+    if (!p->dom_q_active) B.qdT = nullptr;
+    const size_t lds = (size_t)2 * p->M * sizeof(float4);
+    const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
+    if (cf <= 1 && wait_rest) (void)hipStreamWaitEvent(st, wait_rest, 0);
+    if (!gated) reset_chain_counters(p, st);
+    const int grid = gated ? std::min(g1 - g0, p->persist_wgs) : g1 - g0;
+    p->mark_begin(1, st, round_cells(p, cf, nr) * T);
+    if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T, gated ? 1 : 0);
+    else      hipLaunchKernelGGL((sx_k_route_fwd<false, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T, gated ? 1 : 0);
+    p->mark_end();
+    p->chain_used = true;
+}
+// Routing launches of one pass.  Rounds below chain_first keep one launch per round (they are wide and
+// HBM-bound); the narrow, latency-bound rounds from there on run chained inside a single launch
+// (sx_kernels.h "rounds chained inside one launch"), which turns their sum into roughly the longest of them.
+// wait_rest: event the launches after round 0 have to wait for (the vertical kernel of the cells outside round 0)
+void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T, hipEvent_t wait_rest = nullptr) {
+    route_fwd_rounds(p, off, tape, t0, T, p->stream_r, wait_rest);
+    route_fwd_chained(p, off, tape, t0, T, p->stream_r, false, wait_rest);
+}
+void route_adj_chained(smashx_plan* p, int off, int t0, int T, hipStream_t st, bool gated) {
+    const int nr = p->sch.nrounds, cf = chain_first(p);
+    if (cf >= nr) return;
     const SxDeviceArrays B = view_at(p, off);
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
-    const int nr = p->sch.nrounds;
-    const int cf = (p->chain && nr - p->chain_from >= 2) ? p->chain_from : nr;
-    if (cf < nr) {
-        const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
-        (void)hipMemsetAsync(p->A.prog, 0, (size_t)p->sch.ngroups * sizeof(int), p->stream_r);
-        p->mark_begin(2, p->stream_r, round_cells(p, cf, nr) * T);
-        hipLaunchKernelGGL((sx_k_route_adj<true>), dim3(g1 - g0), dim3(p->M), lds, p->stream_r, B, g0, g1, t0, T);
-        p->mark_end();
-        p->chain_used = true;
-    }
-    if (cf <= 1 && after_rest) (void)hipEventRecord(after_rest, p->stream_r);
+    const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
+    if (!gated) reset_chain_counters(p, st);
+    const int grid = gated ? std::min(g1 - g0, p->persist_wgs) : g1 - g0;
+    p->mark_begin(2, st, round_cells(p, cf, nr) * T);
+    hipLaunchKernelGGL((sx_k_route_adj<true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T, gated ? 1 : 0);
+    p->mark_end();
+    p->chain_used = true;
+}
+// after_rest: recorded once every round but round 0 has run (their cells' qt_b is final)
+void route_adj_rounds(smashx_plan* p, int off, int t0, int T, hipStream_t st, hipEvent_t after_rest = nullptr) {
+    const SxDeviceArrays B = view_at(p, off);
+    const size_t lds = (size_t)2 * p->M * sizeof(float4);
+    const int cf = chain_first(p);
+    if (cf <= 1 && after_rest) (void)hipEventRecord(after_rest, st);
     for (int r = cf - 1; r >= 0; --r) {
-        if (r == 0 && cf > 1 && after_rest) (void)hipEventRecord(after_rest, p->stream_r);
+        if (r == 0 && cf > 1 && after_rest) (void)hipEventRecord(after_rest, st);
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
-        p->mark_begin(2, p->stream_r, round_cells(p, r, r + 1) * T);
-        hipLaunchKernelGGL((sx_k_route_adj<false>), dim3(ngr), dim3(p->M), lds, p->stream_r, B, g0, g0 + ngr, t0, T);
+        p->mark_begin(2, st, round_cells(p, r, r + 1) * T);
+        hipLaunchKernelGGL((sx_k_route_adj<false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T, 0);
         p->mark_end();
     }
+}
+void route_adj(smashx_plan* p, int off, int t0, int T, hipEvent_t after_rest = nullptr) {
+    route_adj_chained(p, off, t0, T, p->stream_r, false);
+    route_adj_rounds(p, off, t0, T, p->stream_r, after_rest);
 }
 
 SxCostArgs cost_args(smashx_plan* p, float jobs_b) {
@@ -742,6 +776,14 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->stream_r) != hipSuccess) { delete p; return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
     (void)hipEventCreate(&p->ev0); (void)hipEventCreate(&p->ev1);
     if (hipStreamCreate(&p->stream_j) != hipSuccess || hipEventCreate(&p->ev_j) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
+    {   // the exchange kernels beside a persistent chained launch are tiny and on the critical path of the neighbours: high priority
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        // non-blocking: a persistent launch that waits for its gate must never be waited for by work on the legacy default stream
+        if (hipStreamCreateWithFlags(&p->stream_c, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithPriority(&p->stream_x, hipStreamNonBlocking, hi) != hipSuccess) {
+            smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipStreamCreate failed");
+        }
+    }
     SxDeviceArrays& A = p->A;
     A.n = p->n; A.npad = p->npad; A.nt = p->nt; A.dt = cfg->dt; A.dx = cfg->dx; A.Tc = 0;
     if (getenv("SMASHX_VERBOSE"))
@@ -770,7 +812,9 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         int *d9, *d10;
         TRY(p->upload_vec(&d9, p->sch.x_prod_group)); A.x_prod = d9;
         TRY(p->upload_vec(&d10, p->sch.x_cons_group)); A.x_cons = d10;
-        TRY(p->dmalloc(&A.prog, (size_t)p->sch.ngroups + 1));
+        TRY(p->dmalloc(&A.prog, (size_t)p->sch.ngroups + SX_PROG_EXTRA));
+        if (hipMemset(A.prog, 0, ((size_t)p->sch.ngroups + SX_PROG_EXTRA) * sizeof(int)) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipMemset"); }
+        if (const char* pw = getenv("SMASHX_PERSIST_WGS")) p->persist_wgs = std::max(1, atoi(pw));
         A.ngroups = p->sch.ngroups;
         const char* e = getenv("SMASHX_CHAIN_ROUNDS");
         p->chain = !(e && e[0] == '0');
@@ -799,6 +843,14 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     TRY(p->upload_vec(&p->d_active, std::vector<int>(mesh->active_cell, mesh->active_cell + p->n2)));
     TRY(p->dmalloc(&p->d_jsum, (size_t)SX_JREG_MAXCHAIN));
     p->n_out = (int)p->sch.out_x.size(); p->n_in = (int)p->sch.in_x.size();
+    {   // chained groups whose subtree roots publish a boundary series: what the send of a sub-chunk waits for beside a persistent launch
+        std::vector<int> prod;
+        const int gc = p->sch.round_group_begin[std::min(std::max(p->chain_from, 0), p->sch.nrounds)];
+        for (int x : p->sch.out_x) { const int g = p->sch.x_prod_group[x]; if (g >= gc) prod.push_back(g); }
+        std::sort(prod.begin(), prod.end()); prod.erase(std::unique(prod.begin(), prod.end()), prod.end());
+        p->n_out_prod = (int)prod.size();
+        TRY(p->upload_vec(&p->d_out_prod, prod.empty() ? std::vector<int>(1, 0) : prod));
+    }
     TRY(p->upload_vec(&p->d_out_x, p->sch.out_x.empty() ? std::vector<int>(1, 0) : p->sch.out_x));
     TRY(p->upload_vec(&p->d_in_x, p->sch.in_x.empty() ? std::vector<int>(1, 0) : p->sch.in_x));
     // per-cell mesh data
@@ -878,6 +930,8 @@ int smashx_plan_destroy(smashx_plan* p) {
     if (p->stream) (void)hipStreamDestroy(p->stream);
     if (p->stream_r) (void)hipStreamDestroy(p->stream_r);
     if (p->stream_j) { (void)hipStreamSynchronize(p->stream_j); (void)hipStreamDestroy(p->stream_j); }
+    if (p->stream_c) { (void)hipStreamSynchronize(p->stream_c); (void)hipStreamDestroy(p->stream_c); }
+    if (p->stream_x) { (void)hipStreamSynchronize(p->stream_x); (void)hipStreamDestroy(p->stream_x); }
     if (p->ev_j) (void)hipEventDestroy(p->ev_j);
     delete p;
     return 0;
@@ -1227,16 +1281,25 @@ static int close_forcing(smashx_plan* p) {       // compact PET: days that never
     return 0;
 }
 
-// A chained routing launch only makes progress if the groups it waits for are resident or get dispatched (workgroups are
-// dispatched in blockIdx order; HIP does not promise that).  A waiting group that exhausts its poll limit raises a flag and
-// the sweep's results are void: the plan then drops to one launch per round for good and the sweep is run again.
+// A chained routing launch draws its groups by ticket (sx_kernels.h), so a group only waits for groups that are resident or done and
+// for external inputs (the gate) that other streams -- or other ranks -- deliver.  Should a wait nevertheless exhaust its poll limit
+// (a neighbour that died, a starved stream), a flag is raised and the sweep's results are void: the plan then drops to one launch per
+// round for good and the sweep is run again; the ranks of a decomposition take that decision together (one all-reduce per sweep).
 int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     bool stalled = false;
     int rc = sweep_once(p, adjoint, cost_b, &stalled);
-    if (rc || !stalled) return rc;
-    if (p->xcomm || p->halo_fn)      // the neighbours of a tile cannot be made to repeat their sweep from here
+    if (rc) return rc;
+    const bool agree = p->xcomm != nullptr && p->chain;      // a decomposition decides together: same condition on every rank
+    if (agree) {
+        double v = stalled ? 1.0 : 0.0;
+        if ((rc = smashx_comm_allreduce_sum(p->xcomm, &v, 1))) return rc;
+        stalled = v > 0.0;
+    }
+    if (!stalled) return 0;
+    if (p->halo_fn && !p->xcomm)     // host-callback exchange: the neighbours of a tile cannot be made to repeat their sweep from here
         return fail(SMASHX_E_HIP, "chained routing launch stalled waiting for an upstream group (results invalid); set SMASHX_CHAIN_ROUNDS=0");
-    fprintf(stderr, "smashx: a chained routing launch stalled (poll limit reached); this plan now runs one launch per routing round\n");
+    fprintf(stderr, "smashx: a chained routing launch stalled (poll limit reached); this plan now runs one launch per routing round%s\n",
+            p->xcomm ? " (every rank of the decomposition does)" : "");
     p->chain = false;
     p->A.mute_group = -1;
     rc = sweep_once(p, adjoint, cost_b, &stalled);
@@ -1260,6 +1323,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     HIPCHK(hipStreamWaitEvent(sR, p->ev0, 0));
     p->chain_used = false;
     HIPCHK(hipMemsetAsync(p->A.prog + p->sch.ngroups, 0, sizeof(int), sR));   // stall flag of the chained launches
+    HIPCHK(hipMemsetAsync(p->A.prog + p->sch.ngroups + 3, 0, 4 * sizeof(int), sR));   // ... and its diagnostics
     if (p->opt.njr > 0) {
         HIPCHK(hipStreamWaitEvent(p->stream_j, p->ev0, 0));
         if ((rc = run_jreg(p, adjoint, cost_b))) return rc;
@@ -1272,7 +1336,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     const bool halo = (p->halo_fn || native) && (p->n_out > 0 || p->n_in > 0);
     // move the boundary series of one sub-chunk between the exchange rows and the message buffers (the caller's, or the
     // plan's own in peer-grouped edge order when RCCL carries them)
-    auto halo_move = [&](bool pack, bool out_edges, int off, int T) {
+    auto halo_move = [&](bool pack, bool out_edges, int off, int T, hipStream_t st) {
         const int nedge = out_edges ? p->n_out : p->n_in;
         if (nedge == 0) return;
         const int Tq = (T + 3) / 4;
@@ -1280,11 +1344,11 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
         float4* buf = reinterpret_cast<float4*>(native ? (out_edges ? p->x_out : p->x_in) : (out_edges ? p->halo_out : p->halo_in));
         const int* slots = native ? (out_edges ? p->d_out_xp : p->d_in_xp) : (out_edges ? p->d_out_x : p->d_in_x);
         const dim3 g((nedge * Tq + 255) / 256), b(256);
-        if (pack) hipLaunchKernelGGL(k_halo_pack, g, b, 0, sR, buf, x4, slots, nedge, p->A.nx, Tq);
-        else hipLaunchKernelGGL(k_halo_unpack, g, b, 0, sR, x4, buf, slots, nedge, p->A.nx, Tq);
+        if (pack) hipLaunchKernelGGL(k_halo_pack, g, b, 0, st, buf, x4, slots, nedge, p->A.nx, Tq);
+        else hipLaunchKernelGGL(k_halo_unpack, g, b, 0, st, x4, buf, slots, nedge, p->A.nx, Tq);
     };
-    // one grouped send or recv per sub-chunk: a message per peer = its edges x the sub-chunk's steps, stream-ordered on sR
-    auto xfer = [&](bool send, bool out_edges, int T) -> int {
+    // one grouped send or recv per sub-chunk: a message per peer = its edges x the sub-chunk's steps, stream-ordered on st
+    auto xfer = [&](bool send, bool out_edges, int T, hipStream_t st) -> int {
         const std::vector<PeerSeg>& segs = out_edges ? p->out_segs : p->in_segs;
         if (segs.empty()) return 0;
         RcclApi& R = rccl();
@@ -1300,25 +1364,37 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
         NCCLCHK(R.GroupStart());
         for (const PeerSeg& sg : segs) {
             float* b = buf + (size_t)sg.first * per_edge;
-            const ncclResult_t r = send ? R.Send(b, (size_t)sg.count * per_edge, ncclFloat, sg.rank, p->xcomm->comm, sR)
-                                        : R.Recv(b, (size_t)sg.count * per_edge, ncclFloat, sg.rank, p->xcomm->comm, sR);
+            const ncclResult_t r = send ? R.Send(b, (size_t)sg.count * per_edge, ncclFloat, sg.rank, p->xcomm->comm, st)
+                                        : R.Recv(b, (size_t)sg.count * per_edge, ncclFloat, sg.rank, p->xcomm->comm, st);
             if (r != ncclSuccess) { (void)R.GroupEnd(); return fail(SMASHX_E_HIP, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(r)); }
         }
         NCCLCHK(R.GroupEnd());
         if (trace) {
-            HIPCHK(hipStreamSynchronize(sR));
+            HIPCHK(hipStreamSynchronize(st));
             fprintf(stderr, "[smashx rank %d]   ... completed\n", p->xcomm->rank);
         }
         return 0;
     };
     // phases as in smashx_halo_fn: 0 FWD_RECV (in), 1 FWD_SEND (out), 2 ADJ_RECV (out), 3 ADJ_SEND (in)
-    auto hook = [&](int phase, int t0, int T) -> int {
-        if (native) return xfer(phase == 1 || phase == 3, phase == 1 || phase == 2, T);
-        if (phase == 1 || phase == 3) HIPCHK(hipStreamSynchronize(sR));     // the packed buffer must be complete before the host moves it
+    auto hook = [&](int phase, int t0, int T, hipStream_t st) -> int {
+        if (native) return xfer(phase == 1 || phase == 3, phase == 1 || phase == 2, T, st);
+        // host callback: the packed buffer must be complete before the host moves it; the unpack of the previous message must have
+        // consumed the receive buffer before the host fills it again
+        HIPCHK(hipStreamSynchronize(st));
         const int rc2 = p->halo_fn(p->halo_user, phase, t0, T);
         return rc2 ? fail(SMASHX_E_ARG, "halo callback failed") : 0;
     };
     const bool split = p->split_v && !halo && p->sch.nrounds > 1 && p->n0 > 0 && p->n0 < p->n;
+    // SMASHX_PERSIST=1: ONE gated chained launch per storage chunk instead of one per pipeline sub-chunk (persistent workgroups, tickets
+    // and the gate of sx_kernels.h).  Built to take the fill of the chained rounds out of every sub-chunk of a tile; measured and left
+    // OFF by default: a time-skewed group consumes inputs up to its depth (~340 blocks of 4 steps at 512 slots) ahead
+    // of what it publishes, so behind such a launch a rank can only send sub-chunk j after it has received j + 1 and j + 2 -- the fill a
+    // per-sub-chunk launch pays in time comes back as look-ahead and the rank pipeline coarsens to whole storage chunks; alone on a
+    // GPU the tile gains 9 ms of 357 (its persistent workgroups hold compute units the vertical kernels then run on at lower occupancy).
+    // Experimental switch: with a host-callback exchange between plans that share one GPU (tests/test_gpu_tiles.py) a wait was seen to
+    // run into its poll limit although every input arrived in the end (cause not found); the launch per sub-chunk is what tiles run.
+    const char* pers_env = getenv("SMASHX_PERSIST");
+    const bool persist_on = pers_env && pers_env[0] == '1' && (!halo || pers_env[1] == 'x');
     auto forward_chunk = [&](int c, bool tape) -> int {
         const int t0c = c * p->Tc, Tcur = chunk_len(p, c), ns = nsub_of(Tcur);
         std::vector<hipEvent_t> ev(ns), ev_rest(ns, nullptr);
@@ -1340,17 +1416,63 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
         // disjoint parts of the chunk buffers, so the V stream never waits for the host, which blocks in the halo hooks
         // of the routing pipeline below (tiles) -- the vertical work then hides the pipeline fill across tiles
         for (int jb = 0; jb < ns; ++jb) if ((rc = launch_v(jb))) return rc;
+        if (persist_on && ns > 1 && !split && chain_first(p) < p->sch.nrounds) {
+            // ONE chained launch for the whole storage chunk (persistent workgroups, tickets, gate: sx_kernels.h) beside the per-sub-chunk
+            // work: receive + unpack, round 0 and the gate bump on the R stream; gate on the producers' progress, pack and send on
+            // the X stream.  The fill of the chained rounds -- (time blocks + the longest cell path) super-steps -- is paid once per
+            // chunk pass instead of once per sub-chunk, and a sub-chunk's boundary series leave as soon as its blocks are published.
+            const int nb = (Tcur + 3) / 4;
+            hipStream_t sC = p->stream_c, sX = p->stream_x;
+            reset_chain_counters(p, sR);
+            hipEvent_t e_reset = p->event();
+            HIPCHK(hipEventRecord(e_reset, sR));
+            HIPCHK(hipStreamWaitEvent(sC, e_reset, 0));
+            HIPCHK(hipStreamWaitEvent(sX, e_reset, 0));
+            // two passes over the sub-chunks: a time-skewed group works up to its depth in blocks AHEAD of what it publishes, so the
+            // boundary series of sub-chunk j only complete once round 0 of the following sub-chunks has run -- nothing that feeds the
+            // gate may queue (or, with a host callback, block the host) behind a send
+            std::vector<hipEvent_t> e_r0(ns);
+            for (int jb = 0; jb < ns; ++jb) {
+                const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
+                if (halo && p->n_in > 0) {
+                    if ((rc = hook(0, t0c + off, T, sR))) return rc;
+                    halo_move(false, false, off, T, sR);
+                }
+                HIPCHK(hipStreamWaitEvent(sR, ev[jb], 0));
+                route_fwd_rounds(p, off, tape, t0c + off, T, sR);
+                hipLaunchKernelGGL(sx_k_gate_bump, dim3(1), dim3(64), 0, sR, SX_PROG_GATE(p->A), std::min((off + T + 3) / 4, nb));
+                e_r0[jb] = p->event();
+                HIPCHK(hipEventRecord(e_r0[jb], sR));
+                if (jb == 0) {
+                    HIPCHK(hipStreamWaitEvent(sC, e_r0[0], 0));
+                    route_fwd_chained(p, 0, tape, t0c, Tcur, sC, true);
+                }
+            }
+            for (int jb = 0; jb < ns && halo && p->n_out > 0; ++jb) {
+                const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
+                HIPCHK(hipStreamWaitEvent(sX, e_r0[jb], 0));
+                if (p->n_out_prod > 0)
+                    hipLaunchKernelGGL(sx_k_wait_groups, dim3(1), dim3(256), 0, sX, p->A.prog, p->d_out_prod, p->n_out_prod, 0, 0,
+                                       std::min((off + T + 3) / 4, nb), SX_PROG_STALL(p->A), p->A.spin_limit);
+                halo_move(true, true, off, T, sX);
+                if ((rc = hook(1, t0c + off, T, sX))) return rc;
+            }
+            hipEvent_t e_c = p->event(), e_x = p->event();
+            HIPCHK(hipEventRecord(e_c, sC)); HIPCHK(hipEventRecord(e_x, sX));
+            HIPCHK(hipStreamWaitEvent(sR, e_c, 0)); HIPCHK(hipStreamWaitEvent(sR, e_x, 0));
+            return 0;
+        }
         for (int jb = 0; jb < ns; ++jb) {
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
             if (halo && p->n_in > 0) {
-                if ((rc = hook(0, t0c + off, T))) return rc;      // in_buf now holds the upstream tiles' series
-                halo_move(false, false, off, T);
+                if ((rc = hook(0, t0c + off, T, sR))) return rc;      // in_buf now holds the upstream tiles' series
+                halo_move(false, false, off, T, sR);
             }
             HIPCHK(hipStreamWaitEvent(sR, ev[jb], 0));
             route_fwd(p, off, tape, t0c + off, T, ev_rest[jb]);
             if (halo && p->n_out > 0) {
-                halo_move(true, true, off, T);
-                if ((rc = hook(1, t0c + off, T))) return rc;
+                halo_move(true, true, off, T, sR);
+                if ((rc = hook(1, t0c + off, T, sR))) return rc;
             }
         }
         return 0;
@@ -1437,11 +1559,61 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
                 if ((rc = restore_states(p, src))) return rc;
                 if ((rc = forward_chunk(c, true))) return rc;
             }
-            for (int jb = (Tcur + p->Tpa - 1) / p->Tpa - 1; jb >= 0; --jb) {
+            const int nsa = (Tcur + p->Tpa - 1) / p->Tpa;
+            const bool persa = persist_on && nsa > 1 && !split && chain_first(p) < p->sch.nrounds;
+            const int nbc = (Tcur + 3) / 4;
+            if (persa) {   // the chained rounds of the whole storage chunk in one gated launch, started first: roots of the basin lead
+                reset_chain_counters(p, sR);
+                hipEvent_t e_reset = p->event();
+                HIPCHK(hipEventRecord(e_reset, sR));
+                HIPCHK(hipStreamWaitEvent(p->stream_c, e_reset, 0));
+                HIPCHK(hipStreamWaitEvent(p->stream_x, e_reset, 0));
+                route_adj_chained(p, 0, t0c, Tcur, p->stream_c, true);
+            }
+            std::vector<hipEvent_t> e_in(persa ? nsa : 0);
+            for (int jb = nsa - 1; persa && jb >= 0; --jb) {
+                // The adjoint boundary series of every sub-chunk arrive on the X stream, which then opens the gate: reverse blocks whose
+                // series are there -- the chained roots fed by other ranks may enter them.  A time-skewed group works up to its depth in
+                // blocks AHEAD of what it publishes, so the launch can only finish a sub-chunk once the following ones' series are in:
+                // receive, unpack and gate bump never queue (or block the host) behind a sub-chunk's round 0 and send.
                 const int off = jb * p->Tpa, T = std::min(p->Tpa, Tcur - off);
+                hipStream_t sX = p->stream_x;
                 if (halo && p->n_out > 0) {
-                    if ((rc = hook(2, t0c + off, T))) return rc;  // out_buf now holds the downstream tiles' adjoint contributions
-                    halo_move(false, true, off, T);
+                    if ((rc = hook(2, t0c + off, T, sX))) return rc;
+                    halo_move(false, true, off, T, sX);
+                }
+                hipLaunchKernelGGL(sx_k_gate_bump, dim3(1), dim3(64), 0, sX, SX_PROG_GATE(p->A), nbc - off / 4);
+                e_in[jb] = p->event();
+                HIPCHK(hipEventRecord(e_in[jb], sX));
+            }
+            for (int jb = nsa - 1; jb >= 0; --jb) {
+                const int off = jb * p->Tpa, T = std::min(p->Tpa, Tcur - off);
+                if (persa) {
+                    const int avail = nbc - off / 4;
+                    const int gc0 = p->sch.round_group_begin[chain_first(p)];
+                    HIPCHK(hipStreamWaitEvent(sR, e_in[jb], 0));
+                    // round 0 of this sub-chunk waits until every chained group has left its blocks behind
+                    hipLaunchKernelGGL(sx_k_wait_groups, dim3(1), dim3(256), 0, sR, p->A.prog, (const int*)nullptr, 0, gc0, p->sch.ngroups, avail,
+                                       SX_PROG_STALL(p->A), p->A.spin_limit);
+                    route_adj_rounds(p, off, t0c + off, T, sR);
+                    hipEvent_t e = p->event();
+                    HIPCHK(hipEventRecord(e, sR));
+                    HIPCHK(hipStreamWaitEvent(sV, e, 0));
+                    vert_adj(p, off, t0c + off, T);
+                    if (halo && p->n_in > 0) {
+                        halo_move(true, false, off, T, sR);
+                        if ((rc = hook(3, t0c + off, T, sR))) return rc;
+                    }
+                    if (jb == 0) {
+                        hipEvent_t e_c = p->event();
+                        HIPCHK(hipEventRecord(e_c, p->stream_c));
+                        HIPCHK(hipStreamWaitEvent(sR, e_c, 0));
+                    }
+                    continue;
+                }
+                if (halo && p->n_out > 0) {
+                    if ((rc = hook(2, t0c + off, T, sR))) return rc;  // out_buf now holds the downstream tiles' adjoint contributions
+                    halo_move(false, true, off, T, sR);
                 }
                 hipEvent_t e_rest = split ? p->event() : nullptr;
                 route_adj(p, off, t0c + off, T, e_rest);
@@ -1457,8 +1629,8 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
                     vert_adj(p, off, t0c + off, T);
                 }
                 if (halo && p->n_in > 0) {
-                    halo_move(true, false, off, T);
-                    if ((rc = hook(3, t0c + off, T))) return rc;
+                    halo_move(true, false, off, T, sR);
+                    if ((rc = hook(3, t0c + off, T, sR))) return rc;
                 }
             }
         }
@@ -1476,7 +1648,20 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     if (p->chain_used) {
         int stalled = 0;
         HIPCHK(hipMemcpy(&stalled, p->A.prog + p->sch.ngroups, sizeof(int), hipMemcpyDeviceToHost));
-        if (stalled) { *stalled_out = true; return 0; }
+        if (stalled) {
+            if (getenv("SMASHX_VERBOSE")) {
+                int d[7] = {0};
+                (void)hipMemcpy(d, p->A.prog + p->sch.ngroups, sizeof(d), hipMemcpyDeviceToHost);
+                fprintf(stderr, "smashx: stall: waiter %d (group id, -1 = a gate kernel) followed counter %d (< 0: group %d's progress; 2 = the gate), "
+                        "needed %d blocks, saw %d; gate now %d, tickets drawn %d, chained groups %d..%d, progress:", d[3] - 2, d[4], p->sch.ngroups + d[4], d[5], d[6], d[2],
+                        d[1], p->sch.round_group_begin[chain_first(p)], p->sch.ngroups - 1);
+                std::vector<int> pr(p->sch.ngroups);
+                (void)hipMemcpy(pr.data(), p->A.prog, pr.size() * sizeof(int), hipMemcpyDeviceToHost);
+                for (int g = p->sch.round_group_begin[chain_first(p)]; g < p->sch.ngroups; ++g) fprintf(stderr, " %d", pr[g]);
+                fprintf(stderr, " (n_in %d n_out %d)\n", p->n_in, p->n_out);
+            }
+            *stalled_out = true; return 0;
+        }
     }
     // timing
     smashx_timing& tm = p->timing;
@@ -2087,8 +2272,8 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
             for (int r = 0; r < p->sch.nrounds; ++r) {                  // one launch per round
                 const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
                 p->mark_begin(1, sR);
-                if (pass == 1) hipLaunchKernelGGL((sx_k_route_fwd<true, false, 1>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c, Tcur);
-                else           hipLaunchKernelGGL((sx_k_route_fwd<false, false, 2>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c, Tcur);
+                if (pass == 1) hipLaunchKernelGGL((sx_k_route_fwd<true, false, 1>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c, Tcur, 0);
+                else           hipLaunchKernelGGL((sx_k_route_fwd<false, false, 2>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c, Tcur, 0);
                 p->mark_end();
             }
     }

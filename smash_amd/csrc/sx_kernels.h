@@ -108,19 +108,43 @@ __device__ __forceinline__ void sx_pinu(unsigned& v) { asm volatile("" : "+v"(v)
 // have drained their stores (vmcnt(0), then the workgroup barrier), writes its L2 back (release fence) and
 // bumps the counter; a consumer that sees the counter move invalidates its caches (acquire fence) before it
 // requests the newly published blocks.
-// Forward progress: workgroups are dispatched in blockIdx order and only ever wait for a lower blockIdx.
+// Forward progress (round 3): a chained launch no longer relies on the order in which the hardware dispatches workgroups.  Every
+// workgroup that becomes resident draws the next TICKET (one atomic add) and routes the group of that ticket -- tickets run through
+// the chained groups in dependency order (forward: ascending group id; reverse: descending), so a group only ever waits for groups
+// whose tickets were drawn earlier, i.e. by workgroups that are resident or done -- and loops until the tickets are exhausted.  The
+// grid may therefore be SMALLER than the number of groups (persistent workgroups): tiled plans launch ONE chained kernel per
+// storage chunk on a bounded number of compute units and leave the rest to the round-0 launches, the vertical kernels and the
+// exchange kernels that run beside it.
+// External inputs of a chained launch that spans several pipeline sub-chunks arrive while it runs; `gate` (prog[ngroups + 2]) counts
+// the chunk-local time blocks whose external inputs are complete: forward = vertical kernel, boundary series received from other
+// ranks and routing round 0 of the sub-chunk (bumped in stream order behind them); reverse = adjoint boundary series received.
 typedef __attribute__((address_space(1))) int sx_gint;
+#define SX_PROG_STALL(A) ((A).prog + (A).ngroups)          // stall flag
+#define SX_PROG_TICKET(A) ((A).prog + (A).ngroups + 1)     // next ticket of the running chained launch
+#define SX_PROG_GATE(A) ((A).prog + (A).ngroups + 2)       // blocks whose external inputs are complete (gated launches)
+#define SX_PROG_EXTRA 8
 #ifndef SX_PK
 #define SX_PK 16              // macro-steps between two publications (x SX_MU x SX_BT = 256 time steps); 2..16 measured, fences dominate
 #endif
 #define SX_SPIN_LIMIT (1 << 22)   // polls (~1 us each at least) before a stalled chain is reported instead of hanging (SxDeviceArrays::spin_limit)
-__device__ __forceinline__ void sx_wait_prog(const int* prog, int need, int& seen, int* stalled, int limit) {
+// stalled[0] = flag; stalled[3..6] = diagnostics of the first waiter that gave up: tag (the waiting group, -1: a gate kernel), the
+// counter it followed (address distance to the flag, in ints), the blocks it needed and the blocks it last saw
+__device__ __forceinline__ void sx_wait_prog(const int* prog, int need, int& seen, int* stalled, int limit, int tag = -1) {
     if (seen >= need) return;
     int spins = 0;
     while (seen < need) {
         seen = __hip_atomic_load((const sx_gint*)prog, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (seen < need) {
-            if (++spins > limit) { __hip_atomic_store((sx_gint*)stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); seen = 0x7fffffff; break; }
+            // a wait that runs out of polls voids the sweep (the host repeats it without chained launches); once one waiter has
+            // given up every other one follows at its next look at the flag instead of serving its own full limit
+            const bool out = ++spins > limit;
+            if (out || (spins & 1023) == 0) {
+                if (out) {
+                    if (atomicCAS(stalled + 3, 0, tag + 2) == 0) { stalled[4] = (int)(prog - stalled); stalled[5] = need; stalled[6] = seen; }
+                    __hip_atomic_store((sx_gint*)stalled, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (out || __hip_atomic_load((const sx_gint*)stalled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { seen = 0x7fffffff; break; }
+            }
             __builtin_amdgcn_s_sleep(32);
         }
     }
@@ -131,6 +155,24 @@ __device__ __forceinline__ void sx_publish(int* prog, int blocks) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #endif
     __hip_atomic_store((sx_gint*)prog, blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- small kernels beside a gated chained launch (one workgroup each) ------------------------------------------------------
+// "the external inputs of the chunk's first `blocks` time blocks are complete": enqueued behind the kernels that produce them
+__global__ void sx_k_gate_bump(int* gate, int blocks) {
+    if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            __hip_atomic_store((sx_gint*)gate, blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+// waits until every listed group (list == null: every group of [g0, g1)) has published `need` blocks; the kernels enqueued behind it
+// (pack + send of a sub-chunk's boundary series; round 0 of the reverse sweep) then read what those groups stored.  Bounded like
+// every other wait: running out of polls raises the stall flag and returns.
+__global__ void sx_k_wait_groups(const int* prog, const int* list, int nlist, int g0, int g1, int need, int* stalled, int limit) {
+    const int n = list ? nlist : g1 - g0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int g = list ? list[i] : g0 + i;
+        int seen = 0;
+        sx_wait_prog(prog + g, need, seen, stalled, limit);
+    }
 }
 
 struct SxDeviceArrays {
@@ -174,7 +216,8 @@ struct SxDeviceArrays {
     const int *g_slot_begin, *g_dmax;
     const int *s_cell, *s_stage, *s_cstart, *s_ccount, *s_parent, *s_xout;
     const int *x_prod, *x_cons;   // per exchange series: publishing group / group holding the inlet (-1: other tile)
-    int* prog;                    // [ngroups + 1] blocks published by each group in the running launch; last = stall flag
+    int* prog;                    // [ngroups + SX_PROG_EXTRA]: blocks published by each group in the running launch, then the stall flag, the ticket
+                                  // counter and the gate (SX_PROG_STALL / _TICKET / _GATE)
     int ngroups;
     int spin_limit;               // polls before a waiting group gives up and raises the stall flag
     int mute_group;               // tests only (SMASHX_DEBUG_MUTE_GROUP): this group never publishes -> its consumers stall; -1 = none
@@ -577,12 +620,21 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
 // (qup = dt*(qup/temp), forward_db.f90:6464; q = temp*((qt + f*qrout)/dt), :8445-8448): forward_d's discharge differs
 // from forward's in the last bit, and the criteria derivatives amplify that to ~5e-6 of cost_d, so the tangent sweep
 // evaluates the primal the way forward_d does.
-template <bool TAPE, bool CHAIN, int TMODE = 0>
-__global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_fwd(SxDeviceArrays A, int g0, int gend, int t0, int T) {
+// draws the next ticket for the whole workgroup (chained launches); the barrier also separates two groups' use of the LDS rows
+__device__ __forceinline__ int sx_next_ticket(const SxDeviceArrays& A) {
+    __shared__ int s_ticket;
+    __builtin_amdgcn_s_barrier();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add((sx_gint*)SX_PROG_TICKET(A), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return s_ticket;
+}
+
+template <bool TAPE, bool CHAIN, int TMODE>
+__device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, const int g, const int g0, const int gend, const int t0, const int T,
+                                                   const bool gated) {
     constexpr bool TAN = (TMODE == 2);
     constexpr bool DFORM = (TMODE == 1);
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];   // [2][blockDim.x]
-    const int g = g0 + blockIdx.x;
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
     const int j = threadIdx.x, M = blockDim.x;
     const bool valid = j < m;
@@ -623,10 +675,13 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
     const int* wprog = nullptr;
     int seen = 0;
     if (CHAIN && xin >= 0) { const int pg = A.x_prod[xin]; if (pg >= g0 && pg < gend) wprog = A.prog + pg; }
+    // gated launch: everything else a slot reads -- its cell's runoff, a series published by round 0 or received from another
+    // rank -- belongs to a pipeline sub-chunk that may not have been produced yet: follow the gate
+    if (CHAIN && gated && valid && !wprog) wprog = SX_PROG_GATE(A);
     auto fetch = [&](int tb) -> float4 { return cell >= 0 ? sx_gload4s(src + (size_t)tb * sstride) : sx_gload4(src + (size_t)tb * sstride); };
 
     float4 nxt[SX_MU], outq[SX_MU], outh[SX_MU], nhr[SX_MU];
-    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - stage, nb), seen, A.prog + A.ngroups, A.spin_limit);
+    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - stage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
 #pragma unroll
     for (int u = 0; u < SX_MU; ++u) {
         const int tb = u - stage;
@@ -662,7 +717,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
         }
         if (mw == nmacro) break;
         // inputs of the next macro-step are requested now
-        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - stage, nb), seen, A.prog + A.ngroups, A.spin_limit);
+        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - stage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
             const int tb = SX_MU * (mw + 1) + u - stage;
@@ -767,6 +822,17 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
     }
 }
 
+// gated != 0: the launch spans several pipeline sub-chunks whose external inputs arrive while it runs (see "gate" above)
+template <bool TAPE, bool CHAIN, int TMODE = 0>
+__global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_fwd(SxDeviceArrays A, int g0, int gend, int t0, int T, int gated) {
+    if (!CHAIN) { sx_route_fwd_group<TAPE, false, TMODE>(A, g0 + (int)blockIdx.x, g0, gend, t0, T, false); return; }
+    for (;;) {
+        const int ticket = sx_next_ticket(A);
+        if (ticket >= gend - g0) break;
+        sx_route_fwd_group<TAPE, CHAIN, TMODE>(A, g0 + ticket, g0, gend, t0, T, gated != 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // routing adjoint: same groups, roots first, time descending.  Reverse of the q update, LINEAR_ROUTING_B
 // (forward_db.f90:6628-6652) and UPSTREAM_DISCHARGE_B (:6520-6564), as in GR_x_FORWARD_B :8649-8672.
@@ -774,10 +840,9 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
 // Same macro-step staging of global memory as the forward kernel.
 // ------------------------------------------------------------------------------------------------
 template <bool CHAIN>
-__global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDeviceArrays A, int g0, int gend, int t0, int T) {
+__device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, const int g, const int g0, const int gend, const int t0, const int T,
+                                                   const bool gated) {
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];
-    // chained rounds run roots-of-the-basin first: the producers of adjoint series get the low block indices
-    const int g = CHAIN ? gend - 1 - (int)blockIdx.x : g0 + (int)blockIdx.x;
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
     const int j = threadIdx.x, M = blockDim.x;
     const bool valid = j < m;
@@ -834,9 +899,11 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
     const int* wprog = nullptr;
     int seen = 0;
     if (CHAIN && root_in) { const int cg = A.x_cons[xout]; if (cg >= g0 && cg < gend) wprog = A.prog + cg; }
+    // gated launch: a root whose receiver lives on another rank reads an adjoint series that arrives sub-chunk by sub-chunk
+    if (CHAIN && gated && root_in && !wprog) wprog = SX_PROG_GATE(A);
     auto fetch_in = [&](int tb) -> float4 { return sx_gload4(x4 + (size_t)tb * A.nx + xout); };
     float4 nhr[SX_MU], nin[SX_MU], nsd[SX_MU], outq[SX_MU];
-    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - rstage, nb), seen, A.prog + A.ngroups, A.spin_limit);
+    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - rstage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
 #pragma unroll
     for (int u = 0; u < SX_MU; ++u) {
         const int tbr = u - rstage;
@@ -868,7 +935,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
             }
         }
         if (mw == nmacro) break;
-        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - rstage, nb), seen, A.prog + A.ngroups, A.spin_limit);
+        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - rstage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
 #pragma unroll
         for (int u = 0; u < SX_MU; ++u) {
             const int tbr = SX_MU * (mw + 1) + u - rstage;
@@ -939,6 +1006,17 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (j == 0 && g != A.mute_group) sx_publish(A.prog + g, nb);
+    }
+}
+
+template <bool CHAIN>
+__global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDeviceArrays A, int g0, int gend, int t0, int T, int gated) {
+    if (!CHAIN) { sx_route_adj_group<false>(A, g0 + (int)blockIdx.x, g0, gend, t0, T, false); return; }
+    // chained rounds run roots-of-the-basin first: tickets walk the groups downwards
+    for (;;) {
+        const int ticket = sx_next_ticket(A);
+        if (ticket >= gend - g0) break;
+        sx_route_adj_group<CHAIN>(A, gend - 1 - ticket, g0, gend, t0, T, gated != 0);
     }
 }
 
