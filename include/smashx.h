@@ -245,6 +245,21 @@ int smashx_halo_edges(const smashx_plan* plan, int* out_src, int* out_dst, int* 
 int smashx_plan_chunking(smashx_plan* plan, int* chunk_steps, int* pipe_steps);   /* fixes and returns the chunk lengths */
 int smashx_set_halo(smashx_plan* plan, float* d_out_buf, float* d_in_buf, smashx_halo_fn fn, void* user);
 
+/* Cost terms that span the tiles of a decomposition (round 3; reference smash/solver/optimize/mwd_cost.f90:139-154, 159-245).
+ *  - Regularisation (compute_jreg) needs nothing new: every plan holds whole (nrow, ncol) parameter / state planes, so every rank
+ *    evaluates the reference's ordered sums over the WHOLE grid -- bit-identical to the single domain -- and takes the gradient of
+ *    its own cells.  smashx_costs.cost_jreg is therefore the same on every rank and smashx_costs.cost contains wjreg * cost_jreg on
+ *    every rank: the cost of the decomposition is  sum over ranks of cost_jobs  +  wjreg * cost_jreg (once).
+ *  - The median over the negative-weight gauges (wgauge < 0, mwd_cost.f90:139-154 + quantile1d_r :675-723) needs the gauge_jobs of
+ *    gauges on other ranks.  slot_of_gauge[g] = position of local gauge g among ALL negative-weight gauges of the decomposition in
+ *    global gauge order (-1 for the others), nslots = their number (the same on every rank, > 0 even on a rank that owns none).
+ *    Between the two phases of the cost kernel the nslots values are summed over the ranks: by ncclAllReduce on the routing stream
+ *    when smashx_set_exchange is active, else by reduce_fn (host: sums n floats in place over the tiles; called once per sweep by
+ *    every tile).  Each rank's cost_jobs then carries its own gauges' share of the median (the interpolation weights of its slots),
+ *    so the sum over ranks is the reference's jobs.  nslots = 0 switches it off.  Call before smashx_set_options. */
+typedef int (*smashx_reduce_fn)(void* user, float* values, int n);
+int smashx_set_median_slots(smashx_plan* plan, int nslots, const int* slot_of_gauge, smashx_reduce_fn reduce_fn, void* user);
+
 /* ---- native exchange: grouped ncclSend / ncclRecv on the plan's routing stream ----------------------
  * The reference has no counterpart (its only parallel code is the OpenMP replica loop, mw_multiple_run.f90:96-117).
  * One RCCL communicator per process (= per GPU); rank 0 draws the id, every rank calls smashx_comm_create with it (the

@@ -23,9 +23,11 @@ SYMBOLS = [
     "smashx_set_forcing_layout", "smashx_forcing_info", "smashx_control_size", "smashx_control_set", "smashx_control_get",
     "smashx_control_gradient",
     "smashx_comm_unique_id", "smashx_comm_create", "smashx_comm_destroy", "smashx_comm_allreduce_sum", "smashx_set_exchange",
+    "smashx_set_median_slots",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
+REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_int)
 
 
 class Config(C.Structure):

@@ -356,6 +356,8 @@ struct smashx_plan {
     float *d_area = nullptr, *d_wgauge = nullptr, *d_qobs = nullptr, *d_qsim_b = nullptr, *d_cost_out = nullptr;
     SxGaugeSums* d_sums = nullptr; SxCostCoef* d_coef = nullptr;
     float* d_med = nullptr; int* d_med_idx = nullptr;    // median over negative-weight gauges
+    int med_nslots = 0; int* d_med_slot = nullptr; float* d_medx = nullptr; int* d_medx_idx = nullptr;   // ... of several tiles
+    smashx_reduce_fn med_fn = nullptr; void* med_user = nullptr; std::vector<int> med_slot_h;
     float jobs = 0.f;
     // optional whole-domain outputs of forward sweeps (host arrays owned by the caller)
     float* h_qsim_domain = nullptr; float* h_net_prcp_domain = nullptr; int dom_sparse = 0;
@@ -695,17 +697,34 @@ SxCostArgs cost_args(smashx_plan* p, float jobs_b) {
     C.gauge_gid = p->d_gauge_gid; C.gauge_flwacc = p->d_gauge_flwacc; C.area = p->d_area; C.wgauge = p->d_wgauge;
     C.qobs = p->d_qobs; C.qsim_b = p->d_qsim_b; C.sums = p->d_sums; C.coef = p->d_coef; C.out = p->d_cost_out;
     C.med = p->d_med; C.med_idx = p->d_med_idx;
+    C.nslots = p->med_nslots; C.slot = p->d_med_slot; C.medx = p->d_medx; C.medx_idx = p->d_medx_idx;
     C.jobs_b = jobs_b;
     return C;
 }
 
 int run_cost(smashx_plan* p, int adjoint, float cost_b) {
-    if (p->ng == 0) return 0;
+    if (p->ng == 0 && p->med_nslots == 0) return 0;      // (a tile without gauges still takes part in the sum of the median's slots)
     SxCostArgs C = cost_args(p, cost_b);
     p->mark_begin(4, p->stream_r);
-    hipLaunchKernelGGL(sx_k_cost_sums, dim3(p->ng), dim3(64), 0, p->stream_r, C);
-    hipLaunchKernelGGL(sx_k_cost_final, dim3(1), dim3(1), 0, p->stream_r, C, adjoint);
-    if (adjoint) {
+    if (p->ng > 0) hipLaunchKernelGGL(sx_k_cost_sums, dim3(p->ng), dim3(64), 0, p->stream_r, C);
+    if (p->med_nslots > 0) {
+        // the median spans several tiles: local gauge_jobs into their slots, slots summed over the ranks, then the median of all
+        HIPCHK(hipMemsetAsync(p->d_medx, 0, (size_t)p->med_nslots * sizeof(float), p->stream_r));
+        hipLaunchKernelGGL(sx_k_cost_final, dim3(1), dim3(1), 0, p->stream_r, C, adjoint, 1);
+        if (p->xcomm) {
+            NCCLCHK(rccl().AllReduce(p->d_medx, p->d_medx, (size_t)p->med_nslots, ncclFloat, ncclSum, p->xcomm->comm, p->stream_r));
+        } else if (p->med_fn) {
+            std::vector<float> h(p->med_nslots);
+            HIPCHK(hipMemcpyAsync(h.data(), p->d_medx, h.size() * sizeof(float), hipMemcpyDeviceToHost, p->stream_r));
+            HIPCHK(hipStreamSynchronize(p->stream_r));
+            if (p->med_fn(p->med_user, h.data(), p->med_nslots)) return fail(SMASHX_E_ARG, "median reduce callback failed");
+            HIPCHK(hipMemcpyAsync(p->d_medx, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, p->stream_r));
+            HIPCHK(hipStreamSynchronize(p->stream_r));
+        } else return fail(SMASHX_E_STATE, "median over the gauges of several tiles: no exchange to sum the slots (smashx_set_exchange or a reduce_fn)");
+        hipLaunchKernelGGL(sx_k_cost_final, dim3(1), dim3(1), 0, p->stream_r, C, adjoint, 2);
+    } else
+        hipLaunchKernelGGL(sx_k_cost_final, dim3(1), dim3(1), 0, p->stream_r, C, adjoint, 0);
+    if (adjoint && p->ng > 0) {
         const dim3 b(256), g1((p->nt + 255) / 256, p->ng), g2((p->nt + 255) / 256, p->ngc);
         hipLaunchKernelGGL(sx_k_cost_seeds, g1, b, 0, p->stream_r, C);
         hipLaunchKernelGGL(sx_k_cost_cellseeds, g2, b, 0, p->stream_r, C);
@@ -1126,14 +1145,15 @@ int smashx_set_options(smashx_plan* p, const smashx_options* o) {
     for (int j = 0; j < o->njr; ++j)
         if (o->jreg_fun[j] < SMASHX_PRIOR || o->jreg_fun[j] > SMASHX_HARD_SMOOTHING)
             return fail(SMASHX_E_UNSUPPORTED, "unknown jreg_fun (prior / smoothing / hard_smoothing, mwd_cost.f90:199-224)");
-    if (o->njr > 0 && p->tiled)
-        return fail(SMASHX_E_UNSUPPORTED, "jreg on a tiled plan: the regulariser is one ordered sum over the whole grid; evaluate it on an untiled plan");
     p->opt = *o;
     p->jr_ready = false;
     p->opt.wgauge = nullptr;
     for (int g = 0; g < p->ng; ++g) {
         const float w = o->wgauge ? o->wgauge[g] : 1.f / p->ng;
-        if (w < 0.f && p->tiled) return fail(SMASHX_E_UNSUPPORTED, "negative wgauge (median over gauges) on a tiled plan: the median needs every gauge on one plan");
+        if (w < 0.f && p->tiled && p->med_nslots == 0)
+            return fail(SMASHX_E_UNSUPPORTED, "negative wgauge (median over gauges) on a tiled plan: declare the slots of the whole decomposition first (smashx_set_median_slots)");
+        if (p->med_nslots > 0 && (w < 0.f) != (p->med_slot_h[g] >= 0))
+            return fail(SMASHX_E_ARG, "smashx_set_median_slots and wgauge disagree: exactly the negative-weight gauges have a slot");
         p->wgauge[g] = w;
     }
     HIPCHK(hipMemcpy(p->d_wgauge, p->wgauge.data(), p->wgauge.size() * 4, hipMemcpyHostToDevice));
@@ -1769,6 +1789,25 @@ int smashx_set_halo(smashx_plan* p, float* d_out_buf, float* d_in_buf, smashx_ha
     if (!p) return fail(SMASHX_E_ARG, "null plan");
     if (fn && ((p->n_out > 0 && !d_out_buf) || (p->n_in > 0 && !d_in_buf))) return fail(SMASHX_E_ARG, "halo buffers missing");
     p->halo_out = d_out_buf; p->halo_in = d_in_buf; p->halo_fn = fn; p->halo_user = user;
+    return 0;
+}
+
+int smashx_set_median_slots(smashx_plan* p, int nslots, const int* slot_of_gauge, smashx_reduce_fn fn, void* user) {
+    if (!p || nslots < 0 || (nslots > 0 && !slot_of_gauge)) return fail(SMASHX_E_ARG, "bad argument");
+    int rc = set_device(p); if (rc) return rc;
+    p->med_nslots = 0; p->med_fn = fn; p->med_user = user;
+    if (nslots == 0) return 0;
+    std::vector<int> sl(std::max(p->ng, 1), -1);
+    for (int g = 0; g < p->ng; ++g) {
+        sl[g] = slot_of_gauge[g];
+        if (sl[g] < -1 || sl[g] >= nslots) return fail(SMASHX_E_ARG, "slot_of_gauge out of range");
+    }
+    if (p->d_med_slot) { p->dfree(p->d_med_slot); p->dfree(p->d_medx); p->dfree(p->d_medx_idx); }
+    if ((rc = p->upload_vec(&p->d_med_slot, sl))) return rc;
+    p->med_slot_h = sl;
+    if ((rc = p->dmalloc(&p->d_medx, (size_t)3 * nslots))) return rc;
+    if ((rc = p->dmalloc(&p->d_medx_idx, (size_t)nslots))) return rc;
+    p->med_nslots = nslots;
     return 0;
 }
 

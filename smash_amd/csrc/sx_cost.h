@@ -47,6 +47,11 @@ struct SxCostArgs {
     float jobs_b;
     float* med;                     // [2 ng] gauge_jobs of the negative-weight gauges, then their adjoint weights
     int* med_idx;                   // [2 ng] sort permutation, then gauge of each entry
+    // tiled plans (smashx_set_median_slots): the negative-weight gauges of the whole decomposition, in global gauge order
+    int nslots;                     // 0: every gauge of the median is on this plan (the path above)
+    const int* slot;                // [ng] slot of a local negative-weight gauge, else -1
+    float* medx;                    // [3 nslots]: gauge_jobs of every slot (summed over the ranks between the two phases), sorted copy, weights
+    int* medx_idx;                  // [nslots] sort permutation
 };
 
 __device__ __forceinline__ float sx_qs(const SxCostArgs& C, int g, int t) {
@@ -148,12 +153,72 @@ __device__ inline void sx_heap_sort_idx(int n, float* arr, int* idx) {
     }
 }
 
-__global__ void sx_k_cost_final(SxCostArgs C, int adjoint) {
+// the per-criterion adjoint coefficients of one gauge given the seed of its gauge_jobs (COMPUTE_JOBS_B, forward_db.f90:2656-2704);
+// j_imd_b is the reference's scalar, carried from gauge to gauge
+__device__ inline void sx_cost_gauge_coef(const SxCostArgs& C, int g, float gauge_jobs_b, float& j_imd_b) {
+    const SxGaugeSums S = C.sums[g];
+    const bool any = S.n > 0;
+    const float n = (float)S.n;
+    for (int j = C.njf - 1; j >= 0; --j) {
+        j_imd_b = j_imd_b + C.wjobs_fun[j] * gauge_jobs_b;
+        if (!any) continue;
+        SxCostCoef c; c.kind = 0; c.c_xy = c.c_yy = c.c_y = c.c = 0.f;
+        switch (C.jobs_fun[j]) {
+            case 1: { const float mean_x = S.sum_x / n;
+                      const float den = S.sum_xx - n * mean_x * mean_x;
+                      const float num_b = j_imd_b / den;
+                      c.kind = 1; c.c_yy = num_b; c.c_xy = -(2.f * num_b); c.c_y = 0.f; j_imd_b = 0.f; } break;
+            case 2: { const SxKge k = sx_kge_components(S); sx_kge_coef(S, k, j_imd_b, c); j_imd_b = 0.f; } break;
+            case 3: { const SxKge k = sx_kge_components(S); const float imd = sx_kge_value(k);
+                      sx_kge_coef(S, k, 2.f * imd * j_imd_b, c); j_imd_b = 0.f; } break;
+            case 4: c.kind = 2; c.c = j_imd_b; j_imd_b = 0.f; break;
+            case 5: { const float result1 = S.se;
+                      c.kind = 2; c.c = (result1 / n == 0.f) ? 0.f : j_imd_b / (n * 2.0f * sqrtf(result1 / n)); j_imd_b = 0.f; } break;
+            case 6: c.kind = 3; c.c = j_imd_b; j_imd_b = 0.f; break;
+            default: break;
+        }
+        C.coef[g * SX_MAXJF + j] = c;
+    }
+}
+
+// phase 0: everything (plans that hold every gauge of the median).  Tiled plans with a median over gauges of several ranks run
+// phase 1 -- the gauge_jobs of the local negative-weight gauges into their slots of medx -- then sum medx over the ranks (one all-reduce of nslots floats) and run phase 2: the median of ALL slots, this plan's
+// share of it (the interpolation weights of its own slots: the shares of the ranks add up to the median) and the seeds of its gauges.
+__global__ void sx_k_cost_final(SxCostArgs C, int adjoint, int phase = 0) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float jobs = 0.f;
     int arr_size = 0;
     float* arr = C.med; float* arr_b = C.med + C.ng;
     int* perm = C.med_idx; int* arr_gauge = C.med_idx + C.ng;
+    if (phase == 2) {
+        // QUANTILE / QUANTILE_B over the slots of the whole decomposition (mwd_cost.f90:154, 675-723; forward_db.f90:4327-4370)
+        const int ns = C.nslots;
+        float* val = C.medx; float* srt = C.medx + ns; float* wq = C.medx + 2 * ns; int* pm = C.medx_idx;
+        for (int i = 0; i < ns; ++i) { srt[i] = val[i]; wq[i] = 0.f; pm[i] = i; }
+        if (ns > 1) {
+            sx_heap_sort_idx(ns, srt, pm);
+            const float frac = (float)(ns - 1) * 0.5f + 1.f;
+            if (frac <= 1.f) wq[pm[0]] = 1.f;
+            else if (frac >= (float)ns) wq[pm[ns - 1]] = 1.f;
+            else { const int k = (int)frac; const float f = frac - (float)k; wq[pm[k]] = wq[pm[k]] + f; wq[pm[k - 1]] = wq[pm[k - 1]] + (1.f - f); }
+        } else if (ns == 1) wq[0] = 1.f;
+        // the median REPLACES the weighted sum of the positive-weight gauges (mwd_cost.f90:154; phase 0 does the same: jobs = res,
+        // jobs_b = 0), so those neither enter the cost nor receive a seed
+        jobs = 0.f;
+        for (int g = 0; g < C.ng; ++g) { const int sl = C.slot[g]; if (sl >= 0) jobs = jobs + wq[sl] * val[sl]; }
+        C.out[0] = jobs;
+        if (!adjoint) return;
+        // seeds: the positive-weight gauges see jobs_b through their weight; the median's seed reaches a slot through its weight
+        float j_imd_b2 = 0.f;
+        for (int g = C.ng - 1; g >= 0; --g) {
+            for (int j = 0; j < SX_MAXJF; ++j) { SxCostCoef z; z.kind = 0; z.c_xy = z.c_yy = z.c_y = z.c = 0.f; C.coef[g * SX_MAXJF + j] = z; }
+            const float w = C.wgauge[g];
+            if (!(w > 0.f || w < 0.f)) continue;
+            const float gauge_jobs_b = (w > 0.f) ? 0.f : wq[C.slot[g]] * C.jobs_b;
+            sx_cost_gauge_coef(C, g, gauge_jobs_b, j_imd_b2);
+        }
+        return;
+    }
     for (int g = 0; g < C.ng; ++g) {
         const float w = C.wgauge[g];
         if (!(w > 0.f || w < 0.f)) continue;
@@ -179,8 +244,10 @@ __global__ void sx_k_cost_final(SxCostArgs C, int adjoint) {
             gauge_jobs = gauge_jobs + C.wjobs_fun[j] * j_imd;
         }
         if (w > 0.f) jobs = jobs + w * gauge_jobs;
+        else if (phase == 1) C.medx[C.slot[g]] = gauge_jobs;
         else { arr[arr_size] = gauge_jobs; arr_b[arr_size] = 0.f; perm[arr_size] = arr_size; arr_gauge[arr_size] = g; ++arr_size; }
     }
+    if (phase == 1) { C.out[2] = jobs; return; }
     float jobs_b = C.jobs_b;
     if (arr_size > 0) {
         // quantile(arr, 0.5) replaces the weighted sum (mwd_cost.f90:154, 675-723); QUANTILE_B forward_db.f90:4327-4370
@@ -214,27 +281,8 @@ __global__ void sx_k_cost_final(SxCostArgs C, int adjoint) {
         const SxGaugeSums S = C.sums[g];
         const bool any = S.n > 0;
         const float gauge_jobs_b = (w > 0.f) ? w * jobs_b : arr_b[--arr_size];
-        const float n = (float)S.n;
-        for (int j = C.njf - 1; j >= 0; --j) {
-            j_imd_b = j_imd_b + C.wjobs_fun[j] * gauge_jobs_b;
-            if (!any) continue;
-            SxCostCoef c; c.kind = 0; c.c_xy = c.c_yy = c.c_y = c.c = 0.f;
-            switch (C.jobs_fun[j]) {
-                case 1: { const float mean_x = S.sum_x / n;
-                          const float den = S.sum_xx - n * mean_x * mean_x;
-                          const float num_b = j_imd_b / den;
-                          c.kind = 1; c.c_yy = num_b; c.c_xy = -(2.f * num_b); c.c_y = 0.f; j_imd_b = 0.f; } break;
-                case 2: { const SxKge k = sx_kge_components(S); sx_kge_coef(S, k, j_imd_b, c); j_imd_b = 0.f; } break;
-                case 3: { const SxKge k = sx_kge_components(S); const float imd = sx_kge_value(k);
-                          sx_kge_coef(S, k, 2.f * imd * j_imd_b, c); j_imd_b = 0.f; } break;
-                case 4: c.kind = 2; c.c = j_imd_b; j_imd_b = 0.f; break;
-                case 5: { const float result1 = S.se;
-                          c.kind = 2; c.c = (result1 / n == 0.f) ? 0.f : j_imd_b / (n * 2.0f * sqrtf(result1 / n)); j_imd_b = 0.f; } break;
-                case 6: c.kind = 3; c.c = j_imd_b; j_imd_b = 0.f; break;
-                default: break;
-            }
-            C.coef[g * SX_MAXJF + j] = c;
-        }
+        (void)S; (void)any;
+        sx_cost_gauge_coef(C, g, gauge_jobs_b, j_imd_b);
     }
 }
 

@@ -217,6 +217,28 @@ class Solver:
         self._halo_cb = _lib.HALO_FN(tramp)
         _lib.check(_lib.lib().smashx_set_halo(self._h, C.c_void_p(out_ptr), C.c_void_p(in_ptr), self._halo_cb, None))
 
+    def set_median_slots(self, nslots, slot_of_gauge, reduce_fn=None):
+        """The median over the negative-weight gauges of a decomposition (include/smashx.h "cost terms that span the tiles";
+        tiles.median_slots builds the arguments).  reduce_fn(values: float32 array, in place) sums the slot values over the tiles;
+        not needed with the native exchange (set_exchange), which all-reduces them on the routing stream.  Call before set_options."""
+        sl = np.ascontiguousarray(slot_of_gauge, np.int32) if self.ng else np.full(1, -1, np.int32)
+        cb = None
+        if reduce_fn is not None:
+            def tramp(user, vals, n):
+                try:
+                    a = np.ctypeslib.as_array(vals, shape=(n,))
+                    reduce_fn(a)
+                    return 0
+                except Exception:  # pragma: no cover
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            cb = _lib.REDUCE_FN(tramp)
+        self._median_cb = cb
+        fn = _lib.lib().smashx_set_median_slots
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.check(fn(self._h, int(nslots), _ptr(sl), C.cast(cb, C.c_void_p) if cb is not None else None, None))
+
     def set_exchange(self, comm, out_peer, in_peer):
         """Native exchange (smashx_set_exchange): comm = a Comm (or None to unset); out_peer / in_peer = the rank owning the
         other end of every out / in boundary edge, in the order of halo_edges()."""

@@ -79,6 +79,22 @@ def partition_subcatchments(mesh, nparts: int):
     return np.asfortranarray(owner.reshape(nrow, ncol).astype(np.int32))
 
 
+def median_slots(wgauge_global, local_gauges):
+    """Arguments of Solver.set_median_slots for one tile: the negative-weight gauges of the whole decomposition are numbered in
+    global gauge order (the order the reference's compute_jobs collects them in, mwd_cost.f90:139-150); local_gauges = the global
+    indices of this tile's gauges, in the tile's order.  Returns (nslots, slot_of_gauge)."""
+    w = np.asarray(wgauge_global, np.float32)
+    neg = np.flatnonzero(w < 0)
+    slot = {int(g): i for i, g in enumerate(neg)}
+    return len(neg), np.array([slot.get(int(g), -1) for g in local_gauges], np.int32)
+
+
+def decomposition_cost(cost_jobs_per_rank, cost_jreg, wjreg):
+    """The cost of a decomposition from the ranks' smashx_costs: every rank evaluates the regulariser over the whole grid (same
+    cost_jreg everywhere), so it enters once: sum(cost_jobs) + wjreg * cost_jreg (mwd_cost.f90:300)."""
+    return float(np.sum(np.asarray(cost_jobs_per_rank, np.float64)) + float(wjreg) * float(cost_jreg))
+
+
 class PeerLists:
     """For one tile: which rows of the out / in message buffers go to / come from which peer rank.
     owner: optional (nrow, ncol) part id per cell (partition_subcatchments) instead of the pr x pc rectangles."""

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--pipe", type=int, default=16)
     ap.add_argument("--exchange", default="rccl")
     ap.add_argument("--cut", default="rect")
+    ap.add_argument("--opts", action="store_true", help="the fixture's own calibration options (criteria, normalisation, regularisers, "
+                    "gauge weights incl. the median over gauges) instead of the plain nse of the short window")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 
@@ -46,8 +48,8 @@ def main():
     import smash_amd
     from smash_amd.solver import Comm, Solver
     from test_gpu_parity import _run_adjoint
-    from test_gpu_tiles import _short, _tile_inputs
-    g = _short(a.case, a.nt)
+    from test_gpu_tiles import _apply_opts, _short, _tile_inputs
+    g = gu.load(a.case) if a.opts else _short(a.case, a.nt)
     _, _, ref_out, ref_pb, ref_sb = _run_adjoint(g)
     pr, pc = tiles.tile_grid(world)
     nrow, ncol = g.mesh.nrow, g.mesh.ncol
@@ -66,6 +68,12 @@ def main():
     sol.set_forcing(g.prcp, g.pet)
     if loc:
         sol.set_qobs(np.asfortranarray(g.qobs[loc]))
+    nslots = 0
+    if a.opts:
+        nslots, slots = _apply_opts(setup, g, loc)
+        if nslots:                                  # the median's slots are summed over the ranks by RCCL on the routing stream (native exchange)
+            assert a.exchange == "rccl"
+            sol.set_median_slots(nslots, slots)
     sol.set_options(setup.optimize)
     comm = None
     if a.exchange == "rccl":
@@ -81,8 +89,13 @@ def main():
     out = smash_amd.OutputDT(setup, mesh)
     pb, sb = par.copy(), sta.copy()
     bad = []
+    bgd = ()
+    if a.opts and "params_bgd" in g.opts:
+        bgd = (smash_amd.ParametersDT.from_dict(mesh, g.opts["params_bgd"]), smash_amd.StatesDT.from_dict(mesh, g.opts["states_bgd"]))
     for rep in range(2):                            # twice: the second sweep reuses every buffer and the communicator
-        sol.upload(par, sta)
+        if a.opts:                                  # (a normalised control comes back denormalised: start from the fixture's fields again)
+            par, sta = smash_amd.ParametersDT.from_dict(mesh, g.params), smash_amd.StatesDT.from_dict(mesh, g.states)
+        sol.upload(par, sta, *bgd)
         sol.sweep(True, 1.0)
         say(f"sweep {rep} done")
         sol.download(True, par, sta, out, pb, sb)
@@ -95,12 +108,16 @@ def main():
         for k in gu.STRUCT_STATES[g.structure]:
             if not np.array_equal(getattr(sb, k)[rows, cols], getattr(ref_sb, k)[rows, cols]):
                 bad.append((k, rep))
+    # the regulariser is evaluated over the whole grid by every rank (same bits as the single domain) and enters the cost once
+    if out.cost_jreg != ref_out.cost_jreg:
+        bad.append(("cost_jreg", out.cost_jreg, ref_out.cost_jreg))
     if comm is not None:
-        cost = float(comm.allreduce_sum([out.cost])[0])
+        jobs = float(comm.allreduce_sum([out.cost_jobs])[0])
     else:
-        ct = torch.tensor([out.cost], dtype=torch.float64, device=dev)
+        ct = torch.tensor([out.cost_jobs], dtype=torch.float64, device=dev)
         dist.all_reduce(ct)
-        cost = float(ct.item())
+        jobs = float(ct.item())
+    cost = tiles.decomposition_cost([jobs], out.cost_jreg, float(g.opts.get("wjreg", 0.0)) if a.opts else 0.0)
     if abs(cost - ref_out.cost) > 1e-6 * abs(ref_out.cost) + 1e-7:
         bad.append(("cost", cost, ref_out.cost))
     n_out, n_in = sol.halo_counts()

@@ -39,6 +39,14 @@ def test_subcatchment_parts_over_rccl_equal_single_domain():
     _launch(3, ["--case", "gr_c_32x32x240_d8_ragged", "--cut", "sub", "--chunk", "96", "--pipe", "16"], 7)
 
 
+def test_regularisation_and_median_across_ranks_over_rccl():
+    """Cost terms that span the ranks (smashx.h): the regulariser's ordered sums over the whole grid on every rank of a 2 x 2
+    decomposition (cost_jreg and gradients bit-identical to the single domain), and the median over negative-weight gauges that sit
+    on different ranks, its slots summed by ncclAllReduce on the routing stream between the two phases of the cost kernel."""
+    _launch(4, ["--case", "gr_b_24x24x120_norm_jreg", "--opts", "--chunk", "64", "--pipe", "16"], 11)
+    _launch(2, ["--case", "gr_b_16x16x96_median2", "--opts", "--cut", "sub", "--chunk", "96", "--pipe", "32"], 13)
+
+
 def test_bench_self_launch_two_ranks():
     """python bench.py --gpus 2 with no launcher starts both ranks itself and prints one JSON line with n_gpus = 2."""
     import json

@@ -68,6 +68,40 @@ def _tile_inputs(g, rect, ng_total, mine=None):
     return setup, mesh, loc
 
 
+def _apply_opts(setup, g, loc):
+    """The fixture's own calibration options on a tile's setup: criteria, start step, normalisation, regularisers, flags and bounds as
+    they are, the weights of the tile's gauges; returns (nslots, slot_of_gauge) of the median over the decomposition's gauges."""
+    from smash_amd import tiles
+    o = setup.optimize
+    o.jobs_fun = list(g.opts.get("jobs_fun", ("nse",)))
+    o.wjobs_fun = list(g.opts.get("wjobs_fun", (1.0,)))
+    o.optimize_start_step = int(g.opts.get("optimize_start_step", 1))
+    o.denormalize_forward = bool(g.opts.get("denormalize_forward", False))
+    wg = np.asarray(g.opts.get("wgauge", np.full(g.mesh.ng, 1.0 / g.mesh.ng)), np.float32)
+    o.wgauge = wg[loc] if loc else np.zeros(0, np.float32)
+    if "jreg_fun" in g.opts:
+        o.jreg_fun, o.wjreg_fun, o.wjreg = list(g.opts["jreg_fun"]), list(g.opts["wjreg_fun"]), float(g.opts["wjreg"])
+    if "optim_parameters" in g.opts:
+        o.optim_parameters = np.asarray(g.opts["optim_parameters"], np.int32)
+        o.optim_states = np.asarray(g.opts["optim_states"], np.int32)
+    return tiles.median_slots(wg, loc)
+
+
+class _SumOverTiles:
+    """reduce_fn of Solver.set_median_slots for plans that live in one process: every tile's thread adds its values, all read the sum."""
+
+    def __init__(self, world):
+        self.bar, self.lock, self.acc = threading.Barrier(world), threading.Lock(), None
+
+    def __call__(self, vals):
+        with self.lock:
+            self.acc = vals.copy() if self.acc is None else self.acc + vals
+        self.bar.wait(timeout=120)
+        vals[:] = self.acc
+        if self.bar.wait(timeout=120) == 0:
+            self.acc = None
+
+
 def _short(name, nt):
     g = gu.load(name)
     g.nt = nt                                     # a short window keeps 8 plans on one card cheap
@@ -93,7 +127,7 @@ def test_subcatchment_partition_equals_single_domain(name, world, chunk, pipe, c
     _check_partitioned(g, world, chunk, pipe, owner)
 
 
-def _check_partitioned(g, world, chunk, pipe, owner):
+def _check_partitioned(g, world, chunk, pipe, owner, keep_opts=False):
     import torch
     torch.zeros(1, device="cuda")                 # initialise torch's HIP context in the main thread
     import smash_amd
@@ -101,6 +135,7 @@ def _check_partitioned(g, world, chunk, pipe, owner):
     from smash_amd.solver import Solver
     from test_gpu_parity import _run_adjoint
     _, _, ref_out, ref_pb, ref_sb = _run_adjoint(g)
+    summer = _SumOverTiles(world)
     pr, pc = tiles.tile_grid(world)
     nrow, ncol = g.mesh.nrow, g.mesh.ncol
     box = {(a, b, k): queue.Queue() for a in range(world) for b in range(world) for k in "fa"}
@@ -121,13 +156,20 @@ def _check_partitioned(g, world, chunk, pipe, owner):
             sol.set_forcing(g.prcp, g.pet)
             if loc:
                 sol.set_qobs(np.asfortranarray(g.qobs[loc]))
+            if keep_opts:
+                nslots, slots = _apply_opts(setup, g, loc)
+                if nslots:
+                    sol.set_median_slots(nslots, slots, summer)
             sol.set_options(setup.optimize)
             ex = Loopback(rank, sol, nrow, ncol, pr, pc, box, owner)
             par = smash_amd.ParametersDT.from_dict(mesh, g.params)
             sta = smash_amd.StatesDT.from_dict(mesh, g.states)
             out = smash_amd.OutputDT(setup, mesh)
             pb, sb = par.copy(), sta.copy()
-            sol.upload(par, sta)
+            if keep_opts and "params_bgd" in g.opts:
+                sol.upload(par, sta, smash_amd.ParametersDT.from_dict(mesh, g.opts["params_bgd"]), smash_amd.StatesDT.from_dict(mesh, g.opts["states_bgd"]))
+            else:
+                sol.upload(par, sta)
             sol.sweep(True, 1.0)
             sol.download(True, par, sta, out, pb, sb)
             res[rank] = (loc, out, pb, sb, rows, cols, ex.calls)
@@ -143,16 +185,48 @@ def _check_partitioned(g, world, chunk, pipe, owner):
         t.join(timeout=300)
     assert not errs and len(res) == world
     cost = 0.0
+    owned = np.zeros((nrow, ncol), bool)
     for rank, (loc, out, pb, sb, rows, cols, calls) in res.items():
-        cost += out.cost
+        # every rank evaluates the regulariser over the whole grid: the same cost_jreg everywhere, counted once (smashx.h)
+        cost += out.cost_jobs
+        assert out.cost_jreg == ref_out.cost_jreg, (rank, out.cost_jreg, ref_out.cost_jreg)
+        owned[rows, cols] = True
         for i, gi in enumerate(loc):
             assert np.array_equal(out.qsim[i], ref_out.qsim[gi]), (rank, gi)
         for k in gu.STRUCT_PARAMS[g.structure]:
             assert np.array_equal(getattr(pb, k)[rows, cols], getattr(ref_pb, k)[rows, cols]), (rank, k)
         for k in gu.STRUCT_STATES[g.structure]:
             assert np.array_equal(getattr(sb, k)[rows, cols], getattr(ref_sb, k)[rows, cols]), (rank, k)
-    assert abs(cost - ref_out.cost) <= 1e-6 * abs(ref_out.cost) + 1e-7
+    cost = tiles.decomposition_cost([cost], ref_out.cost_jreg, float(g.opts.get("wjreg", 0.0)) if keep_opts else 0.0)
+    assert abs(cost - ref_out.cost) <= 1e-6 * abs(ref_out.cost) + 1e-7, (cost, ref_out.cost)
     assert sum(r[6] for r in res.values()) > 0       # the exchange really ran
+    if keep_opts and "jreg_fun" in g.opts:
+        # cells nobody owns (inactive ones) only carry the regulariser's gradient, which every rank holds for the whole grid
+        _, _, pb0, sb0, _, _, _ = res[0]
+        for k in gu.STRUCT_PARAMS[g.structure]:
+            assert np.array_equal(getattr(pb0, k)[~owned], getattr(ref_pb, k)[~owned]), k
+
+
+def test_regularisation_on_tiles_equals_single_domain():
+    """compute_jreg (prior + smoothing + hard smoothing, normalised control, mwd_cost.f90:159-245, 1100-1221) on a 2 x 2 decomposition:
+    every plan holds whole parameter planes, evaluates the reference's ordered sums over the WHOLE grid and takes the gradient of its own
+    cells -- cost_jreg and every gradient field bit-identical to the single domain, the cost = sum(cost_jobs) + wjreg * cost_jreg."""
+    _check_partitioned(gu.load("gr_b_24x24x120_norm_jreg"), 4, 64, 16, None, keep_opts=True)
+
+
+@pytest.mark.parametrize("name,world", [("gr_a_16x16x96_median3", 4), ("gr_b_16x16x96_median2", 2)])
+def test_median_over_gauges_of_several_tiles(name, world):
+    """wgauge < 0: the cost is the median of the gauges' criteria (mwd_cost.f90:139-154, quantile1d_r).  The gauges sit in different
+    sub-catchment parts: each plan computes its own gauges' criteria, the slots are summed over the parts between the two phases of
+    the cost kernel (smashx_set_median_slots), every plan takes the median of all -- discharge and gradients bit-identical to the
+    single domain, the parts' cost_jobs add up to the reference's cost."""
+    from smash_amd import tiles
+    g = gu.load(name)
+    owner = tiles.partition_subcatchments(g.mesh, world)
+    wg = np.asarray(g.opts["wgauge"])
+    gp = np.asarray(g.mesh.gauge_pos)
+    assert len({int(np.asarray(owner)[r, c]) for (r, c), w in zip(gp, wg) if w < 0}) > 1      # the median really spans parts
+    _check_partitioned(g, world, 96, 32, owner, keep_opts=True)
 
 
 def test_tile_refuses_self_sized_chunks():
