@@ -344,8 +344,14 @@ __device__ __forceinline__ void sx_forcing_at(const SxDeviceArrays& A, int t, un
 // ------------------------------------------------------------------------------------------------
 // vertical forward: one thread per cell marches the time chunk [t0, t0+T)
 // ------------------------------------------------------------------------------------------------
+// gr-b with the tape on and the compact forcing (the headline's forward kernel) comes out at 68 registers = 7 waves per SIMD; held to
+// 64 (two values spilled, outside the time loop's critical path) it runs 8: 41.2 -> 39.7 ms at 1024^2 x 8760, 239.7 -> 232.2 ms per
+// sweep at 2048^2.  The other instantiations are at or below 64 anyway, or (gr-c) would spill 6-10 registers: left alone.
+#ifndef SX_VFWD_WAVES
+#define SX_VFWD_WAVES 8
+#endif
 template <int ST, bool TAPE, bool CF>
-__global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
+__global__ __launch_bounds__(SX_VBLOCK, (ST == 2 && TAPE && CF) ? SX_VFWD_WAVES : 1) void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
     SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
