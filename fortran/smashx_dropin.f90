@@ -292,7 +292,10 @@ subroutine smashx_prepare(setup, mesh, input_data, plain)
     type(c_ptr) :: fkey
     integer :: key(6), j, want_layout
     type(smashx_forcing_layout) :: lay
-    integer(c_long) :: n2, nf, hmesh, hforce
+    integer(c_long) :: n2, nf, hmesh, hforce, hstep
+    integer(c_long), save :: rehash_count = 0
+    character(len=8) :: envbuf
+    integer :: envstat
     integer(c_int), pointer :: wp(:), we(:)
     integer(c_int) :: abi(7), ver
     type(smashx_parameters) :: abi_p
@@ -325,7 +328,10 @@ subroutine smashx_prepare(setup, mesh, input_data, plain)
         hmesh = sx_hash_words(mesh%gauge_pos, 2_c_long*mesh%ng, 1_c_long, hmesh)
         hmesh = sx_hash_words(transfer(mesh%area, [1_c_int]), int(mesh%ng, c_long), 1_c_long, hmesh)
     end if
-    !  forcing: ~65 k samples per field, every call (0.1 ms); transfer() would copy the arrays, so the words are read in place
+    !  forcing: fields up to 2**24 values are hashed whole, larger ones by ~65 k samples per field (0.1 ms per call; hashing 70 GB would
+    !  cost more than the sweep) -- an in-place edit of a small window of a LARGE field can therefore go unnoticed: set the environment
+    !  variable SMASHX_DROPIN_REHASH=1 to force a fresh upload on every call, or touch a sampled value.  transfer() would copy the
+    !  arrays, so the words are read in place
     if (setup%sparse_storage) then
         nf = int(size(input_data%sparse_prcp, kind=c_long), c_long)
         call c_f_pointer(c_loc(input_data%sparse_prcp), wp, [nf])
@@ -335,8 +341,15 @@ subroutine smashx_prepare(setup, mesh, input_data, plain)
         call c_f_pointer(c_loc(input_data%prcp), wp, [nf])
         call c_f_pointer(c_loc(input_data%pet), we, [nf])
     end if
-    hforce = sx_hash_words(wp, nf, max(1_c_long, nf/65536_c_long), 11_c_long)
-    hforce = sx_hash_words(we, nf, max(1_c_long, nf/65536_c_long), hforce)
+    hstep = 1_c_long
+    if (nf .gt. 16777216_c_long) hstep = max(1_c_long, nf/65536_c_long)
+    hforce = sx_hash_words(wp, nf, hstep, 11_c_long)
+    hforce = sx_hash_words(we, nf, hstep, hforce)
+    call get_environment_variable("SMASHX_DROPIN_REHASH", envbuf, status=envstat)
+    if (envstat .eq. 0 .and. envbuf(1:1) .eq. '1') then
+        rehash_count = rehash_count + 1_c_long
+        hforce = hforce + rehash_count        ! never equal to the cached value: the forcing is sent again
+    end if
 
     want_layout = 0
     if (setup%daily_interannual_pet .and. abs(setup%dt - 3600._sp) .lt. 0.5_sp .and. setup%prcp_conversion_factor .gt. 0._sp) &

@@ -284,6 +284,7 @@ struct SxComm {
     int rank = 0, nranks = 1, device = -1;
     hipStream_t stream = nullptr;    // collectives outside the sweeps (agreement check, cost sum)
     double* d_buf = nullptr;         // 64 doubles
+    std::vector<smashx_plan*> plans; // plans whose exchange runs on this communicator: unhooked when it is destroyed
 };
 struct PeerSeg { int rank, first, count; };   // a run of boundary edges that share the peer rank
 
@@ -349,6 +350,7 @@ struct smashx_plan {
     smashx_forcing_layout flay{};
     unsigned short* d_prcp16 = nullptr; float* d_petd = nullptr; float* d_ratio = nullptr; unsigned* d_fstatus = nullptr;
     int ndays = 0; bool petd_open = false;
+    std::vector<char> block_seen;    // device-block uploads: steps covered so far (the forcing counts as set once every step is)
     // cost
     int ngc = 0;
     std::vector<int> gauge_gid;
@@ -940,6 +942,7 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
 int smashx_plan_destroy(smashx_plan* p) {
     if (!p) return 0;
     (void)set_device(p);
+    if (p->xcomm) { auto& v = p->xcomm->plans; v.erase(std::remove(v.begin(), v.end(), p), v.end()); }
     if (p->stream) (void)hipStreamSynchronize(p->stream);
     if (p->stream_r) (void)hipStreamSynchronize(p->stream_r);
     for (void* q : p->allocs) (void)hipFree(q);
@@ -1097,6 +1100,14 @@ int smashx_set_forcing(smashx_plan* p, const float* prcp, const float* pet, int 
     return 0;
 }
 
+// The forcing only counts as set once device blocks have covered every step of [0, nt): a sweep started earlier would close the
+// daily PET of days it has not seen (k_close_petd pins them to 0) and later blocks for those days would then fail verification.
+static void mark_block(smashx_plan* p, int t0, int t1) {
+    if (t0 == 0 || (int)p->block_seen.size() != p->nt) { if (t0 == 0) p->block_seen.assign(p->nt, 0); else p->block_seen.resize(p->nt, 0); }
+    std::fill(p->block_seen.begin() + t0, p->block_seen.begin() + t1, 1);
+    p->have_forcing = std::find(p->block_seen.begin(), p->block_seen.end(), 0) == p->block_seen.end();
+}
+
 int smashx_set_forcing_device_block(smashx_plan* p, int t0, int t1, const float* d_prcp, const float* d_pet) {
     if (!p || !d_prcp || !d_pet || t0 < 0 || t1 > p->nt || t0 >= t1) return fail(SMASHX_E_ARG, "bad block");
     int rc = set_device(p); if (rc) return rc;
@@ -1113,13 +1124,13 @@ int smashx_set_forcing_device_block(smashx_plan* p, int t0, int t1, const float*
             return fail(SMASHX_E_UNSUPPORTED, "forcing block [" + std::to_string(t0) + ", " + std::to_string(t1) + ") is not of the compact form "
                         "(prcp = k * factor with k < 65535 or one gap value; pet = daily * ratio(hour)): reset the layout to fp32 and send the forcing again");
         }
-        p->have_forcing = true;
+        mark_block(p, t0, t1);
         return 0;
     }
     HIPCHK(hipMemcpy2DAsync(p->d_prcp + (size_t)t0 * p->npad, (size_t)p->npad * 4, d_prcp, (size_t)p->n * 4, (size_t)p->n * 4, t1 - t0, hipMemcpyDeviceToDevice, p->stream));
     HIPCHK(hipMemcpy2DAsync(p->d_pet + (size_t)t0 * p->npad, (size_t)p->npad * 4, d_pet, (size_t)p->n * 4, (size_t)p->n * 4, t1 - t0, hipMemcpyDeviceToDevice, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
-    p->have_forcing = true;
+    mark_block(p, t0, t1);
     return 0;
 }
 
@@ -1842,10 +1853,13 @@ int smashx_comm_create(const unsigned char id[SMASHX_COMM_ID_BYTES], int rank, i
     return 0;
 }
 
+static void smashx_forget_comm(smashx_plan* p, SxComm* c) { if (p->xcomm == c) p->xcomm = nullptr; }
+
 int smashx_comm_destroy(void* comm) {
     SxComm* c = (SxComm*)comm;
     if (!c) return 0;
     if (c->device >= 0) (void)hipSetDevice(c->device);
+    for (smashx_plan* q : c->plans) smashx_forget_comm(q, c);      // no plan keeps a pointer to a communicator that is gone
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->d_buf) (void)hipFree(c->d_buf);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
@@ -1869,27 +1883,25 @@ int smashx_set_exchange(smashx_plan* p, void* comm, const int* out_peer, const i
     if (!p) return fail(SMASHX_E_ARG, "null plan");
     SxComm* c = (SxComm*)comm;
     if (!c) { p->xcomm = nullptr; return 0; }
-    if ((p->n_out > 0 && !out_peer) || (p->n_in > 0 && !in_peer)) return fail(SMASHX_E_ARG, "peer lists missing");
-    int rc = set_device(p); if (rc) return rc;
-    if ((rc = ensure_chunk_buffers(p, false))) return rc;
-    // every rank must cut time identically: the messages are per pipeline sub-chunk
-    {
-        RcclApi& R = rccl();
-        double v[6] = {(double)p->Tc, -(double)p->Tc, (double)p->Tp, -(double)p->Tp, (double)p->nt, -(double)p->nt};
-        HIPCHK(hipMemcpyAsync(c->d_buf, v, sizeof(v), hipMemcpyHostToDevice, c->stream));
-        NCCLCHK(R.AllReduce(c->d_buf, c->d_buf, 6, ncclDouble, ncclMax, c->comm, c->stream));
-        HIPCHK(hipMemcpyAsync(v, c->d_buf, sizeof(v), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (v[0] != -v[1] || v[2] != -v[3] || v[4] != -v[5])
-            return fail(SMASHX_E_ARG, "the ranks of the decomposition disagree on chunk_steps / pipe_steps / nt (this rank: " +
-                                      std::to_string(p->Tc) + " / " + std::to_string(p->Tp) + " / " + std::to_string(p->nt) + ")");
-    }
+    // The call is collective (an agreement all-reduce, then one grouped hello exchange): a rank that left early would leave its
+    // neighbours waiting inside ncclGroupEnd for ever.  So everything that can fail locally -- argument checks, regrouping, allocations --
+    // happens FIRST and only feeds a status word; the ranks then agree on the status together with the chunking, and enter the hello
+    // group only if every rank reported success.
+    int rc = 0, lrc = 0;
+    std::string lerr;
+    auto local = [&](int code, const std::string& msg) { if (!lrc) { lrc = code; lerr = msg; } };
+    if ((p->n_out > 0 && !out_peer) || (p->n_in > 0 && !in_peer)) local(SMASHX_E_ARG, "peer lists missing");
+    if ((rc = set_device(p))) return rc;            // (a wrong device id is a caller bug on this rank alone: nothing collective has started)
+    if (!lrc && (rc = ensure_chunk_buffers(p, false))) local(rc, g_err);
     // regroup the boundary edges by peer rank; inside a peer they keep the order both sides share (sorted by source cell)
-    auto regroup = [&](int n, const int* peer, const std::vector<int>& xs, std::vector<PeerSeg>& segs, int** d_xp) -> int {
+    std::vector<PeerSeg> out_segs, in_segs;
+    std::vector<int> out_xp, in_xp;
+    auto regroup = [&](int n, const int* peer, const std::vector<int>& xs, std::vector<PeerSeg>& segs, std::vector<int>& xp) {
         segs.clear();
-        std::vector<int> order(n), xp(std::max(n, 1), 0);
+        std::vector<int> order(n);
+        xp.assign(std::max(n, 1), 0);
         for (int i = 0; i < n; ++i) {
-            if (peer[i] < 0 || peer[i] >= c->nranks || peer[i] == c->rank) return fail(SMASHX_E_ARG, "boundary edge with a bad peer rank");
+            if (peer[i] < 0 || peer[i] >= c->nranks || peer[i] == c->rank) { local(SMASHX_E_ARG, "boundary edge with a bad peer rank"); return; }
             order[i] = i;
         }
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return peer[a] < peer[b]; });
@@ -1898,13 +1910,39 @@ int smashx_set_exchange(smashx_plan* p, void* comm, const int* out_peer, const i
             if (segs.empty() || segs.back().rank != peer[order[i]]) segs.push_back(PeerSeg{peer[order[i]], i, 0});
             segs.back().count++;
         }
-        return p->upload_vec(d_xp, xp);
     };
-    if ((rc = regroup(p->n_out, out_peer, p->sch.out_x, p->out_segs, &p->d_out_xp))) return rc;
-    if ((rc = regroup(p->n_in, in_peer, p->sch.in_x, p->in_segs, &p->d_in_xp))) return rc;
-    if (!p->x_out) {
-        if ((rc = p->dmalloc(&p->x_out, (size_t)std::max(p->n_out, 1) * p->Tp))) return rc;
-        if ((rc = p->dmalloc(&p->x_in, (size_t)std::max(p->n_in, 1) * p->Tp))) return rc;
+    if (!lrc) regroup(p->n_out, out_peer, p->sch.out_x, out_segs, out_xp);
+    if (!lrc) regroup(p->n_in, in_peer, p->sch.in_x, in_segs, in_xp);
+    int *d_oxp = nullptr, *d_ixp = nullptr;
+    float* hello = nullptr;
+    std::vector<int> peers;
+    if (!lrc) {
+        for (const PeerSeg& sg : out_segs) peers.push_back(sg.rank);
+        for (const PeerSeg& sg : in_segs) if (std::find(peers.begin(), peers.end(), sg.rank) == peers.end()) peers.push_back(sg.rank);
+        std::sort(peers.begin(), peers.end());
+        if ((rc = p->upload_vec(&d_oxp, out_xp)) || (rc = p->upload_vec(&d_ixp, in_xp)) || (rc = p->dmalloc(&hello, 2 * std::max<size_t>(peers.size(), 1))))
+            local(rc, g_err);
+        if (!lrc && !p->x_out) {
+            if ((rc = p->dmalloc(&p->x_out, (size_t)std::max(p->n_out, 1) * p->Tp)) || (rc = p->dmalloc(&p->x_in, (size_t)std::max(p->n_in, 1) * p->Tp)))
+                local(rc, g_err);
+        }
+    }
+    auto drop_new = [&]() { if (d_oxp) p->dfree(d_oxp); if (d_ixp) p->dfree(d_ixp); if (hello) p->dfree(hello); };
+    // every rank must cut time identically (the messages are per pipeline sub-chunk), and every rank must have got this far
+    {
+        RcclApi& R = rccl();
+        double v[7] = {(double)p->Tc, -(double)p->Tc, (double)p->Tp, -(double)p->Tp, (double)p->nt, -(double)p->nt, lrc ? 1.0 : 0.0};
+        HIPCHK(hipMemcpyAsync(c->d_buf, v, sizeof(v), hipMemcpyHostToDevice, c->stream));
+        NCCLCHK(R.AllReduce(c->d_buf, c->d_buf, 7, ncclDouble, ncclMax, c->comm, c->stream));
+        HIPCHK(hipMemcpyAsync(v, c->d_buf, sizeof(v), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (lrc) { drop_new(); return fail(lrc, lerr); }
+        if (v[6] != 0.0) { drop_new(); return fail(SMASHX_E_STATE, "smashx_set_exchange failed on another rank of the decomposition"); }
+        if (v[0] != -v[1] || v[2] != -v[3] || v[4] != -v[5]) {
+            drop_new();
+            return fail(SMASHX_E_ARG, "the ranks of the decomposition disagree on chunk_steps / pipe_steps / nt (this rank: " +
+                                      std::to_string(p->Tc) + " / " + std::to_string(p->Tp) + " / " + std::to_string(p->nt) + ")");
+        }
     }
     // Connect now, symmetrically: RCCL sets a point-to-point connection up the first time a pair is used, inside ncclGroupEnd on the
     // HOST, and both ends must be inside a group naming each other at that moment.  During a sweep the ranks reach their groups in
@@ -1912,28 +1950,25 @@ int smashx_set_exchange(smashx_plan* p, void* comm, const int* out_peer, const i
     // group while B waits for A's current one (observed: 3 sub-catchment parts hang in their first sub-chunk).  Here every rank
     // exchanges one float with each neighbour in both directions within ONE group -- the all-to-all shape RCCL's schedule is built
     // for -- so no connection is ever set up inside a sweep.
-    {
+    if (!peers.empty()) {
         RcclApi& R = rccl();
-        std::vector<int> peers;
-        for (const PeerSeg& sg : p->out_segs) peers.push_back(sg.rank);
-        for (const PeerSeg& sg : p->in_segs) if (std::find(peers.begin(), peers.end(), sg.rank) == peers.end()) peers.push_back(sg.rank);
-        std::sort(peers.begin(), peers.end());
-        if (!peers.empty()) {
-            float* hello = nullptr;
-            if ((rc = p->dmalloc(&hello, 2 * peers.size()))) return rc;
-            HIPCHK(hipMemsetAsync(hello, 0, 2 * peers.size() * sizeof(float), c->stream));
-            NCCLCHK(R.GroupStart());
-            for (size_t i = 0; i < peers.size(); ++i) {
-                ncclResult_t r1 = R.Send(hello + 2 * i, 1, ncclFloat, peers[i], c->comm, c->stream);
-                ncclResult_t r2 = R.Recv(hello + 2 * i + 1, 1, ncclFloat, peers[i], c->comm, c->stream);
-                if (r1 != ncclSuccess || r2 != ncclSuccess) { (void)R.GroupEnd(); return fail(SMASHX_E_HIP, "ncclSend/ncclRecv (connection set-up) failed"); }
-            }
-            NCCLCHK(R.GroupEnd());
-            HIPCHK(hipStreamSynchronize(c->stream));
-            p->dfree(hello);
+        HIPCHK(hipMemsetAsync(hello, 0, 2 * peers.size() * sizeof(float), c->stream));
+        NCCLCHK(R.GroupStart());
+        for (size_t i = 0; i < peers.size(); ++i) {
+            ncclResult_t r1 = R.Send(hello + 2 * i, 1, ncclFloat, peers[i], c->comm, c->stream);
+            ncclResult_t r2 = R.Recv(hello + 2 * i + 1, 1, ncclFloat, peers[i], c->comm, c->stream);
+            if (r1 != ncclSuccess || r2 != ncclSuccess) { (void)R.GroupEnd(); return fail(SMASHX_E_HIP, "ncclSend/ncclRecv (connection set-up) failed"); }
         }
+        NCCLCHK(R.GroupEnd());
+        HIPCHK(hipStreamSynchronize(c->stream));
     }
+    p->dfree(hello);
+    if (p->d_out_xp) p->dfree(p->d_out_xp);          // a second call replaces the tables of the first
+    if (p->d_in_xp) p->dfree(p->d_in_xp);
+    p->d_out_xp = d_oxp; p->d_in_xp = d_ixp;
+    p->out_segs.swap(out_segs); p->in_segs.swap(in_segs);
     p->xcomm = c;
+    if (std::find(c->plans.begin(), c->plans.end(), p) == c->plans.end()) c->plans.push_back(p);
     return 0;
 }
 

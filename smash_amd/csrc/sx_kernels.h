@@ -51,7 +51,8 @@ __device__ __forceinline__ float4 sx_gload4(const float4* p) {
 #endif
 }
 // streaming variants (SX_R_NT: 1 = loads, 2 = stores, 3 = both) for the cell-indexed arrays of the routing kernels (qt, hr tape,
-// qt_b): read once / written once per pass.  Never for the exchange rows (xT), which neighbouring groups re-read through L2.
+// qt_b): read once / written once per pass.  Never for the exchange rows (xT), which neighbouring groups re-read through L2: stores
+// whose destination may be such a row go through sx_gstore4 (always plain).
 // Measured at 1024^2 x 8760 (sweep 172.8 ms with 0): loads 175.3, stores 181.1 (route_fwd 24.8 -> 33.6 ms), both 180.9 -> off.
 #ifndef SX_R_NT
 #define SX_R_NT 0
@@ -79,6 +80,16 @@ __device__ __forceinline__ void sx_gstore4s(float4* p, const float4& q) {
     }
 #endif
     *p = q;
+}
+// always a plain global store (never nontemporal, whatever SX_R_NT says): for destinations that may be exchange rows (xT), which
+// other groups re-read through L2 behind the progress counters
+__device__ __forceinline__ void sx_gstore4(float4* p, const float4& q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sx_f4v v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w;
+    *(__attribute__((address_space(1))) sx_f4v*)p = v;
+#else
+    *p = q;
+#endif
 }
 __device__ __forceinline__ float sx_gload1(const float* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -936,7 +947,8 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
                 const int tbr = SX_MU * (mw - 1) + u - rstage;
                 if (tbr >= 0 && tbr < nb) {
                     const int tb = nb - 1 - tbr;
-                    if (!(cell >= 0 ? SX_ABL_A_NOQ : SX_ABL_A_NOX)) sx_gstore4s(dst + (size_t)tb * dstride, outq[u]);
+                    // one store instruction for both kinds of slot; the inlets' destination is an exchange row: never nontemporal
+                    if (!(cell >= 0 ? SX_ABL_A_NOQ : SX_ABL_A_NOX)) sx_gstore4(dst + (size_t)tb * dstride, outq[u]);
                 }
             }
         }
@@ -1031,11 +1043,14 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
 // taped pre-step levels; parameter gradients accumulate per cell in reverse time order like
 // parameters_b%x(row,col) does in the reference (forward_db.f90:8699-8702).
 // ------------------------------------------------------------------------------------------------
+// gr-b on the compact forcing (the headline's reverse kernel): 112 registers = 4 waves per SIMD; held to 96 = 5 waves it spills 12
+// values (52 B of scratch per lane) and still wins: 68.3 -> 66.6 ms at 1024^2 x 8760, 258.2 -> 249.8 ms per sweep at 2048^2 (round 2
+// had measured 69.0 -> 67.7 and declined; with the larger grid's 64 waves per SIMD the fifth wave is worth 3 %).  Bit-identical.
 #ifndef SX_VADJ_WAVES
-#define SX_VADJ_WAVES 1
+#define SX_VADJ_WAVES 5
 #endif
 template <int ST, bool CF>
-__global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES) void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
+__global__ __launch_bounds__(SX_VBLOCK, (ST == 2 && CF) ? SX_VADJ_WAVES : 1) void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
     SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;

@@ -93,20 +93,27 @@ def wjreg_range(wjreg_opt, nb_wjreg_lcurve):
 
 def best_lcurve_weight(cost_jobs, cost_jreg, wjreg, jobs_min, jobs_max, jreg_min, jreg_max):
     """The weight at the corner of the L-curve (core/simulation/_optimize.py:948-1003, `_compute_best_lcurve_weight`).  In the
-    plane x = share of the attainable misfit reduction a cycle kept, y = share of the largest regularisation term it paid,
-    the corner is the point farthest below the diagonal y = x: the reference measures hyp * sin(pi/4 - acos(x / hyp)), which
-    is (x - y) / sqrt(2).  Points on or above the diagonal get NaN, cycles that did not reduce the misfit 0; of equal
-    distances the last one wins (>=).  Returns (distance float32 array, weight or None)."""
-    cost_jobs, cost_jreg = np.asarray(cost_jobs, np.float64), np.asarray(cost_jreg, np.float64)
+    plane x = share of the attainable misfit reduction a cycle kept, y = share of the largest regularisation term it paid, the
+    corner is the point farthest below the diagonal y = x, measured the reference's way: hyp * sin(pi/4 - acos(x / hyp)) with
+    hyp = sqrt(x^2 + y^2).  Operand types are the caller's (the reference's cycles hand float32 arrays and float32 extrema), so
+    the `y < x` test next to the diagonal and the `>=` tie-break (of equal distances the LAST wins) fall as they do there.
+    Points on or above the diagonal get NaN, cycles that did not reduce the misfit 0.  Returns (distance float32 array, weight
+    or None)."""
+    cost_jobs, cost_jreg = np.asarray(cost_jobs), np.asarray(cost_jreg)
     if not (cost_jobs.size > 2 and (jreg_max - jreg_min) > 0.0 and (jobs_max - jobs_min) > 0.0):
         return np.empty(0, np.float32), None
-    x = (float(jobs_max) - cost_jobs) / (float(jobs_max) - float(jobs_min))
-    y = (cost_jreg - float(jreg_min)) / (float(jreg_max) - float(jreg_min))
-    dist = np.where(cost_jobs < jobs_max, (x - y) / np.sqrt(2.0), 0.0)
-    dist = np.where(y < x, dist, np.nan).astype(np.float32)
-    best, far = None, np.float32(0.0)
-    for i in range(dist.size):
-        if not np.isnan(dist[i]) and dist[i] >= far:
+    x = (jobs_max - cost_jobs) / (jobs_max - jobs_min)         # element type of the inputs
+    y = (cost_jreg - jreg_min) / (jreg_max - jreg_min)
+    dist = np.zeros(cost_jobs.size, np.float32)
+    best, far = None, 0.0
+    for i in range(cost_jobs.size):
+        if not (y[i] < x[i]):
+            dist[i] = np.nan
+            continue
+        if cost_jobs[i] < jobs_max:
+            hyp = (x[i] ** 2.0 + y[i] ** 2.0) ** 0.5
+            dist[i] = hyp * np.sin(np.pi * 0.25 - np.arccos(x[i] / hyp))
+        if dist[i] >= far:
             far, best = dist[i], wjreg[i]
     return dist, best
 
@@ -188,8 +195,9 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
             return dict(cost=output.cost, cost_jobs=output.cost_jobs, cost_jreg=output.cost_jreg, cost_jobs_initial=h["cost_jobs_initial"])
 
         w, lcurve = auto_wjreg_cycles(run_cycle, restore, auto_wjreg, nb_wjreg_lcurve, verbose)
-        if w is None:                         # no corner found: the model is run as it is
-            o.wjreg = 0.0
+        if w is None:
+            # no corner found: the model is run as it is; like the reference, wjreg stays at the last weight a cycle tried
+            # (core/simulation/_optimize.py:434-450 does not reset it), so output.cost carries that weight's regularisation term
             forward(setup, mesh, input_data, parameters, parameters.copy(), states, states.copy(), output, np.float32(0))
         h = dict(last["h"], wjreg=w)
         if return_lcurve and lcurve is not None:

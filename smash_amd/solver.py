@@ -108,15 +108,21 @@ class Solver:
         h = hash(tuple(np.ascontiguousarray(getattr(mesh, k)).tobytes() for k in ("flwdir", "flwacc", "active_cell", "gauge_pos", "area")))
         return (setup.structure, setup.ntime_step, float(setup.dt), mesh.nrow, mesh.ncol, mesh.ng, float(mesh.dx), bool(setup.sparse_storage), h)
 
+    FULL_HASH_ELEMENTS = 1 << 24        # fields up to 64 MB are hashed whole
+
     @staticmethod
     def forcing_fingerprint(prcp, pet):
-        """Strided hash (~65 k samples per field) of the forcing arrays, recomputed on every call: values written in place, or new
-        arrays that happen to land at the old address, must not be served the forcing already resident in HBM."""
+        """Hash of the forcing arrays, recomputed on every call: values written in place, or new arrays that happen to land at the
+        old address, must not be served the forcing already resident in HBM.  Fields up to FULL_HASH_ELEMENTS values are hashed
+        whole; larger ones by a strided sample of ~65 k values per field (hashing 70 GB per call would cost more than the sweep), so
+        an in-place edit of a small window of a LARGE field can go unnoticed: after such an edit call invalidate_forcing(input_data)
+        (or Solver.set_forcing again) -- the reference has no such cache because it has no device copy."""
         out = []
         for a in (prcp, pet):
             a = np.asarray(a)
             flat = a.reshape(-1, order="A") if (a.flags.f_contiguous or a.flags.c_contiguous) else a.ravel()
-            out.append((a.shape, flat[::max(1, flat.size // 65536)].tobytes()))
+            step = 1 if flat.size <= Solver.FULL_HASH_ELEMENTS else max(1, flat.size // 65536)
+            out.append((a.shape, flat[::step].tobytes()))
         return hash(tuple(out))
 
     def close(self):
@@ -383,6 +389,14 @@ def _tangent_call(s, parameters, parameters_d, parameters_bgd, states, states_d,
     if output_d is not None and qd is not None:
         output_d.qsim = qd
     return float(costs.cost), float(cost_d.value)
+
+
+def invalidate_forcing(input_data):
+    """The forcing arrays of input_data were edited in place: the next forward / forward_b / forward_d call uploads them again."""
+    s = getattr(input_data, "_smashx_solver", None)
+    if s is not None:
+        s._fp = None
+        s._forcing_external = False
 
 
 def _solver_for(setup, mesh, input_data, **kw):

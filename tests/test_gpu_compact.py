@@ -101,11 +101,18 @@ def test_gap_days_and_unaligned_device_blocks():
     sol = Solver(setup, mesh)
     sol.set_forcing_layout(**SYNTH_LAYOUT)
     rows, cols = sol.cell_order()
+    sol.upload(par, sta)
     for t0 in range(0, g.nt, 50):
         t1 = min(g.nt, t0 + 50)
         bp = torch.from_numpy(np.ascontiguousarray(g.prcp[rows, cols, t0:t1].T)).cuda()
         be = torch.from_numpy(np.ascontiguousarray(g.pet[rows, cols, t0:t1].T)).cuda()
         torch.cuda.synchronize()
+        if t0 > 0:
+            # until device blocks have covered EVERY step the forcing does not count as set: a sweep now would close the daily PET of
+            # the days still to come
+            with pytest.raises(smash_amd.SmashxError) as e:
+                sol.sweep(False)
+            assert e.value.code == _lib.E_STATE
         sol.set_forcing_device_block(t0, t1, bp.data_ptr(), be.data_ptr())
     assert sol.forcing_info()["layout"].startswith("compact")
     inp._smashx_solver = sol

@@ -378,6 +378,7 @@ def test_auto_wjreg_cycles_on_cance_vs_reference(mode, start):
         assert lc["wjreg"].size == len(rec) - 1 and np.allclose(lc["wjreg"], rec[:-1, 0], rtol=1e-3)
         assert np.allclose(lc["cost_jobs"], rec[:-1, 2], rtol=5e-4) and np.allclose(lc["cost_jreg"], rec[:-1, 3], rtol=2e-3, atol=1e-9)
         assert np.array_equal(np.isnan(lc["distance"]), np.isnan(z["lcurve_distance"]))
+        assert np.allclose(np.nan_to_num(lc["distance"]), np.nan_to_num(z["lcurve_distance"]), atol=2e-3)     # the values too (the costs differ by 5e-4)
 
 
 @pytest.mark.parametrize("mode", ["fast", "lcurve"])
@@ -526,6 +527,12 @@ def test_forcing_written_in_place_is_not_served_from_the_cache():
     g2.prcp = inp.prcp.copy(order="F")
     fresh = _run_forward(g2)[2].qsim
     assert not np.array_equal(q1, q2) and np.array_equal(q2, fresh)
+    # explicit invalidation (for edits of a LARGE field that the sampled fingerprint could miss): the forcing goes up again
+    fp = s1._fp
+    smash_amd.invalidate_forcing(inp)
+    assert s1._fp is None
+    smash_amd.forward(setup, mesh, inp, par.copy(), inp._bgd[0], sta.copy(), inp._bgd[1], out, np.float32(0))
+    assert inp._smashx_solver is s1 and s1._fp == fp and np.array_equal(out.qsim, q2)
     # a different mesh of the same shape (one more inactive cell) must rebuild the plan
     mesh.active_cell = np.asfortranarray(mesh.active_cell.copy())
     r, c = np.argwhere((np.asarray(mesh.flwacc) == 1) & (np.asarray(mesh.active_cell) == 1))[0]
