@@ -426,6 +426,17 @@ int set_device(const smashx_plan* p) {
     return 0;
 }
 
+// Levels of the river tree a routing wavefront resolves inside ONE super-step (sx_plan.h "components"): SMASHX_SUBLEVELS for the
+// rounds >= 1, SMASHX_SUBLEVELS_R0 for round 0.  Default 1 = one level per super-step.  Measured (profiles/r3_sublevels.json): with 4
+// levels the groups are 3.5 x shallower (335 -> 96 stages) and every result is bit-identical, but a super-step then runs its body four
+// times -- 0.7 us + 0.45 us per pass, against 1.15 us for one level -- so what the fill gains the steady state loses: 1024^2 x 8760
+// 157.5 -> 160.7 ms, a 2048 x 1024 tile 354 -> 375 ms; in round 0 (vector-bound) it costs 22 ms.  Kept as a switch.
+int sublevels_env() {
+    const char* e = getenv("SMASHX_SUBLEVELS");
+    const char* e0 = getenv("SMASHX_SUBLEVELS_R0");
+    return (e ? std::max(1, atoi(e)) : 1) | ((e0 ? std::max(1, atoi(e0)) : 1) << 8);
+}
+
 int chunk_len(const smashx_plan* p, int c) { return std::min(p->Tc, p->nt - c * p->Tc); }
 
 // allocate the time-chunk buffers; Tc from cfg or from free HBM
@@ -787,7 +798,7 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     const bool rect_tile = cfg->tile[1] > cfg->tile[0] && cfg->tile[3] > cfg->tile[2];
     const bool tiled = rect_tile || mesh->owner_mask;
     const int rc0 = sx_build_schedule(cfg->nrow, cfg->ncol, mesh->flwdir, mesh->active_cell, cfg->ng, mesh->gauge_pos, p->M,
-                                      rect_tile ? cfg->tile : nullptr, p->sch, mesh->owner_mask);
+                                      rect_tile ? cfg->tile : nullptr, p->sch, mesh->owner_mask, sublevels_env());
     if (rc0 != 0) { std::string e = p->sch.error; delete p; return fail(rc0 == -5 ? SMASHX_E_MESH : SMASHX_E_ARG, e); }
     p->tiled = tiled;
     p->n = p->sch.n; p->npad = (p->n + SX_VBLOCK - 1) / SX_VBLOCK * SX_VBLOCK;
@@ -813,7 +824,7 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
             const int ga = p->sch.round_group_begin[r], gb = p->sch.round_group_begin[r + 1];
             for (int g = ga; g < gb; ++g) {
                 dsum += p->sch.g_dmax[g]; dmx = std::max(dmx, p->sch.g_dmax[g]);
-                for (int q = p->sch.g_slot_begin[g]; q < p->sch.g_slot_begin[g + 1]; ++q) { ++slots; if (p->sch.s_cell[q] < 0) ++inlets; }
+                for (int q = p->sch.g_slot_begin[g]; q < p->sch.g_slot_begin[g + 1]; ++q) { if (p->sch.s_cell[q] == INT_MIN) continue; ++slots; if (p->sch.s_cell[q] < 0) ++inlets; }
             }
             fprintf(stderr, "smashx: routing round %d: %d groups, %ld slots (%ld inlets), depth mean %.1f max %d\n", r, gb - ga, slots, inlets,
                     gb > ga ? (double)dsum / (gb - ga) : 0.0, dmx);
@@ -824,8 +835,9 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     TRY(p->upload_vec(&d2, p->sch.g_dmax)); A.g_dmax = d2;
     TRY(p->upload_vec(&d3, p->sch.s_cell)); A.s_cell = d3;
     TRY(p->upload_vec(&d4, p->sch.s_stage)); A.s_stage = d4;
-    TRY(p->upload_vec(&d5, p->sch.s_cstart)); A.s_cstart = d5;
+    TRY(p->upload_vec(&d5, p->sch.s_child)); A.s_child = d5;
     TRY(p->upload_vec(&d6, p->sch.s_ccount)); A.s_ccount = d6;
+    { int *e1, *e2; TRY(p->upload_vec(&e1, p->sch.s_sub)); A.s_sub = e1; TRY(p->upload_vec(&e2, p->sch.s_wsub)); A.s_wsub = e2; }
     TRY(p->upload_vec(&d7, p->sch.s_parent)); A.s_parent = d7;
     TRY(p->upload_vec(&d8, p->sch.s_xout)); A.s_xout = d8;
     {   // chained rounds (the rounds from SMASHX_CHAIN_FROM, default 1, share one launch); SMASHX_CHAIN_ROUNDS=0
@@ -1763,7 +1775,7 @@ int smashx_tile_probe(const smashx_config* cfg, const smashx_mesh* mesh, int* in
     const bool tiled = cfg->tile[1] > cfg->tile[0] && cfg->tile[3] > cfg->tile[2];
     const int M = cfg->group_size > 0 ? cfg->group_size : 512;
     const int rc = sx_build_schedule(cfg->nrow, cfg->ncol, mesh->flwdir, mesh->active_cell, cfg->ng, mesh->gauge_pos, M,
-                                     tiled ? cfg->tile : nullptr, sch, mesh->owner_mask);
+                                     tiled ? cfg->tile : nullptr, sch, mesh->owner_mask, sublevels_env());
     if (rc) return fail(rc == -5 ? SMASHX_E_MESH : SMASHX_E_ARG, sch.error);
     const int no = (int)sch.out_x.size(), ni = (int)sch.in_x.size();
     const int v[8] = {sch.n, sch.nrounds, sch.ngroups, sch.nslots, sch.nxslots, sch.max_stage, no, ni};

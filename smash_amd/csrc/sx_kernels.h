@@ -19,6 +19,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <climits>
+
 #include "sx_ops.h"
 #include "sx_tangent.h"
 #include "sx_vic.h"
@@ -35,6 +37,13 @@ __device__ __forceinline__ void sx_lds_barrier() {
 #ifndef SX_ABL_NOBAR
     __builtin_amdgcn_s_barrier();
 #endif
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// between two sub-levels of one wavefront (sx_plan.h "components"): writes of the lower sub-level before reads of the higher one
+__device__ __forceinline__ void sx_lds_wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
@@ -225,7 +234,7 @@ struct SxDeviceArrays {
     int* cell_gauge;              // [npad] gauge-cell id or -1
     // schedule
     const int *g_slot_begin, *g_dmax;
-    const int *s_cell, *s_stage, *s_cstart, *s_ccount, *s_parent, *s_xout;
+    const int *s_cell, *s_stage, *s_sub, *s_wsub, *s_child, *s_ccount, *s_parent, *s_xout;   // sx_plan.h: components, sub-levels
     const int *x_prod, *x_cons;   // per exchange series: publishing group / group holding the inlet (-1: other tile)
     int* prog;                    // [ngroups + SX_PROG_EXTRA]: blocks published by each group in the running launch, then the stall flag, the ticket
                                   // counter and the gate (SX_PROG_STALL / _TICKET / _GATE)
@@ -654,19 +663,26 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];   // [2][blockDim.x]
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
     const int j = threadIdx.x, M = blockDim.x;
-    const bool valid = j < m;
+    bool valid = j < m;
     const int nb = (T + SX_BT - 1) / SX_BT;
     if (A.gtime && j == 0) A.gtime[2 * g] = wall_clock64();
 
-    int cell = -1, stage = 0, cstart = 0, ccount = 0, xout = -1, xin = -1, gid = -1;
+    int cell = -1, stage = 0, sub = 0, ccount = 0, xout = -1, xin = -1, gid = -1;
+    unsigned ch01 = ~0u, ch23 = ~0u, ch45 = ~0u, ch67 = ~0u;      // children: 16 bits each, slot | 0x8000 = same component (sx_plan.h)
     float a = 0.f, f = 0.f, den = 1.f, hlr = 0.f, ad = 0.f;
     bool hasup = false;
+    // sub-levels of this wavefront's components (wave-uniform): the number of passes through a super-step's body
+    const int nsubw = __builtin_amdgcn_readfirstlane(m > 0 ? A.s_wsub[sb + min(j, m - 1)] : 1);
+    if (valid && A.s_cell[sb + j] == INT_MIN) valid = false;      // a hole of a partly filled wavefront
     if (valid) {
         const int c = A.s_cell[sb + j];
         stage = A.s_stage[sb + j];
+        sub = A.s_sub[sb + j];
         if (c >= 0) {
             cell = c;
-            cstart = A.s_cstart[sb + j]; ccount = A.s_ccount[sb + j]; xout = A.s_xout[sb + j];
+            const int4 cw = reinterpret_cast<const int4*>(A.s_child)[sb + j];
+            ch01 = (unsigned)cw.x; ch23 = (unsigned)cw.y; ch45 = (unsigned)cw.z; ch67 = (unsigned)cw.w;
+            ccount = A.s_ccount[sb + j]; xout = A.s_xout[sb + j];
             a = A.rt_a[c]; f = A.rt_f[c]; den = (TAN || DFORM) ? A.rt_denb[c] : A.rt_denf[c]; hlr = TAN ? A.hlr_b[c] : A.hlr[c];
             if (TAN) { const float lrv = A.lr[c]; ad = a * ((A.dt / (60.f * lrv)) * A.lr_b[c] / lrv); }
             hasup = A.flwacc[c] > 1;
@@ -747,8 +763,14 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
             const int tb = w - stage;
             const bool act = valid && tb >= 0 && tb < nb;
             float4* pub = sx_lds + (size_t)(w & 1) * M;
-            const float4* prev = sx_lds + (size_t)((w + 1) & 1) * M;
-            if (act) {
+            // a child's block: published in THIS super-step by a lower sub-level of the same component (same wavefront: row w & 1),
+            // or in the previous super-step by the root of a component one stage below (row (w + 1) & 1)
+            auto child_val = [&](unsigned e) -> float4 {
+                const float4* row = sx_lds + (size_t)((w + 1 + (int)((e >> 15) & 1u)) & 1) * M;
+                return row[min((int)(e & 0x7fffu), M - 1)];
+            };
+          for (int sl = 0; sl < nsubw; ++sl) {
+            if (act && sub == sl) {
                 const int tl = tb * SX_BT;           // first step of the block, chunk-local
                 if (cell >= 0) {
                     // upstream sum in D8 order; the first two children (almost every cell has <= 2) are fetched
@@ -758,7 +780,7 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
 #ifdef SX_ABL_NOLDS
                         const float4 v0 = cur[u], v1 = cur[u];
 #else
-                        const float4 v0 = prev[min(cstart, M - 1)], v1 = prev[min(cstart + 1, M - 1)];
+                        const float4 v0 = child_val(ch01 & 0xffffu), v1 = child_val(ch01 >> 16);
 #endif
                         const bool h0 = ccount > 0, h1 = ccount > 1;
                         s[0] = (h0 ? v0.x : 0.f) + (h1 ? v1.x : 0.f); s[1] = (h0 ? v0.y : 0.f) + (h1 ? v1.y : 0.f);
@@ -769,7 +791,8 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
 #else
                     for (int c = 2; c < ccount; ++c) {
 #endif
-                        const float4 v = prev[cstart + c];
+                        const unsigned wd = c < 4 ? ch23 : c < 6 ? ch45 : ch67;
+                        const float4 v = child_val((wd >> ((c & 1) * 16)) & 0xffffu);
                         s[0] = s[0] + v.x; s[1] = s[1] + v.y; s[2] = s[2] + v.z; s[3] = s[3] + v.w;
                     }
                     const float qt[SX_BT] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
@@ -824,6 +847,10 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
                     pub[j] = cur[u];
                 }
             }
+            // the next sub-level of this wavefront reads what this one has just published: LDS operations of one wave complete in
+            // order, the fence keeps the compiler from moving the reads up
+            if (sl + 1 < nsubw) sx_lds_wave_fence();
+          }
             sx_lds_barrier();
             // every wave has passed this macro-step's vmcnt(0): what the roots (stage dmax) stored one macro-step
             // ago -- blocks below SX_MU (mw-1) - dmax -- has reached L2 and can be released
@@ -862,17 +889,22 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
     const int j = threadIdx.x, M = blockDim.x;
-    const bool valid = j < m;
+    bool valid = j < m;
     const int nb = (T + SX_BT - 1) / SX_BT;
     if (A.gtime && j == 0) A.gtime[2 * (A.ngroups + g)] = wall_clock64();
 
-    int cell = -1, rstage = 0, par = -1, xout = -1, xin = -1, gid = -1;
+    int cell = -1, rstage = 0, sub = 0, par = -1, xout = -1, xin = -1, gid = -1;
+    bool psame = false;                 // the parent sits in the same component (same wavefront, next sub-level up)
     float a = 0.f, f = 0.f, den = 1.f, lr = 1.f, hr_b = 0.f, lr_b = 0.f;
     bool hasup = false;
+    const int nsubw = __builtin_amdgcn_readfirstlane(m > 0 ? A.s_wsub[sb + min(j, m - 1)] : 1);
+    if (valid && A.s_cell[sb + j] == INT_MIN) valid = false;      // a hole of a partly filled wavefront
     if (valid) {
         const int c = A.s_cell[sb + j];
         rstage = dmax - A.s_stage[sb + j];
+        sub = A.s_sub[sb + j];
         par = A.s_parent[sb + j];
+        if (par >= 0) { psame = (par & 0x40000000) != 0; par &= 0xffff; }
         if (c >= 0) {
             cell = c;
             xout = A.s_xout[sb + j];
@@ -970,11 +1002,12 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
             const bool act = valid && tbr >= 0 && tbr < nb;
             float4* pub = sx_lds + (size_t)(w & 1) * M;
             const float4* prev = sx_lds + (size_t)((w + 1) & 1) * M;
-            if (act) {
+          for (int sl = nsubw - 1; sl >= 0; --sl) {     // the reverse of the forward order: a component's top first
+            if (act && sub == sl) {
                 const int tb = nb - 1 - tbr;
                 const int tl = tb * SX_BT;
                 float4 in4 = cin[u];                 // contribution of the downstream cell
-                if (par >= 0) in4 = prev[par];
+                if (par >= 0) in4 = psame ? pub[par] : prev[par];
                 if (cell >= 0) {
                     const float hrv[SX_BT] = {chr[u].x, chr[u].y, chr[u].z, chr[u].w};
                     const float inv[SX_BT] = {in4.x, in4.y, in4.z, in4.w};
@@ -1013,6 +1046,8 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
                     outq[u] = in4;
                 }
             }
+            if (sl > 0) sx_lds_wave_fence();
+          }
             sx_lds_barrier();
             // inlet slots sit at reverse stage <= dmax: reverse blocks below SX_MU (mw-1) - dmax are complete
             if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0 && g != A.mute_group) sx_publish(A.prog + g, done); }

@@ -2,6 +2,7 @@
 #include "sx_plan.h"
 
 #include <algorithm>
+#include <climits>
 #include <cstdint>
 #include <map>
 #include <numeric>
@@ -15,7 +16,7 @@ const int DCOL[8] = {0, 1, 1, 1, 0, -1, -1, -1};
 }  // namespace
 
 int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_cell, int ng, const int* gauge_pos,
-                      int group_size, const int* rect, SxSchedule& s, const int* own) {
+                      int group_size, const int* rect, SxSchedule& s, const int* own, int sublevels) {
     const int M = group_size;
     if (nrow <= 0 || ncol <= 0 || M < 16) { s.error = "bad sizes"; return -1; }
     const long n2 = (long)nrow * ncol;
@@ -138,7 +139,12 @@ int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_c
         for (int q : in) { s.in_x.push_back(xslot_of[n + q]); s.in_src.push_back(rflat[q]); s.in_dst.push_back(flat_of_a[rparent[q]]); }
     }
 
-    // ---- group-local breadth-first order, stages, device cell numbering ----
+    // ---- group-local layout: components (one wavefront, <= U levels), stages, sub-levels, device cell numbering ----
+    // sublevels = levels per super-step in the rounds >= 1 (low byte) | levels in round 0 << 8 (0: one).  Round 0 is wide and bound by
+    // HBM: every extra pass through the super-step's body costs it vector time it does not have (measured: 4 levels everywhere make a
+    // 1024^2 x 8760 sweep 22 ms slower), the later rounds are bound by the latency of their chain of stages
+    const int U_late = std::max(1, std::min(sublevels & 0xff, 16)), U_first = std::max(1, std::min((sublevels >> 8) & 0xff, 16));
+    const int WAVE = 64, nwaves = (M + WAVE - 1) / WAVE;
     s.round_group_begin.assign(1, 0);
     s.g_slot_begin.assign(1, 0);
     std::vector<int> k_of_a(n, -1);
@@ -146,39 +152,124 @@ int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_c
     s.max_stage = 0;
     s.x_prod_group.assign(std::max(nx, 1), -1);
     s.x_cons_group.assign(std::max(nx, 1), -1);
-    std::vector<int> q_node, q_par, q_depth;   // BFS queue: node (>=0 cell a, <0 inlet of cell -1-a), local parent, depth
+    // per-group scratch: the group's forest in breadth-first order (parents before children), node >= 0 cell a, < 0 inlet of node -1-a
+    std::vector<int> q_node, q_par;
+    std::vector<int> kid_begin, kids;          // children (local indices) of local node i, D8 order
     for (int r = 0; r < s.nrounds; ++r) {
+        const int U = r == 0 ? U_first : U_late;
         for (auto& g : round_groups[r]) {
-            q_node.clear(); q_par.clear(); q_depth.clear();
-            for (int a : g) { q_node.push_back(a); q_par.push_back(-1); q_depth.push_back(0); }
-            std::vector<int> cstart, ccount;
+            q_node.clear(); q_par.clear(); kid_begin.assign(1, 0); kids.clear();
+            for (int a : g) { q_node.push_back(a); q_par.push_back(-1); }
             for (size_t i = 0; i < q_node.size(); ++i) {
                 const int node = q_node[i];
-                cstart.push_back((int)q_node.size()); ccount.push_back(0);
-                if (node < 0) continue;   // inlet pseudo-cell: no children here
-                for (int j = cbeg[node]; j < cbeg[node + 1]; ++j) {
-                    const int c = child[j];
-                    q_node.push_back((c < n && round_of[c] == r) ? c : -1 - c);
-                    q_par.push_back((int)i); q_depth.push_back(q_depth[i] + 1);
-                    ccount[i]++;
-                }
+                if (node >= 0)
+                    for (int j = cbeg[node]; j < cbeg[node + 1]; ++j) {
+                        const int c = child[j];
+                        kids.push_back((int)q_node.size());
+                        q_node.push_back((c < n && round_of[c] == r) ? c : -1 - c);
+                        q_par.push_back((int)i);
+                    }
+                kid_begin.push_back((int)kids.size());
             }
             const int m = (int)q_node.size();
             if (m > M) { s.error = "internal: group overflow"; return -1; }
+            // -- components, bottom-up (children have larger local indices than their parent): a node takes the components of as many
+            //    children as fit one wavefront and U levels, the child with the deepest component tree below it first (that is the
+            //    path the fill runs along)
+            std::vector<int> comp(m), csize(m, 1), cheight(m, 1), cdepth(m, 1);   // comp: representative (the component's top node)
+            std::vector<char> merged(m, 0);                                          // node i sits in its parent's component
+            for (int i = 0; i < m; ++i) comp[i] = i;
+            auto build_components = [&](const std::vector<char>& forbid) {
+                for (int i = m - 1; i >= 0; --i) {
+                    csize[i] = 1; cheight[i] = 1; cdepth[i] = 1;
+                    std::vector<int> ks(kids.begin() + kid_begin[i], kids.begin() + kid_begin[i + 1]);
+                    std::stable_sort(ks.begin(), ks.end(), [&](int x, int y) { return cdepth[x] != cdepth[y] ? cdepth[x] > cdepth[y] : csize[x] > csize[y]; });
+                    for (int c : ks) {
+                        merged[c] = 0;
+                        if (U > 1 && !forbid[c] && csize[i] + csize[c] <= WAVE && cheight[c] + 1 <= U) {
+                            merged[c] = 1;
+                            csize[i] += csize[c];
+                            cheight[i] = std::max(cheight[i], cheight[c] + 1);
+                            cdepth[i] = std::max(cdepth[i], cdepth[c]);
+                        } else {
+                            cdepth[i] = std::max(cdepth[i], cdepth[c] + 1);
+                        }
+                    }
+                }
+                for (int i = 0; i < m; ++i) comp[i] = (q_par[i] >= 0 && merged[i]) ? comp[q_par[i]] : i;
+            };
+            // -- pack the components into wavefronts (first fit, largest first); one that fits nowhere is split at its top node (its
+            //    merged children become components of their own) and everything is rebuilt: single slots always fit
+            std::vector<char> forbid(m, 0);
+            std::vector<int> wave_of(m, -1);
+            for (;;) {
+                build_components(forbid);
+                std::vector<int> tops;
+                for (int i = 0; i < m; ++i) if (comp[i] == i) tops.push_back(i);
+                std::stable_sort(tops.begin(), tops.end(), [&](int x, int y) { return csize[x] > csize[y]; });
+                std::vector<int> room(nwaves, WAVE);
+                for (int w = 0; w < nwaves; ++w) room[w] = std::max(0, std::min(WAVE, M - w * WAVE));   // (M below a wavefront multiple)
+                int bad = -1;
+                std::vector<int> wtop(m, -1);
+                for (int t : tops) {
+                    int w = 0;
+                    while (w < nwaves && room[w] < csize[t]) ++w;
+                    if (w == nwaves) { bad = t; break; }
+                    room[w] -= csize[t]; wtop[t] = w;
+                }
+                if (bad < 0) { for (int i = 0; i < m; ++i) wave_of[i] = wtop[comp[i]]; break; }
+                bool any = false;
+                for (int j = kid_begin[bad]; j < kid_begin[bad + 1]; ++j) if (merged[kids[j]]) { forbid[kids[j]] = 1; any = true; }
+                if (!any) { s.error = "internal: component packing"; return -1; }
+            }
+            // -- stages top-down over the component tree, sub-levels inside the components
             int dmax = 0;
-            for (int i = 0; i < m; ++i) dmax = std::max(dmax, q_depth[i]);
+            for (int i = 0; i < m; ++i) if (q_par[i] < 0) dmax = std::max(dmax, cdepth[i] - 1);
+            std::vector<int> stage(m, 0), sub(m, 0);
+            for (int i = 0; i < m; ++i) stage[i] = q_par[i] < 0 ? dmax : (merged[i] ? stage[q_par[i]] : stage[q_par[i]] - 1);
+            for (int i = m - 1; i >= 0; --i)
+                for (int j = kid_begin[i]; j < kid_begin[i + 1]; ++j) if (merged[kids[j]]) sub[i] = std::max(sub[i], sub[kids[j]] + 1);
+            for (int i = 0; i < m; ++i) if (stage[i] < 0) { s.error = "internal: negative stage"; return -1; }
+            // -- slot order: wave by wave, inside a wave in local (breadth-first) order; unused lanes of a wave stay empty only at the end
+            std::vector<int> order(m), slot_of(m);
+            for (int i = 0; i < m; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return wave_of[x] < wave_of[y]; });
+            // waves must start at multiples of 64: pad with nothing by construction only if every earlier wave is full -- otherwise
+            // shift: slots are placed at wave * 64 + position, and the group's slot count covers the holes with empty slots
+            std::vector<int> fill(nwaves, 0);
+            int m_slots = 0;
+            for (int i : order) { slot_of[i] = wave_of[i] * WAVE + fill[wave_of[i]]++; m_slots = std::max(m_slots, slot_of[i] + 1); }
+            if (m_slots > M) { s.error = "internal: group overflow after packing"; return -1; }
+            std::vector<int> wsub(nwaves, 1);
+            for (int i = 0; i < m; ++i) wsub[wave_of[i]] = std::max(wsub[wave_of[i]], sub[i] + 1);
             s.g_dmax.push_back(dmax);
             s.max_stage = std::max(s.max_stage, dmax);
-            for (int i = 0; i < m; ++i) {
+            const int gi = (int)s.g_slot_begin.size() - 1, sbase = (int)s.s_cell.size();
+            // empty slots (holes of partly filled waves): an inlet of no series is not expressible, so they are marked by cell = INT_MIN
+            s.s_cell.resize(sbase + m_slots, INT32_MIN);
+            s.s_stage.resize(sbase + m_slots, 0); s.s_sub.resize(sbase + m_slots, 0); s.s_wsub.resize(sbase + m_slots, 1);
+            s.s_ccount.resize(sbase + m_slots, 0); s.s_parent.resize(sbase + m_slots, -1); s.s_xout.resize(sbase + m_slots, -1);
+            s.s_child.resize((size_t)(sbase + m_slots) * 4, -1);
+            for (int q = 0; q < m_slots; ++q) s.s_wsub[sbase + q] = wsub[q / WAVE];
+            // cells are numbered in slot order (the hr_imd tape relies on it: a super-step's row is written cell next to cell)
+            std::vector<int> by_slot(m_slots, -1);
+            for (int i = 0; i < m; ++i) by_slot[slot_of[i]] = i;
+            for (int q = 0; q < m_slots; ++q) {
+                const int i = by_slot[q];
+                if (i < 0) continue;
                 const int node = q_node[i];
-                if (node >= 0) { k_of_a[node] = knext++; s.s_cell.push_back(k_of_a[node]); }
-                else s.s_cell.push_back(-1 - xslot_of[-1 - node]);
-                s.s_stage.push_back(dmax - q_depth[i]);
-                s.s_cstart.push_back(cstart[i]);
-                s.s_ccount.push_back(ccount[i]);
-                s.s_parent.push_back(q_par[i]);
-                s.s_xout.push_back((node >= 0 && q_par[i] < 0) ? xslot_of[node] : -1);
-                const int gi = (int)s.g_slot_begin.size() - 1;
+                if (node >= 0) { k_of_a[node] = knext++; s.s_cell[sbase + q] = k_of_a[node]; }
+                else s.s_cell[sbase + q] = -1 - xslot_of[-1 - node];
+                s.s_stage[sbase + q] = stage[i];
+                s.s_sub[sbase + q] = sub[i];
+                const int nk = kid_begin[i + 1] - kid_begin[i];
+                s.s_ccount[sbase + q] = nk;
+                unsigned short e[8];
+                for (int j = 0; j < 8; ++j) e[j] = 0xffff;
+                for (int j = 0; j < nk; ++j) { const int c = kids[kid_begin[i] + j]; e[j] = (unsigned short)(slot_of[c] | (merged[c] ? 0x8000 : 0)); }
+                for (int j = 0; j < 4; ++j) s.s_child[(size_t)(sbase + q) * 4 + j] = (int)((unsigned)e[2 * j] | ((unsigned)e[2 * j + 1] << 16));
+                s.s_parent[sbase + q] = q_par[i] < 0 ? -1 : (slot_of[q_par[i]] | (merged[i] ? 0x40000000 : 0));
+                s.s_xout[sbase + q] = (node >= 0 && q_par[i] < 0) ? xslot_of[node] : -1;
                 if (node >= 0 && q_par[i] < 0 && xslot_of[node] >= 0) s.x_prod_group[xslot_of[node]] = gi;
                 if (node < 0) s.x_cons_group[xslot_of[-1 - node]] = gi;
             }

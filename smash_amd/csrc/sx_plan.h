@@ -26,10 +26,20 @@ struct SxSchedule {
     std::vector<int> g_dmax;             // ngroups: largest stage in the group
     // per slot (a slot = one thread of the routing workgroup: a real cell or an inlet pseudo-cell)
     std::vector<int> s_cell;     // k (>= 0) for a cell, -1 - x for the inlet fed by exchange series x
-    std::vector<int> s_stage;    // children sit exactly one stage below their parent
-    std::vector<int> s_cstart;   // group-local index of the first child; children are contiguous, D8 order 1..8
+    // Stages and sub-levels (round 3).  The slots of a group are cut into COMPONENTS: connected pieces of the tree, at most `sublevels`
+    // levels high, that live in ONE wavefront (64 consecutive slots).  All slots of a component share a stage; inside it a slot's
+    // sub-level is one above its highest child of the same component.  A child is therefore either in its parent's component (same
+    // stage, same wave, lower sub-level: its value passes through LDS inside the super-step, no workgroup barrier needed) or the
+    // root of another component exactly one stage below.  A chain of L cells needs ~L / sublevels stages instead of L: the fill of a
+    // routing launch -- (longest cell path) super-steps -- shrinks by that factor.  sublevels = 1 is the old schedule (every slot
+    // its own component).
+    std::vector<int> s_stage;
+    std::vector<int> s_sub;      // sub-level inside the component (0 = no child in the same component)
+    std::vector<int> s_wsub;     // number of sub-levels used in the slot's wavefront (the same for its 64 slots): the kernels' loop bound
+    std::vector<int> s_child;    // 4 words per slot: 8 children in D8 order 1..8, 16 bits each: group-local slot index | 0x8000 if the child
+                                 // is in the same component; unused entries 0xffff
     std::vector<int> s_ccount;
-    std::vector<int> s_parent;   // group-local index of the parent, -1 for a subtree root
+    std::vector<int> s_parent;   // group-local index of the parent (| 0x40000000 if it is in the same component), -1 for a subtree root
     std::vector<int> s_xout;     // subtree roots: exchange series id they publish, else -1
     std::vector<int> gauge_k;    // ng: device cell of every gauge
     // per exchange series: the group whose subtree root publishes it / the group holding its inlet slot
@@ -47,4 +57,4 @@ struct SxSchedule {
 // publish theirs.  rect == nullptr: the whole grid.
 // own (nullable, (nrow,ncol), 1 = owned) replaces rect for arbitrary partitions (sub-catchments).
 int sx_build_schedule(int nrow, int ncol, const int* flwdir, const int* active_cell, int ng, const int* gauge_pos,
-                      int group_size, const int* rect, SxSchedule& s, const int* own = nullptr);
+                      int group_size, const int* rect, SxSchedule& s, const int* own = nullptr, int sublevels = 1);

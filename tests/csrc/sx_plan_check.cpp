@@ -1,8 +1,10 @@
 /* Host check of the routing-schedule builder (smash_amd/csrc/sx_plan.cpp), built with -fsanitize=address,undefined by
  * tests/test_plan_sanitized.py: reads a mesh from stdin (nrow ncol group_size tiled r0 r1 c0 c1, then flwdir and active_cell,
- * column-major), builds the schedule and verifies its invariants -- every active cell of the tile appears in exactly one slot,
- * children are contiguous, exactly one stage below their parent and in D8 order, rounds only receive from earlier rounds, a group
- * never exceeds group_size slots -- then prints a one-line summary. */
+ * column-major, optionally the sub-level count), builds the schedule and verifies its invariants -- every active cell of the tile
+ * appears in exactly one slot; a child is either in its parent's component (same stage, same wavefront, lower sub-level) or exactly
+ * one stage below it; child lists and parent links agree; sub-levels stay below the limit and below the wavefront's count; rounds
+ * only receive from earlier rounds; a group never exceeds group_size slots -- then prints a one-line summary. */
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -17,8 +19,10 @@ int main() {
     std::vector<int> fd(n2), act(n2);
     for (long i = 0; i < n2; ++i) if (std::scanf("%d", &fd[i]) != 1) return 1;
     for (long i = 0; i < n2; ++i) if (std::scanf("%d", &act[i]) != 1) return 1;
+    int U = 4;
+    if (std::scanf("%d", &U) != 1) U = 4;
     SxSchedule s;
-    const int rc = sx_build_schedule(nrow, ncol, fd.data(), act.data(), 0, nullptr, M, tiled ? rect : nullptr, s, nullptr);
+    const int rc = sx_build_schedule(nrow, ncol, fd.data(), act.data(), 0, nullptr, M, tiled ? rect : nullptr, s, nullptr, U | (U << 8));
     if (rc != 0) { std::printf("rc %d: %s\n", rc, s.error.c_str()); return rc == -5 ? 0 : 3; }
     long want = 0;
     for (int c = 0; c < ncol; ++c)
@@ -28,26 +32,48 @@ int main() {
     std::vector<int> seen(s.n, 0), round_of_group(s.ngroups, -1);
     for (int r = 0; r < s.nrounds; ++r)
         for (int g = s.round_group_begin[r]; g < s.round_group_begin[r + 1]; ++g) round_of_group[g] = r;
+    long stage_sum = 0;
     for (int g = 0; g < s.ngroups; ++g) {
         const int b = s.g_slot_begin[g], m = s.g_slot_begin[g + 1] - b;
         REQUIRE(m >= 1 && m <= M, "group size");
         int dmax = 0;
         for (int j = 0; j < m; ++j) {
             const int c = s.s_cell[b + j];
+            if (c == INT_MIN) { REQUIRE(s.s_ccount[b + j] == 0 && s.s_parent[b + j] == -1, "empty slot carries links"); continue; }
             if (c >= 0) { REQUIRE(c < s.n, "cell index"); seen[c]++; }
             else REQUIRE(-1 - c < std::max(s.nxslots, 1), "inlet series");
             dmax = std::max(dmax, s.s_stage[b + j]);
-            const int cs = s.s_cstart[b + j], cc = s.s_ccount[b + j];
-            REQUIRE(cc >= 0 && cc <= 8 && (cc == 0 || (cs >= 0 && cs + cc <= m)), "child range");
-            for (int q = 0; q < cc; ++q) {
-                REQUIRE(s.s_parent[b + cs + q] == j, "parent link");
-                REQUIRE(s.s_stage[b + cs + q] == s.s_stage[b + j] - 1, "child one stage below");
+            REQUIRE(s.s_stage[b + j] >= 0, "stage");
+            REQUIRE(s.s_sub[b + j] >= 0 && s.s_sub[b + j] < U && s.s_sub[b + j] < s.s_wsub[b + j], "sub-level range");
+            REQUIRE(s.s_wsub[b + j] == s.s_wsub[b + (j / 64) * 64], "wavefront sub-level count is wave-uniform");
+            const int cc = s.s_ccount[b + j];
+            REQUIRE(cc >= 0 && cc <= 8, "child count");
+            int need_sub = 0;
+            for (int q = 0; q < 8; ++q) {
+                const unsigned wd = (unsigned)s.s_child[(size_t)(b + j) * 4 + q / 2];
+                const unsigned e = (wd >> ((q & 1) * 16)) & 0xffffu;
+                if (q >= cc) { REQUIRE(e == 0xffffu, "unused child entry"); continue; }
+                const int ci = (int)(e & 0x7fffu);
+                const bool same = (e & 0x8000u) != 0;
+                REQUIRE(ci < m && s.s_cell[b + ci] != INT_MIN, "child index");
+                REQUIRE((s.s_parent[b + ci] & 0xffff) == j && s.s_parent[b + ci] >= 0, "parent link");
+                REQUIRE(((s.s_parent[b + ci] & 0x40000000) != 0) == same, "component flag agrees on both ends");
+                if (same) {
+                    REQUIRE(s.s_stage[b + ci] == s.s_stage[b + j], "same component, same stage");
+                    REQUIRE(ci / 64 == j / 64, "same component, same wavefront");
+                    REQUIRE(s.s_sub[b + ci] < s.s_sub[b + j], "child of the same component sits on a lower sub-level");
+                    need_sub = std::max(need_sub, s.s_sub[b + ci] + 1);
+                } else {
+                    REQUIRE(s.s_stage[b + ci] == s.s_stage[b + j] - 1, "child component exactly one stage below");
+                }
             }
+            REQUIRE(s.s_sub[b + j] == need_sub, "sub-level is one above the highest child of the component");
             const int par = s.s_parent[b + j];
-            REQUIRE(par >= -1 && par < m, "parent index");
+            REQUIRE(par >= -1 && (par < 0 || (par & 0xffff) < m), "parent index");
             if (c < 0) REQUIRE(cc == 0, "inlet has no children");
         }
         REQUIRE(dmax == s.g_dmax[g], "g_dmax");
+        stage_sum += dmax;
     }
     for (int k = 0; k < s.n; ++k) REQUIRE(seen[k] == 1, "every cell exactly once");
     for (int x = 0; x < s.nxslots; ++x) {
@@ -57,7 +83,7 @@ int main() {
     REQUIRE(s.out_x.size() == s.out_src.size() && s.in_x.size() == s.in_src.size(), "edge lists");
     for (size_t i = 1; i < s.out_src.size(); ++i) REQUIRE(s.out_src[i - 1] < s.out_src[i], "out edges sorted by source");
     for (size_t i = 1; i < s.in_src.size(); ++i) REQUIRE(s.in_src[i - 1] < s.in_src[i], "in edges sorted by source");
-    std::printf("ok cells %d rounds %d groups %d slots %d series %d deepest %d out %zu in %zu\n", s.n, s.nrounds, s.ngroups, s.nslots, s.nxslots,
-                s.max_stage, s.out_x.size(), s.in_x.size());
+    std::printf("ok cells %d rounds %d groups %d slots %d series %d deepest %d out %zu in %zu stagesum %ld\n", s.n, s.nrounds, s.ngroups, s.nslots,
+                s.nxslots, s.max_stage, s.out_x.size(), s.in_x.size(), stage_sum);
     return 0;
 }

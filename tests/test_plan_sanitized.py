@@ -26,11 +26,11 @@ def exe():
     return EXE
 
 
-def _run(exe, m, group, rect=None, flwdir=None):
+def _run(exe, m, group, rect=None, flwdir=None, sublevels=4):
     fd = np.asarray(m.flwdir if flwdir is None else flwdir, np.int32).reshape(-1, order="F")
     act = np.asarray(m.active_cell, np.int32).reshape(-1, order="F")
     head = f"{m.nrow} {m.ncol} {group} {int(rect is not None)} " + " ".join(str(v) for v in (rect or (0, 0, 0, 0)))
-    txt = head + "\n" + " ".join(map(str, fd)) + "\n" + " ".join(map(str, act)) + "\n"
+    txt = head + "\n" + " ".join(map(str, fd)) + "\n" + " ".join(map(str, act)) + f"\n{sublevels}\n"
     r = subprocess.run([exe], input=txt, capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-1500:])
@@ -47,6 +47,23 @@ def test_schedule_builder_under_sanitizers(exe, group):
         assert _run(exe, m, group).startswith(f"ok cells {m.nac}")
     m = synth.make_mesh(64, 64, ng=1, mask_corner=True)
     assert _run(exe, m, group).startswith(f"ok cells {m.nac}")
+
+
+@pytest.mark.parametrize("group", [64, 256, 512])
+def test_components_shorten_the_stages(exe, group):
+    """Sub-levels (sx_plan.h "components"): the invariants hold for 1 (the old one-level-per-stage schedule), 2, 4 and 8 levels per
+    super-step, and the groups' depths -- the super-steps a routing launch spends filling -- shrink accordingly."""
+    m = synth.make_mesh(128, 128, ng=2)
+    depth = {}
+    for u in (1, 2, 4, 8):
+        out = _run(exe, m, group, sublevels=u)
+        assert out.startswith("ok cells 16384")
+        depth[u] = (int(out.split(" deepest ")[1].split()[0]), int(out.split(" stagesum ")[1]))
+    assert depth[2][0] < depth[1][0] and depth[4][0] < depth[2][0] and depth[8][0] <= depth[4][0]
+    assert depth[4][1] < 0.5 * depth[1][1]
+    md = synth.make_mesh_d8(60, 72, ng=2, seed=5)
+    for u in (1, 3, 4):
+        assert _run(exe, md, group, sublevels=u).startswith(f"ok cells {md.nac}")
 
 
 def test_tiles_and_bad_meshes_under_sanitizers(exe):
