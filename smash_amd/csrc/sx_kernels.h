@@ -371,7 +371,11 @@ __device__ __forceinline__ void sx_forcing_at(const SxDeviceArrays& A, int t, un
 #define SX_VFWD_WAVES 8
 #endif
 template <int ST, bool TAPE, bool CF>
-__global__ __launch_bounds__(SX_VBLOCK, (ST == 2 && TAPE && CF) ? SX_VFWD_WAVES : 1) void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
+#ifndef SX_VFWD_WAVES_GRC
+#define SX_VFWD_WAVES_GRC 7       // gr-c, taped, compact: 74 registers = 6 waves as compiled, 72 without a spill when asked for 7
+#endif
+__global__ __launch_bounds__(SX_VBLOCK, (ST == 2 && TAPE && CF) ? SX_VFWD_WAVES : (ST == 3 && TAPE && CF) ? SX_VFWD_WAVES_GRC : 1)
+void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
     SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
@@ -474,8 +478,11 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A,
 
 // compiled for three waves per SIMD (168 registers, a handful spilled): 160 -> 140 ms against the natural 177 registers / two waves;
 // four waves (128 registers) spill the fp64 polynomial constants of log2 / exp2 and take 236 ms
+#ifndef SX_VADJ_WAVES_VIC
+#define SX_VADJ_WAVES_VIC 3
+#endif
 template <bool CF>
-__global__ __launch_bounds__(SX_VBLOCK, 3) void sx_k_vert_adj_vic(SxDeviceArrays A, int t0, int T) {
+__global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES_VIC) void sx_k_vert_adj_vic(SxDeviceArrays A, int t0, int T) {
     SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
@@ -1085,7 +1092,11 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
 #define SX_VADJ_WAVES 5
 #endif
 template <int ST, bool CF>
-__global__ __launch_bounds__(SX_VBLOCK, (ST == 2 && CF) ? SX_VADJ_WAVES : 1) void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
+#ifndef SX_VADJ_WAVES_GRC
+#define SX_VADJ_WAVES_GRC 1       // gr-c, compact: 124 registers = 4 waves as compiled
+#endif
+__global__ __launch_bounds__(SX_VBLOCK, (ST == 2 && CF) ? SX_VADJ_WAVES : (ST == 3 && CF) ? SX_VADJ_WAVES_GRC : 1)
+void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
     SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;
