@@ -292,6 +292,25 @@ int smashx_debug_group_times(smashx_plan* plan, long long* out, int* round_of_gr
  * those, off by more than one ulp. */
 int smashx_selftest_math(int device, long long n, unsigned seed, float blo, float bhi, long long* out);
 
+/* ---- L-BFGS-B, the optimiser of the variational calibration (reference: lbfgsb.f driven by optimize_lbfgsb,
+ * smash/solver/optimize/mw_optimize.f90:484-676: m = 10, factr, pgtol, bounds of the normalised control, reverse communication).
+ * A from-the-paper implementation (Byrd-Lu-Nocedal-Zhu 1995, Morales-Nocedal 2011, More'-Thuente line search; smash_amd/csrc/
+ * sx_lbfgsb.cpp), host C++ with threaded n-vector work, no GPU and no third-party library needed: same method, parameters and stopping
+ * tests as lbfgsb.f, iterates equal to rounding of the inner products (not bit for bit).  lower / upper: NULL or n values (+-inf = none).
+ * Protocol: task = SMASHX_LBFGSB_START; loop { step(...); FG: evaluate f and g at x and call again; NEW_X: an iteration is complete (x is
+ * the new iterate), call again to continue; CONVERGED / ABNORMAL: done }. */
+#define SMASHX_LBFGSB_START 0
+#define SMASHX_LBFGSB_FG 1
+#define SMASHX_LBFGSB_NEW_X 2
+#define SMASHX_LBFGSB_CONVERGED 3
+#define SMASHX_LBFGSB_ABNORMAL 4
+typedef struct smashx_lbfgsb smashx_lbfgsb;
+int smashx_lbfgsb_create(long n, int m, const double* lower, const double* upper, double factr, double pgtol, smashx_lbfgsb** out);
+int smashx_lbfgsb_step(smashx_lbfgsb* opt, double* x, double f, const double* g, int* task);
+long smashx_lbfgsb_iterations(const smashx_lbfgsb* opt);
+const char* smashx_lbfgsb_message(const smashx_lbfgsb* opt);
+int smashx_lbfgsb_destroy(smashx_lbfgsb* opt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@ SYMBOLS = [
     "smashx_control_gradient",
     "smashx_comm_unique_id", "smashx_comm_create", "smashx_comm_destroy", "smashx_comm_allreduce_sum", "smashx_set_exchange",
     "smashx_set_median_slots",
+    "smashx_lbfgsb_create", "smashx_lbfgsb_step", "smashx_lbfgsb_destroy", "smashx_lbfgsb_iterations", "smashx_lbfgsb_message",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
@@ -94,6 +95,12 @@ def lib():
         L.smashx_last_error.restype = C.c_char_p
         for s in SYMBOLS[1:]:
             getattr(L, s).restype = C.c_int
+        L.smashx_lbfgsb_message.restype = C.c_char_p
+        L.smashx_lbfgsb_iterations.restype = C.c_long
+        L.smashx_lbfgsb_create.argtypes = [C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
+        L.smashx_lbfgsb_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
+        for s in ("smashx_lbfgsb_destroy", "smashx_lbfgsb_iterations", "smashx_lbfgsb_message"):
+            getattr(L, s).argtypes = [C.c_void_p]
         _lib = L
     return _lib
 

@@ -5,9 +5,10 @@ Same steps as the reference: normalise the control (mwd_parameters_manipulation.
 start, control vector = optimised fields x active cells in column-major order (var_to_control_lbfgsb :679-718, fp32 ->
 fp64), L-BFGS-B with m = 10, factr = 10, pgtol = 1e-12 and bounds [0, 1] (:505-512, 541-543), every function/gradient
 evaluation one forward_b with denormalize_forward on (:590-606), the two extra stop tests (:625-633), a final forward
-(:646-647).  The L-BFGS-B driver is scipy's (the same Zhu-Byrd-Lu-Nocedal 3.0 code the reference carries as lbfgsb.f);
-with the CPU oracle as the gradient provider the cost trajectory is bit-identical to the reference's
-(tests/test_oracle_golden.py), so on the GPU the only difference is the sweep itself.
+(:646-647).  The L-BFGS-B driver is the library's own (smashx_lbfgsb_*, written from the papers the reference's lbfgsb.f
+implements; round 3) -- scipy's build of that very code is one environment variable away (SMASHX_LBFGSB=scipy) and, fed by
+the CPU oracle, reproduces the reference's cost trajectory bit for bit (tests/test_oracle_golden.py); the native driver
+follows it to rounding of the inner products.
 """
 from __future__ import annotations
 
@@ -27,12 +28,53 @@ class _Stop(Exception):
     pass
 
 
-def _lbfgsb_box(fg, x0, m, factr, pgtol, maxiter, maxfun, callback):
-    """L-BFGS-B (Zhu-Byrd-Lu-Nocedal 3.0, scipy's build of the code the reference carries as lbfgsb.f) on the box [0, 1]^n.
-    scipy's fmin_l_bfgs_b walks the bounds in two Python loops over n before it starts -- tens of seconds for the 1.7e7 control
-    variables of a 2048 x 2048 grid -- so its driver loop (scipy/optimize/_lbfgsb_py.py::_minimize_lbfgsb, 1.15) is restated
-    here around the same setulb with the bound arrays built in one go.  Same iterates, bit for bit
-    (tests/test_cabi_cpu.py).  Other scipy versions go through fmin_l_bfgs_b itself.  Returns (x, f, info)."""
+def _lbfgsb_native(fg, x0, m, factr, pgtol, maxiter, maxfun, callback):
+    """The library's own L-BFGS-B (include/smashx.h smashx_lbfgsb_*: written from Byrd-Lu-Nocedal-Zhu 1995 / Morales-Nocedal 2011 /
+    More'-Thuente, threaded host C++) on the box [0, 1]^n.  No scipy in the loop.  Same method, parameters and stopping tests as the
+    lbfgsb.f the reference calls; on test problems its iterates agree with scipy's build of that code to 1e-15 per iteration
+    (tests/test_cabi_cpu.py).  Returns (x, f, info) like _lbfgsb_scipy."""
+    import ctypes as C
+    from . import _lib
+    L = _lib.lib()
+    n = x0.size
+    lo, up = np.zeros(n, np.float64), np.ones(n, np.float64)
+    h = C.c_void_p()
+    _lib.check(L.smashx_lbfgsb_create(n, int(m), lo.ctypes.data, up.ctypes.data, float(factr), float(pgtol), C.byref(h)))
+    try:
+        x = np.array(x0, dtype=np.float64)
+        task, f, g = C.c_int(0), 0.0, np.zeros(n, np.float64)
+        nit = nfev = 0
+        stop = None
+        while True:
+            _lib.check(L.smashx_lbfgsb_step(h, x.ctypes.data, float(f), g.ctypes.data, C.byref(task)))
+            if task.value == 1:                              # f and g wanted at x
+                f, g = fg(np.copy(x))
+                g = np.ascontiguousarray(g, np.float64)
+                nfev += 1
+            elif task.value == 2:                            # new iterate
+                nit += 1
+                if callback is not None:
+                    callback(np.copy(x))
+                if nit >= maxiter:
+                    stop = "STOP: TOTAL NO. of ITERATIONS REACHED LIMIT"
+                    break
+                if nfev > maxfun:
+                    stop = "STOP: TOTAL NO. of f AND g EVALUATIONS EXCEEDS LIMIT"
+                    break
+            else:
+                break
+        msg = stop or L.smashx_lbfgsb_message(h).decode()
+        return x, float(f), {"task": msg, "nit": nit, "funcalls": nfev, "grad": g}
+    finally:
+        L.smashx_lbfgsb_destroy(h)
+
+
+def _lbfgsb_scipy(fg, x0, m, factr, pgtol, maxiter, maxfun, callback):
+    """scipy's build of the Zhu-Byrd-Lu-Nocedal 3.0 code the reference carries as lbfgsb.f, for comparison (SMASHX_LBFGSB=scipy):
+    bit-identical iterates to the reference's.  scipy's public drivers walk the bounds in Python loops over n before they start --
+    tens of seconds for the 1.7e7 control variables of a 2048 x 2048 grid -- so where its `setulb` entry point has the signature of
+    scipy 1.15 the driver loop (scipy/optimize/_lbfgsb_py.py::_minimize_lbfgsb) is restated around it with the bound arrays built in
+    one go; any other scipy goes through the public fmin_l_bfgs_b.  Returns (x, f, info)."""
     import scipy
     from scipy.optimize import fmin_l_bfgs_b
     n = x0.size
@@ -47,7 +89,7 @@ def _lbfgsb_box(fg, x0, m, factr, pgtol, maxiter, maxfun, callback):
     x = np.clip(np.array(x0, dtype=np.float64), 0.0, 1.0)
     nbd = np.full(n, 2, np.int32)                       # both bounds present
     low, up = np.zeros(n, np.float64), np.ones(n, np.float64)
-    f = np.array(0.0, dtype=np.int32)
+    f = np.array(0.0, dtype=np.int32)                   # (scipy's own driver starts from this placeholder; setulb never reads it before task 3)
     g = np.zeros(n, np.float64)
     wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
     iwa = np.zeros(3 * n, np.int32)
@@ -72,6 +114,15 @@ def _lbfgsb_box(fg, x0, m, factr, pgtol, maxiter, maxfun, callback):
             break
     msg = {4: "CONVERGENCE", 5: "STOP", 6: "WARNING", 7: "ERROR", 8: "ABNORMAL"}.get(int(task[0]), str(int(task[0])))
     return x, float(f), {"task": f"{msg} ({int(task[1])})", "nit": nit, "funcalls": nfev, "grad": g}
+
+
+def _lbfgsb_box(fg, x0, m, factr, pgtol, maxiter, maxfun, callback):
+    """L-BFGS-B on the box [0, 1]^n: the library's own implementation (default), or scipy's build of the reference's lbfgsb.f with
+    SMASHX_LBFGSB=scipy."""
+    import os
+    if os.environ.get("SMASHX_LBFGSB", "native") == "scipy":
+        return _lbfgsb_scipy(fg, x0, m, factr, pgtol, maxiter, maxfun, callback)
+    return _lbfgsb_native(fg, x0, m, factr, pgtol, maxiter, maxfun, callback)
 
 
 def wjreg_range(wjreg_opt, nb_wjreg_lcurve):

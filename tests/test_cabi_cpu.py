@@ -45,13 +45,8 @@ def test_product_does_not_import_the_oracle():
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, f
 
 
-def test_lbfgsb_driver_reproduces_scipy_bit_for_bit():
-    """smash_amd.optimize._lbfgsb_box (the host L-BFGS-B loop with vectorised bound arrays) against scipy's own
-    fmin_l_bfgs_b on a bounded, badly scaled problem: same iterates, same function values, same number of evaluations."""
-    from scipy.optimize import fmin_l_bfgs_b
-    from smash_amd.optimize import _lbfgsb_box
-    rng = np.random.default_rng(3)
-    n = 400
+def _bounded_problem(n, seed=3):
+    rng = np.random.default_rng(seed)
     tgt = rng.uniform(-0.3, 1.3, n)                    # some optima outside the box: active bounds
     w = 10.0 ** rng.uniform(-2, 2, n)
 
@@ -65,12 +60,90 @@ def test_lbfgsb_driver_reproduces_scipy_bit_for_bit():
             log.append((f, x.copy()))
             return f, g
         return fg, log
+    return make
+
+
+def test_scipy_lbfgsb_driver_reproduces_scipy_bit_for_bit():
+    """smash_amd.optimize._lbfgsb_scipy (SMASHX_LBFGSB=scipy: the host loop around scipy's setulb with vectorised bound arrays)
+    against scipy's own fmin_l_bfgs_b on a bounded, badly scaled problem: same iterates, same function values, same number of
+    evaluations."""
+    from scipy.optimize import fmin_l_bfgs_b
+    from smash_amd.optimize import _lbfgsb_scipy
+    n = 400
+    make = _bounded_problem(n)
     x0 = np.full(n, 0.5)
     for maxiter in (1, 4, 25):
         fa, la = make()
         fb, lb = make()
         xa, va, ia = fmin_l_bfgs_b(fa, x0, m=10, factr=10.0, pgtol=1e-12, bounds=[(0.0, 1.0)] * n, maxiter=maxiter, maxfun=10 * maxiter + 20)
-        xb, vb, ib = _lbfgsb_box(fb, x0, 10, 10.0, 1e-12, maxiter, 10 * maxiter + 20, None)
+        xb, vb, ib = _lbfgsb_scipy(fb, x0, 10, 10.0, 1e-12, maxiter, 10 * maxiter + 20, None)
         assert len(la) == len(lb) and ia["nit"] == ib["nit"]
         assert all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(la, lb))
         assert np.array_equal(xa, xb) and va == vb
+
+
+def test_native_lbfgsb_follows_the_reference_code_iterate_by_iterate():
+    """The library's own L-BFGS-B (smashx_lbfgsb_*, the default of smash_amd.optimize) against scipy's build of the lbfgsb.f the
+    reference carries, on a bounded, badly scaled problem with active bounds: the same number of iterations and evaluations, every
+    trial point and function value equal to rounding of the inner products (the two codes sum in different orders; threads)."""
+    from smash_amd.optimize import _lbfgsb_native, _lbfgsb_scipy
+    n = 400
+    make = _bounded_problem(n)
+    x0 = np.full(n, 0.5)
+    for maxiter in (1, 4, 12):
+        fa, la = make()
+        fb, lb = make()
+        xa, va, ia = _lbfgsb_scipy(fa, x0, 10, 10.0, 1e-12, maxiter, 10 * maxiter + 20, None)
+        xb, vb, ib = _lbfgsb_native(fb, x0, 10, 10.0, 1e-12, maxiter, 10 * maxiter + 20, None)
+        assert len(la) == len(lb) and ia["nit"] == ib["nit"] == maxiter and ia["funcalls"] == ib["funcalls"]
+        for (f1, x1), (f2, x2) in zip(la, lb):
+            assert abs(f1 - f2) <= 1e-11 * abs(f1) and np.max(np.abs(x1 - x2)) <= 1e-10
+        assert np.array_equal((xa == 0) | (xa == 1), (xb == 0) | (xb == 1))          # the same active set at the end
+
+
+@pytest.mark.parametrize("n,m", [(2, 5), (10, 10), (50, 10), (1000, 7)])
+def test_native_lbfgsb_converges_like_the_reference_code(n, m):
+    """Rosenbrock in a box that cuts the valley ([0, 0.8]^n scaled to the unit box the driver works on) and unconstrained-in-effect
+    ([0,1]^n, optimum at the corner 1): both codes stop by the same test within a few evaluations of each other at the same
+    minimum."""
+    from smash_amd.optimize import _lbfgsb_native, _lbfgsb_scipy
+    for scale in (0.8, 1.0):
+        def fg(u):
+            x = scale * u
+            f = float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+            g = np.zeros_like(x)
+            g[:-1] = -400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+            g[1:] += 200.0 * (x[1:] - x[:-1] ** 2)
+            return f, scale * g
+        x0 = np.full(n, 0.3)
+        xa, va, ia = _lbfgsb_scipy(fg, x0, m, 1e7, 1e-8, 5000, 8000, None)
+        xb, vb, ib = _lbfgsb_native(fg, x0, m, 1e7, 1e-8, 5000, 8000, None)
+        assert ia["task"].startswith("CONVERGENCE") and ib["task"].startswith("CONVERGENCE"), (ia["task"], ib["task"])
+        assert abs(ia["nit"] - ib["nit"]) <= max(3, ia["nit"] // 50), (ia["nit"], ib["nit"])
+        assert abs(va - vb) <= 1e-6 * max(1.0, abs(va)) and np.max(np.abs(xa - xb)) <= 1e-3
+
+
+def test_native_lbfgsb_argument_and_limit_behaviour():
+    """Error behaviour of the C entry points and the driver's own stop tests (iteration and evaluation limits, callback per iterate)."""
+    import ctypes as C
+    from smash_amd import _lib
+    from smash_amd.optimize import _lbfgsb_native
+    L = _lib.lib()
+    h = C.c_void_p()
+    lo, up = np.zeros(3), np.ones(3)
+    assert L.smashx_lbfgsb_create(0, 5, lo.ctypes.data, up.ctypes.data, 1e7, 1e-8, C.byref(h)) != 0
+    assert L.smashx_lbfgsb_create(3, 0, lo.ctypes.data, up.ctypes.data, 1e7, 1e-8, C.byref(h)) != 0
+    assert L.smashx_lbfgsb_create(3, 5, up.ctypes.data, lo.ctypes.data, 1e7, 1e-8, C.byref(h)) != 0      # lower > upper
+    seen = []
+    make = _bounded_problem(50)
+    fg, log = make()
+    x, f, info = _lbfgsb_native(fg, np.full(50, 0.5), 10, 10.0, 1e-14, 3, 1000, lambda xk: seen.append(xk.copy()))
+    assert info["nit"] == 3 and len(seen) == 3 and "ITERATIONS" in info["task"] and np.array_equal(seen[-1], x)
+    assert np.all(x >= 0) and np.all(x <= 1) and f == log[-1][0]
+    fg, log = make()
+    x, f, info = _lbfgsb_native(fg, np.full(50, 0.5), 10, 10.0, 1e-14, 1000, 4, None)
+    assert "EVALUATIONS" in info["task"] and info["funcalls"] <= 7
+    # a start outside the box is projected onto it first (lbfgsb.f projgr / active)
+    fg, log = make()
+    _lbfgsb_native(fg, np.full(50, 1.5), 10, 10.0, 1e-14, 1, 50, None)
+    assert np.all(log[0][1] == 1.0)

@@ -18,7 +18,7 @@ build)
   F="-O3 -ffp-contract=off --offload-arch=gfx950 -fPIC -shared -std=c++17"
   n=0
   for k in "${!V[@]}"; do
-    /opt/rocm/bin/hipcc $F ${V[$k]} -o variants/lib_$k.so smash_amd/csrc/smashx.hip smash_amd/csrc/sx_plan.cpp -ldl 2>/dev/null &
+    /opt/rocm/bin/hipcc $F ${V[$k]} -o variants/lib_$k.so smash_amd/csrc/smashx.hip smash_amd/csrc/sx_plan.cpp smash_amd/csrc/sx_lbfgsb.cpp -pthread -ldl 2>/dev/null &
     n=$((n+1)); if [ $((n % 4)) -eq 0 ]; then wait; fi
   done
   wait; ls variants/*.so ;;
