@@ -266,6 +266,11 @@ __global__ void sx_k_prep_routing(SxDeviceArrays A) {
 // stream (forcing in, tapes and qt out) 42.0 -> 41.1 ms; nt on the reverse kernel's loads 76.4 -> 78.7 ms, so only the
 // forward kernel uses it.
 #define SX_NT 2
+// Still steps (prcp = pet = 0 on every lane of a wavefront: sx_ops.h) take the short form of the vertical step, forward and reverse.
+// -DSX_STILL=0 compiles the general step only (A/B builds: tools/anatomy.sh).
+#ifndef SX_STILL
+#define SX_STILL 1
+#endif
 #define SX_HIK 8             // steps per block of the interception level's checkpoint / rebuild (chunk offsets are multiples of 16)
 #ifndef SX_VADJ_NT
 #define SX_VADJ_NT 0
@@ -374,7 +379,7 @@ template <int ST, bool TAPE, bool CF>
 #ifndef SX_VFWD_WAVES_GRC
 #define SX_VFWD_WAVES_GRC 7       // gr-c, taped, compact: 74 registers = 6 waves as compiled, 72 without a spill when asked for 7
 #endif
-__global__ __launch_bounds__(SX_VBLOCK, (ST == 2 && TAPE && CF) ? SX_VFWD_WAVES : (ST == 3 && TAPE && CF) ? SX_VFWD_WAVES_GRC : 1)
+__global__ __launch_bounds__(SX_VBLOCK, (ST == 2 && CF) ? SX_VFWD_WAVES : (ST == 3 && TAPE && CF) ? SX_VFWD_WAVES_GRC : 1)
 void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
     SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
@@ -419,7 +424,8 @@ void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
                     sx_row_store<SX_NT>(A.tape_hft + o, kb, hft);
                     if (ST == 3) sx_row_store<SX_NT>(A.tape_hst + o, kb, hst);
                 }
-                q[i] = sx_vertical_step<ST>(P, prcp, pet, hi, hp, hft, hst);
+                const bool still = SX_STILL && sx_wave_all(sx_is_still<ST>(prcp, pet, hi, hp));      // wave-uniform
+                q[i] = sx_vertical_step<ST>(P, prcp, pet, hi, hp, hft, hst, still);
             }
         }
         sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
@@ -1175,7 +1181,8 @@ void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
             if (tt > 0) fetch(tt - 1, false);
             const float prcp = F.prcp(), pet = F.pet();
             const float hi = (ST == 2 || ST == 3) ? (hi_taped ? hit : s_hi[tt - tt0][threadIdx.x]) : 0.f;
-            sx_vertical_step_b<ST>(P, Q, prcp, pet, hi, hp, hft, hst, q, G);
+            const bool still = SX_STILL && sx_wave_all(sx_is_still<ST>(prcp, pet, hi, hp));      // wave-uniform
+            sx_vertical_step_b<ST>(P, Q, prcp, pet, hi, hp, hft, hst, q, G, still);
         }
     }
     if (ST == 2 || ST == 3) { A.ci_b[k] = G.ci_b; A.hi_b[k] = G.hi_b; }

@@ -22,6 +22,9 @@
 #ifndef SX_EXACT_LIBM
 #define SX_EXACT_LIBM 0
 #endif
+#ifndef SX_EXACT_DIV
+#define SX_EXACT_DIV 2
+#endif
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #include <hip/hip_runtime.h>
@@ -77,6 +80,17 @@ SX_HD float sx_seed_sqrt(float x) {
 // tests/test_sx_math.py).  3 instructions instead of the ~10 of the IEEE division expansion.
 struct SxDiv { float d, r; };
 SX_HD SxDiv sx_mkdiv(float d) { SxDiv D; D.d = d; D.r = 1.0f / d; return D; }
+// The same division for a tiny numerator (|a / d| < 2^-100, subnormal a included): the three operations on a * 2^64, scaled back.
+// Power-of-two scalings are exact, the residual of the scaled problem does not underflow, so the result is RN(a / d) whenever that
+// is a normal number: *ok says so (false: subnormal or zero result -- scaling back rounded a second time; the caller divides).
+// Checked against a / d on the host, subnormal numerators and results included (tests/test_sx_math.py).
+SX_HD float sx_div_scaled(float a, const SxDiv& D, bool* ok) {
+    const float as = a * 0x1p64f;
+    const float qs = as * D.r;
+    const float q3 = fmaf(fmaf(-D.d, qs, as), D.r, qs) * 0x1p-64f;
+    *ok = fabsf(q3) >= 0x1p-126f;
+    return q3;
+}
 SX_HD float sx_div(float a, const SxDiv& D) {
 #if defined(SX_ABL_DIV)
     return a * D.r;      // timing-only build (tools/anatomy.sh): what the exact divisions cost; results void
@@ -84,11 +98,30 @@ SX_HD float sx_div(float a, const SxDiv& D) {
     const float q = a * D.r;
     const float e = fmaf(-D.d, q, a);
     const float q2 = fmaf(e, D.r, q);
-#if SX_EXACT_LIBM
-    // the theorem needs the residual to be exact: outside the comfortable exponent range (tiny quotients on their way to the
-    // subnormals, huge ones) the exact build takes the IEEE division
+#if SX_EXACT_LIBM && !defined(SX_ABL_NOGUARD)
+    // The theorem needs the residual to be exact: outside the comfortable exponent range (tiny quotients on their way to the
+    // subnormals -- the fringe of a decaying adjoint field is full of them -- and huge ones) the exact build takes the IEEE division.
+    // SX_EXACT_DIV: 0 = per-lane branch (round 2), 1 = the test is made for the whole wavefront (scalar branch, the IEEE expansion
+    // only runs in wavefronts that hold such a quotient), 2 = as 1, and quotients below 2^-100 whose IEEE result is still a normal
+    // number are obtained exactly from the same three operations on a * 2^64 (a power-of-two scaling commutes with the division's
+    // single rounding as long as the result stays normal): only subnormal, zero, huge and non-finite results take the expansion.
     const float m = fabsf(q2);
+#if defined(__HIP_DEVICE_COMPILE__) && SX_EXACT_DIV >= 1
+#if SX_EXACT_DIV >= 2
+    const bool tiny = !(m > 0x1p-100f) && a != 0.f;
+    if (__builtin_amdgcn_ballot_w64(tiny || !(m < 0x1p100f)) == 0ull) return q2;
+    bool ok3;
+    const float q3 = sx_div_scaled(a, D, &ok3);
+    const bool bad = (tiny && !ok3) || (!(m < 0x1p100f) && a != 0.f);
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) return bad ? a / D.d : (tiny ? q3 : q2);
+    return tiny ? q3 : q2;
+#else
+    const bool bad = !(m > 0x1p-100f && m < 0x1p100f) && a != 0.f;
+    if (__builtin_amdgcn_ballot_w64(bad) != 0ull) return bad ? a / D.d : q2;
+#endif
+#else
     if (!(m > 0x1p-100f && m < 0x1p100f) && a != 0.f) return a / D.d;
+#endif
 #endif
     return q2;
 }

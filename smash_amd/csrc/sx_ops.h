@@ -90,9 +90,13 @@ SX_DEV void sx_transfer(float prcp, float pr, float ct, const SxDiv& dct, float 
 // one vertical cell-step: everything of md_forward_structure.f90:94-151 (gr-a), 280-330 (gr-b),
 // 466-517 (gr-c), 655-690 (gr-d) that precedes the routing module.  Returns qt.
 template <int ST>
-SX_DEV float sx_vertical_step(const SxCellParams& P, float prcp, float pet, float& hi, float& hp, float& hft, float& hst) {
+SX_DEV float sx_vertical_step(const SxCellParams& P, float prcp, float pet, float& hi, float& hp, float& hft, float& hst, bool still = false) {
     float ei = 0.f, pn = 0.f, en = 0.f, pr = 0.f, perc = 0.f, l = 0.f;
-    if (prcp >= 0.f && pet >= 0.f) {
+    if (still) {       // wave-uniform: every lane in a still step (see sx_is_still below)
+        if (ST == 2 || ST == 3) hi = hi + 0.f;        // hi + (prcp - ei - pn) / ci
+        hp = hp + 0.f;                                // hp_imd = hp + (ps - es) / cp;  perc = (hp_imd cp) (1 - 1) = +-0;  hp = hp_imd - perc / cp
+        if (ST != 4) l = P.exc * sx_pow_3p5(hft);     // pr + perc = +0
+    } else if (prcp >= 0.f && pet >= 0.f) {
         if (ST == 1 || ST == 4) {
             ei = fminf(pet, prcp);
             pn = fmaxf(0.f, prcp - ei);
@@ -125,6 +129,24 @@ SX_DEV float sx_vertical_step(const SxCellParams& P, float prcp, float pet, floa
     }
     return qt;
 }
+
+// ---------------------------------------------------------------- "still" steps
+// A step with no rain and no evaporative demand (prcp = pet = 0) leaves the interception and production stores where they are:
+// every night hour of the reference's own hourly PET disaggregation is one (RATIO_PET_HOURLY is zero for 12 of 24 hours,
+// core/_constant.py:47-75), rain permitting.  When ALL lanes of a wavefront are in that state the step below replaces the
+// general one -- a scalar branch, nothing is predicated -- and is the general step with the zeros carried through by hand
+// (each line says which general expression it is).  Same bits: every dropped operation is an addition of +-0 to, or a product
+// with 0 of, a finite value (only the sign of a zero gradient, or a NaN that the general step would have spread from an
+// already infinite adjoint, can differ).
+//   needs, per lane: prcp == 0, pet == 0; 0 <= hi <= 1 (then ei = min(0, hi ci) = 0 and pn = max(0, -ci (1 - hi)) = 0, no branch
+//   of GR_INTERCEPTION_B is taken); |hp| < 15 (the percolation power is exactly 1, sx_production_full).
+template <int ST>
+SX_DEV bool sx_is_still(float prcp, float pet, float hi, float hp) {
+    bool s = (prcp == 0.f) & (pet == 0.f) & (fabsf(hp) < 15.f);
+    if (ST == 2 || ST == 3) s = s & (hi >= 0.f) & (hi <= 1.f);
+    return s;
+}
+SX_DEV bool sx_wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(!pred) == 0ull; }   // over the active lanes
 
 // ---------------------------------------------------------------- adjoint
 SX_DEV void sx_interception_b(float prcp, float pet, float ci, const SxDiv& dci, float& ci_b, float hi, float& hi_b, float& pn_b, float& ei_b) {
@@ -283,20 +305,25 @@ struct SxAdjParams {   // extra per-cell invariants of the adjoint
     SxDiv dcft2, dcst2, dcp2;      // exact division by cft**2, cst**2, cp**2
 };
 
+// still (wave-uniform): every lane is in a still step (sx_is_still) -- prcp = pet = 0 then, pr + perc = +0 and of
+// GR_PRODUCTION_B only the percolation term reaches hp_b (pn_b and en_b are read by nothing: GR_INTERCEPTION_B takes neither
+// branch and its quotients multiply prcp - ei - pn = 0); ci_b, cp_b, hi_b stay.
 template <int ST>
 SX_DEV void sx_vertical_step_b(const SxCellParams& P, const SxAdjParams& Q, float prcp, float pet, float hi, float hp,
-                               float hft, float hst, float qt_b, SxCellGrads& G) {
-    const bool wet = (prcp >= 0.f && pet >= 0.f);
+                               float hft, float hst, float qt_b, SxCellGrads& G, bool still = false) {
+    const bool wet = still || (prcp >= 0.f && pet >= 0.f);
     float ei = 0.f, pn = 0.f, en = 0.f, pr = 0.f, perc = 0.f, l = 0.f, prr, prl = 0.f, prd = 0.f;
     float h35 = 0.f, h25 = 0.f;
     SxProd R;
     if (wet) {
-        float hi2 = hi;
-        if (ST == 1 || ST == 4) { ei = fminf(pet, prcp); pn = fmaxf(0.f, prcp - ei); }
-        else sx_interception(prcp, pet, P.ci, P.dci, hi2, pn, ei);
-        en = pet - ei;
-        R = sx_production_full<true>(pn, en, P.cp, P.inv_cp, hp);
-        pr = R.pr; perc = R.perc;
+        if (!still) {
+            float hi2 = hi;
+            if (ST == 1 || ST == 4) { ei = fminf(pet, prcp); pn = fmaxf(0.f, prcp - ei); }
+            else sx_interception(prcp, pet, P.ci, P.dci, hi2, pn, ei);
+            en = pet - ei;
+            R = sx_production_full<true>(pn, en, P.cp, P.inv_cp, hp);
+            pr = R.pr; perc = R.perc;
+        }
         if (ST != 4) { sx_pow_3p5_2p5(hft, &h35, &h25); l = P.exc * h35; }
     }
     if (ST == 1 || ST == 2) { prr = 0.9f * (pr + perc) + l; prd = 0.1f * (pr + perc); }
@@ -331,6 +358,16 @@ SX_DEV void sx_vertical_step_b(const SxCellParams& P, const SxAdjParams& Q, floa
         if (ST != 4) {   // GR_EXCHANGE_B
             G.exc_b = G.exc_b + h35 * l_b;
             G.hft_b = G.hft_b + 3.5f * h25 * P.exc * l_b;
+        }
+        if (still) {
+            const SxDiv db4 = {1.0e12f, 1.0f / 1.0e12f};
+            const float hp_imd = hp + 0.f;
+            perc_b = perc_b - P.inv_cp * G.hp_b;
+            const float pwr1_b = -(hp_imd * P.cp * perc_b);
+            const float pwx1_b = -(0.25f * pwr1_b);       // pw125 = 1
+            // hp_b + cp (1 - pwr1) perc_b + 4 hp_imd^3 pwx1_b / beta^4, then the "hp_b = 0; hp_b = hp_b + hp_imd_b" of the dry branches
+            G.hp_b = 0.f + (G.hp_b + (P.cp * 0.f) * perc_b + sx_div(4.f * (hp_imd * hp_imd * hp_imd) * pwx1_b, db4));
+            return;
         }
         sx_production_b(R, pn, pn_b, en, en_b, P.cp, P.inv_cp, Q.dcp2, G.cp_b, hp, G.hp_b, pr_b, perc_b);
         if (ST == 2 || ST == 3) {

@@ -53,6 +53,32 @@ long sxt_div_mismatches(long n) {
     return bad;
 }
 
+/* the scaled form of that division (exact-libm build, tiny quotients): numerators from the smallest subnormal up, quotients between
+ * 2^-160 and 2^-95.  out[0] = results flagged ok that differ from a / d (must be 0), out[1] = flagged ok, out[2] = not ok although
+ * a / d is a normal number (must be 0: only subnormal and zero results may be handed back) */
+void sxt_div_scaled_check(long n, long* out) {
+    srand(991);
+    out[0] = out[1] = out[2] = 0;
+    for (long i = 0; i < n; ++i) {
+        uint32_t ua = ((uint32_t)rand() << 8) ^ (uint32_t)rand(), ub = ((uint32_t)rand() << 8) ^ (uint32_t)rand();
+        const int ed = 90 + rand() % 76;                         /* d in 2^-37 .. 2^38 */
+        const int eq = 127 - 160 + rand() % 66;                  /* target quotient exponent -160 .. -95 */
+        int ea = eq + ed - 127;                                  /* biased exponent of a (may be <= 0: subnormal a) */
+        ub = (ub & 0x007fffffu) | ((uint32_t)ed << 23);
+        if ((i & 255) == 0) ub |= 0x007fffffu;
+        float a;
+        if (ea >= 1) a = sx_u2f((ua & 0x807fffffu) | ((uint32_t)ea << 23));
+        else { const int sh = 1 - ea; a = sh < 24 ? sx_u2f((ua & 0x80000000u) | (((ua & 0x007fffffu) | 0x00800000u) >> sh)) : sx_u2f((ua & 0x80000000u) | 1u); }
+        if (a == 0.f) continue;
+        const float d = sx_u2f(ub);
+        const SxDiv D = sx_mkdiv(d);
+        bool ok;
+        const float q = sx_div_scaled(a, D, &ok), ref = a / d;
+        if (ok) { out[1]++; if (q != ref) out[0]++; }
+        else if (fabsf(ref) >= 0x1p-126f) out[2]++;
+    }
+}
+
 float sxt_expf(float x) { return sx_expf(x); }
 
 /* sx_powf / sx_logf (fp64 log2 / exp2 evaluation) on n random arguments of the vic-a kind: out[0] = fp32 mismatches against

@@ -64,6 +64,14 @@ def test_reciprocal_fma_division_is_ieee_division(lib):
     assert lib.sxt_div_mismatches(20_000_000) == 0
 
 
+def test_scaled_division_of_tiny_numerators_is_ieee_division(lib):
+    """sx_div_scaled (the exact-libm build's division for quotients below 2^-100: the adjoint fringe): whenever it says ok the result
+    is a / d, and it only declines subnormal / zero results."""
+    out = (C.c_long * 3)()
+    lib.sxt_div_scaled_check(20_000_000, out)
+    assert out[0] == 0 and out[2] == 0 and out[1] > 5_000_000, list(out)
+
+
 def test_restated_glibc_expf_logf_powf_are_bit_identical_to_the_c_library(lib):
     """smash_amd/csrc/sx_libm.h (the exact-libm build of the kernels) against glibc 2.35 itself: expf on every 7th float,
     logf on every 5th positive float, powf with the six fixed exponents of the GR operators on every 11th base in [1e-7, 1e4],
