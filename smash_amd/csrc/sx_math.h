@@ -25,6 +25,9 @@
 #ifndef SX_EXACT_DIV
 #define SX_EXACT_DIV 2
 #endif
+#ifndef SX_TANH_FAST
+#define SX_TANH_FAST 1      // wave-uniform straight-line path of sx_tanhf for small arguments (0: the branchy restatement only)
+#endif
 
 #if defined(__HIPCC__) || defined(__HIP__)
 #include <hip/hip_runtime.h>
@@ -396,6 +399,26 @@ SX_HD float sx_tanhf(float x) {
 #endif
     const uint32_t jx = sx_f2u(x), ix = jx & 0x7fffffffu;
     float t, z;
+#if defined(__HIP_DEVICE_COMPILE__) && SX_TANH_FAST
+    // Small arguments on every lane of the wavefront (evaporation or net rain against the store's capacity: en / cp ~ 1e-3): the same
+    // operations as below along the one path such arguments take -- |x| < 2^-55: x (1 + x); else expm1f(-2|x|) with k = 0 (|2x| <
+    // ln2 / 2), its |2x| < 2^-25 shortcut as a select -- without any branch.  Same bits by construction.
+    if (__builtin_amdgcn_ballot_w64(!(ix < 0x3e317218u)) == 0ull) {      // |x| < ln2 / 4: |2x| <= 0x3eb17218 (ln2 / 2), expm1f's k = 0 range
+        const float ax = sx_u2f(ix);
+        const float x2 = -2.0f * ax;
+        const float Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f, Q3 = -7.9365076090e-05f, Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;
+        const float hfx = 0.5f * x2, hxs = x2 * hfx;
+        const float r1 = 1.0f + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+        const float tt = 3.0f - r1 * hfx;
+        const float e = hxs * sx_fdiv(r1 - tt, 6.0f - x2 * tt);
+        float em = x2 - (x2 * e - hxs);
+        em = ((sx_f2u(x2) & 0x7fffffffu) < 0x33000000u) ? x2 : em;           // expm1f: |x| < 2^-25 returns x
+        z = sx_fdiv(-em, em + 2.0f);
+        float res = (jx >> 31) ? -z : z;
+        res = (ix < 0x24000000u) ? x * (1.0f + x) : res;                      // tanhf: |x| < 2^-55
+        return ix == 0u ? x : res;
+    }
+#endif
     if (ix < 0x41b00000u) {             // |x| < 22
         if (ix == 0) return x;
         if (ix < 0x24000000u) return x * (1.0f + x);

@@ -15,6 +15,24 @@
 
 #define SX_DEV __device__ __forceinline__
 
+// Conditions that are nearly always the same on all 64 lanes (rain or no rain, day or night, a data gap) can be tested per WAVEFRONT:
+// a ballot and a scalar branch, the body runs for every lane and a select keeps what the lane's own condition says -- same results by
+// construction.  It pays where a body is a nest of per-lane branches (sx_tanhf's straight-line path, sx_math.h: vert_fwd -7 %, vert_adj
+// -3.5 %; the still steps below) and does NOT pay for the single-level branches of the operators here (measured at 1024^2 x 8760, bit
+// mask SX_WAVE_BRANCH: none 63.0-63.4 ms of vert_adj, production 63.8, production + transfer 63.9, production_b 64.6, all 66.8 -- the
+// selects cost registers, 10 -> 16 spilled): default 0, the per-lane form.  What did pay in the same pass: plain selects instead of
+// the small divergent branches (1e-6 < ht_try in sx_transfer_b, pr, the day branch of sx_production_b): 66.4 -> 64.4 ms.
+#ifndef SX_WAVE_BRANCH
+#define SX_WAVE_BRANCH 0
+#endif
+SX_DEV bool sx_wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(!pred) == 0ull; }   // over the active lanes
+SX_DEV bool sx_wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
+#define SX_ANY_IF(bit, c) (((SX_WAVE_BRANCH) >> (bit)) & 1 ? sx_wave_any(c) : (c))
+#define SX_ANY_P(c) SX_ANY_IF(0, c)      // sx_production_full
+#define SX_ANY_T(c) SX_ANY_IF(1, c)      // sx_transfer (gap)
+#define SX_ANY_B(c) SX_ANY_IF(2, c)      // sx_production_b
+#define SX_ANY_G(c) SX_ANY_IF(3, c)      // sx_transfer_b (gap)
+
 struct SxCellParams {   // time-invariant per cell, hoisted out of the time loop
     float ci, cp, inv_cp, cft, cst, exc;
     float cft_m4, cst_m4;   // powf(ct, -4)
@@ -42,27 +60,35 @@ template <bool ADJ>
 SX_DEV SxProd sx_production_full(float pn, float en, float cp, float inv_cp, float hp) {
     const SxDiv dbeta = {1000.f, 1.0f / 1000.f};   // beta = 1000 at every call site
     SxProd R;
-    R.pr = 0.f;
-    // tanh(0) = 0 exactly, and at most one of pn, en is non-zero in practice: skip the dead evaluation
-    R.thp = 0.f; R.the = 0.f;
-    if (pn > 0.f) R.thp = sx_tanhf(pn * inv_cp);
-    if (en > 0.f) R.the = sx_tanhf(en * inv_cp);
-    // with tanh = 0 the quotient is (+-0)/1: skip the division (dry steps: 90 %; nights: 45 %)
-    R.ps = 0.f; R.es = 0.f;
-    if (pn > 0.f) R.ps = sx_fdiv(cp * (1.f - hp * hp) * R.thp, 1.f + hp * R.thp);
-    if (en > 0.f) R.es = sx_fdiv((hp * cp) * (2.f - hp) * R.the, 1.f + (1.f - hp) * R.the);
+    // tanh(0) = 0 exactly, and at most one of pn, en is non-zero in practice: skip the dead evaluation; with tanh = 0 the quotient
+    // is (+-0)/1: skip the division too (dry steps: 90 %; nights: 45 %)
+    R.thp = 0.f; R.the = 0.f; R.ps = 0.f; R.es = 0.f;
+    const bool wp = pn > 0.f, we = en > 0.f;
+    if (SX_ANY_P(wp)) {
+        const float t = sx_tanhf(pn * inv_cp);
+        const float q = sx_fdiv(cp * (1.f - hp * hp) * t, 1.f + hp * t);
+        R.thp = wp ? t : 0.f; R.ps = wp ? q : 0.f;
+    }
+    if (SX_ANY_P(we)) {
+        const float t = sx_tanhf(en * inv_cp);
+        const float q = sx_fdiv((hp * cp) * (2.f - hp) * t, 1.f + (1.f - hp) * t);
+        R.the = we ? t : 0.f; R.es = we ? q : 0.f;
+    }
     R.hp_imd = hp + (R.ps - R.es) * inv_cp;
-    if (pn > 0.f) R.pr = pn - (R.hp_imd - hp) * cp;
+    R.pr = wp ? pn - (R.hp_imd - hp) * cp : 0.f;
     // |hp_imd| < 15  =>  (hp_imd / 1000)^4 < 2^-24  =>  1 + r^4 rounds to exactly 1 (beta = 1000): the usual case needs
     // neither the division nor the power
     R.pwr1 = 1.f; R.pw125 = 1.f;
-    if (!(fabsf(R.hp_imd) < 15.f)) {
-        const float r = sx_div(R.hp_imd, dbeta);
-        const float r2 = r * r;
-        const float pwx1 = 1.f + r2 * r2;
-        if (pwx1 != 1.f) {
-            if (ADJ) sx_pow_m025_m125(pwx1, &R.pwr1, &R.pw125);
-            else R.pwr1 = sx_pow_m025(pwx1);
+    const bool big = !(fabsf(R.hp_imd) < 15.f);
+    if (SX_ANY_P(big)) {
+        if (big) {
+            const float r = sx_div(R.hp_imd, dbeta);
+            const float r2 = r * r;
+            const float pwx1 = 1.f + r2 * r2;
+            if (pwx1 != 1.f) {
+                if (ADJ) sx_pow_m025_m125(pwx1, &R.pwr1, &R.pw125);
+                else R.pwr1 = sx_pow_m025(pwx1);
+            }
         }
     }
     R.perc = (R.hp_imd * cp) * (1.f - R.pwr1);
@@ -76,11 +102,10 @@ SX_DEV void sx_production(float pn, float en, float cp, float inv_cp, float& hp,
 }
 
 SX_DEV void sx_transfer(float prcp, float pr, float ct, const SxDiv& dct, float ct_m4, float& ht, float& q) {
-    float pr_imd;
-    if (prcp < 0.f) {   // data gap: closed-form inverse (md_gr_operator.f90:94-96)
-        pr_imd = sx_pow_m025(sx_pow_m4(ht * ct) - ct_m4) - (ht * ct);
-    } else {
-        pr_imd = pr;
+    float pr_imd = pr;
+    const bool gap = prcp < 0.f;
+    if (SX_ANY_T(gap)) {   // data gap: closed-form inverse (md_gr_operator.f90:94-96)
+        if (gap) pr_imd = sx_pow_m025(sx_pow_m4(ht * ct) - ct_m4) - (ht * ct);
     }
     const float ht_imd = fmaxf(1.e-6f, ht + sx_div(pr_imd, dct));
     ht = sx_div(sx_pow_m025(sx_pow_m4(ht_imd * ct) + ct_m4), dct);
@@ -146,7 +171,6 @@ SX_DEV bool sx_is_still(float prcp, float pet, float hi, float hp) {
     if (ST == 2 || ST == 3) s = s & (hi >= 0.f) & (hi <= 1.f);
     return s;
 }
-SX_DEV bool sx_wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(!pred) == 0ull; }   // over the active lanes
 
 // ---------------------------------------------------------------- adjoint
 SX_DEV void sx_interception_b(float prcp, float pet, float ci, const SxDiv& dci, float& ci_b, float hi, float& hi_b, float& pn_b, float& ei_b) {
@@ -180,30 +204,38 @@ SX_DEV void sx_production_b(const SxProd& R, float pn, float& pn_b, float en, fl
     const float pwr1_b = -(hp_imd * cp * perc_b);
     const float pwx1_b = -(0.25f * R.pw125 * pwr1_b);
     float hp_imd_b = hp_b + cp * (1.f - pwr1) * perc_b + sx_div(4.f * (hp_imd * hp_imd * hp_imd) * pwx1_b, db4);
-    if (pn > 0.f) {
-        pn_b = pr_b;
-        hp_imd_b = hp_imd_b - cp * pr_b;
-        hp_b = cp * pr_b;
-        cp_b = cp_b - (hp_imd - hp) * pr_b;
-    } else {
-        hp_b = 0.f;
-        pn_b = 0.f;
+    const bool wp = pn > 0.f;
+    hp_b = 0.f;
+    pn_b = 0.f;
+    if (SX_ANY_B(wp)) {
+        if (wp) {
+            pn_b = pr_b;
+            hp_imd_b = hp_imd_b - cp * pr_b;
+            hp_b = cp * pr_b;
+            cp_b = cp_b - (hp_imd - hp) * pr_b;
+        }
     }
     const float es_b = -(inv_cp * hp_imd_b);
     const float ps_b = inv_cp * hp_imd_b;
     float temp0 = hp * cp * (-hp + 2.f);
     float temp_b, temp_b0, temp_b4, temp_b5;
-    if (en > 0.f) {
+    const bool we = en > 0.f;
+    if (SX_ANY_B(we)) {
+        // day: the general form on every lane, the lane's own test selects (a lane with en = 0 has the = 0: same values as below up
+        // to the sign of a zero, but the select keeps it to the letter)
         const float temp4 = the, temp1 = the;
         const SxDiv d3 = sx_mkdiv_fast((-hp + 1.f) * temp4 + 1.f);
         const float temp_b3 = sx_div(es_b, d3);
-        temp_b = (2.f - hp) * temp1 * temp_b3;
-        temp_b0 = -sx_div(temp0 * temp1 * temp_b3, d3);
-        hp_b = hp_b + hp_imd_b + cp * temp_b - hp * cp * temp1 * temp_b3 - temp4 * temp_b0;
-        temp_b4 = (1.0f - the * the) * temp0 * temp_b3;
-        temp_b5 = (1.0f - the * the) * (1.f - hp) * temp_b0;
-        en_b = inv_cp * temp_b5 + inv_cp * temp_b4;
-        cp_b = cp_b + hp * temp_b;
+        const float g_temp_b = (2.f - hp) * temp1 * temp_b3;
+        const float g_temp_b0 = -sx_div(temp0 * temp1 * temp_b3, d3);
+        const float g_hp_b = hp_b + hp_imd_b + cp * g_temp_b - hp * cp * temp1 * temp_b3 - temp4 * g_temp_b0;
+        const float g_temp_b4 = (1.0f - the * the) * temp0 * temp_b3;
+        const float g_temp_b5 = (1.0f - the * the) * (1.f - hp) * g_temp_b0;
+        temp_b4 = we ? g_temp_b4 : temp0 * es_b;
+        temp_b5 = we ? g_temp_b5 : 0.f;
+        hp_b = we ? g_hp_b : hp_b + hp_imd_b;
+        en_b = we ? inv_cp * g_temp_b5 + inv_cp * g_temp_b4 : inv_cp * temp_b4;
+        cp_b = we ? cp_b + hp * g_temp_b : cp_b;
     } else {
         // tanh(en/cp) = 0: the general expressions reduce to these exactly (every dropped term is +-0)
         temp_b4 = temp0 * es_b;
@@ -213,18 +245,25 @@ SX_DEV void sx_production_b(const SxProd& R, float pn, float& pn_b, float en, fl
     }
     float temp_b2;
     const float temp2 = cp * (-(hp * hp) + 1.f);
-    if (pn > 0.f) {
-        const float temp = thp, temp1 = thp;
-        const SxDiv d0 = sx_mkdiv_fast(hp * temp + 1.f);
-        temp_b = sx_div(ps_b, d0);
-        temp_b0 = (1.0f - thp * thp) * temp2 * temp_b;
-        const float temp_b1 = -sx_div(temp2 * temp1 * temp_b, d0);
-        hp_b = hp_b + temp * temp_b1 - 2.f * hp * cp * temp1 * temp_b;
-        temp_b2 = (1.0f - thp * thp) * hp * temp_b1;
-        inv_cp_b = inv_cp_b + (ps - es) * hp_imd_b + en * temp_b5 + en * temp_b4 + pn * temp_b2 + pn * temp_b0;
-        cp_b = cp_b + (1.f - hp * hp) * temp1 * temp_b - sx_div(inv_cp_b, dcp2);
+    if (SX_ANY_B(wp)) {
+        if (wp) {
+            const float temp = thp, temp1 = thp;
+            const SxDiv d0 = sx_mkdiv_fast(hp * temp + 1.f);
+            temp_b = sx_div(ps_b, d0);
+            temp_b0 = (1.0f - thp * thp) * temp2 * temp_b;
+            const float temp_b1 = -sx_div(temp2 * temp1 * temp_b, d0);
+            hp_b = hp_b + temp * temp_b1 - 2.f * hp * cp * temp1 * temp_b;
+            temp_b2 = (1.0f - thp * thp) * hp * temp_b1;
+            inv_cp_b = inv_cp_b + (ps - es) * hp_imd_b + en * temp_b5 + en * temp_b4 + pn * temp_b2 + pn * temp_b0;
+            cp_b = cp_b + (1.f - hp * hp) * temp1 * temp_b - sx_div(inv_cp_b, dcp2);
+        } else {
+            // tanh(pn/cp) = 0 and pn = 0
+            temp_b0 = temp2 * ps_b;
+            temp_b2 = 0.f;
+            inv_cp_b = inv_cp_b + (ps - es) * hp_imd_b + en * temp_b5 + en * temp_b4;
+            cp_b = cp_b - sx_div(inv_cp_b, dcp2);
+        }
     } else {
-        // tanh(pn/cp) = 0 and pn = 0
         temp_b0 = temp2 * ps_b;
         temp_b2 = 0.f;
         inv_cp_b = inv_cp_b + (ps - es) * hp_imd_b + en * temp_b5 + en * temp_b4;
@@ -236,19 +275,19 @@ SX_DEV void sx_production_b(const SxProd& R, float pn, float& pn_b, float en, fl
 // ht = pre-step level
 SX_DEV void sx_transfer_b(float prcp, float pr, float& pr_b, float ct, const SxDiv& dct, const SxDiv& dct2, float ct_m4,
                           float ct_m5, float& ct_b, float ht, float& ht_b, float q_b) {
-    float pr_imd, g_pwx1 = 0.f, g_pwx3 = 0.f;
+    float pr_imd = pr, g_pwx1 = 0.f, g_pwx3 = 0.f;
     const bool gap = prcp < 0.f;
-    if (gap) {
-        g_pwx1 = ht * ct;
-        g_pwx3 = sx_pow_m4(g_pwx1) - ct_m4;
-        pr_imd = sx_pow_m025(g_pwx3) - ht * ct;
-    } else {
-        pr_imd = pr;
+    const bool any_gap = SX_ANY_G(gap);
+    if (any_gap) {
+        if (gap) {
+            g_pwx1 = ht * ct;
+            g_pwx3 = sx_pow_m4(g_pwx1) - ct_m4;
+            pr_imd = sx_pow_m025(g_pwx3) - ht * ct;
+        }
     }
-    float ht_imd;
-    bool br_max;
     const float ht_try = ht + sx_div(pr_imd, dct);
-    if (1.e-6f < ht_try) { ht_imd = ht_try; br_max = true; } else { ht_imd = 1.e-6f; br_max = false; }
+    const bool br_max = 1.e-6f < ht_try;
+    const float ht_imd = br_max ? ht_try : 1.e-6f;
     const float pwx1 = ht_imd * ct;
     float pwr1, pwx1_m5;
     sx_pow_m4_m5(pwx1, &pwr1, &pwx1_m5);
@@ -263,32 +302,28 @@ SX_DEV void sx_transfer_b(float prcp, float pr, float& pr_b, float ct, const SxD
     float pwx1_b = -4.f * pwx1_m5 * pwr1_b;           // pwy1*pwx1**(pwy1-1)*pwr1_b, pwy1 = -4
     const float ht_imd_b = ct * q_b + ct * pwx1_b;
     ct_b = ct_b + (ht_imd - ht_new) * q_b + -4.f * ct_m5 * pwr2_b - sx_div(pwr3 * htb, dct2) + ht_imd * pwx1_b;
-    float pr_imd_b;
-    if (br_max) {
-        htb = ht_imd_b;
-        pr_imd_b = sx_div(ht_imd_b, dct);
-        ct_b = ct_b - sx_div(pr_imd * ht_imd_b, dct2);
-    } else {
-        htb = 0.f;
-        pr_imd_b = 0.f;
-    }
-    if (!gap) {
-        pr_b = pr_imd_b;
-    } else {
-        pwr3_b = pr_imd_b;
-        // Tapenade guards pwx3 <= 0 with a non-integer exponent (forward_db.f90:6391-6395).  The two powers go through the same
-        // fixed-exponent helpers as everywhere else: the general sx_powf would park ~24 fp64 polynomial constants (48 registers) in
-        // the kernel for a branch that runs on 0.1 % of the steps, and cost the whole kernel a wave of occupancy
-        float g_m025, g_m125 = 0.f, g_m4, g_m5;
-        if (g_pwx3 > 0.f) sx_pow_m025_m125(g_pwx3, &g_m025, &g_m125);
-        sx_pow_m4_m5(g_pwx1, &g_m4, &g_m5);
-        pwx3_b = (g_pwx3 <= 0.f) ? 0.f : -0.25f * g_m125 * pwr3_b;
-        pwr1_b = pwx3_b;
-        pwr2_b = -pwx3_b;
-        pwx1_b = -4.f * g_m5 * pwr1_b;
-        htb = htb + ct * pwx1_b - ct * pr_imd_b;
-        ct_b = ct_b + -4.f * ct_m5 * pwr2_b - ht * pr_imd_b + ht * pwx1_b;
-        pr_b = 0.f;
+    // (1.e-6 < ht_try nearly always: both forms computed, the lane's own test selects)
+    const float pr_imd_b1 = sx_div(ht_imd_b, dct), ct_b1 = ct_b - sx_div(pr_imd * ht_imd_b, dct2);
+    htb = br_max ? ht_imd_b : 0.f;
+    const float pr_imd_b = br_max ? pr_imd_b1 : 0.f;
+    ct_b = br_max ? ct_b1 : ct_b;
+    pr_b = gap ? 0.f : pr_imd_b;
+    if (any_gap) {
+        if (gap) {
+            pwr3_b = pr_imd_b;
+            // Tapenade guards pwx3 <= 0 with a non-integer exponent (forward_db.f90:6391-6395).  The two powers go through the same
+            // fixed-exponent helpers as everywhere else: the general sx_powf would park ~24 fp64 polynomial constants (48 registers) in
+            // the kernel for a branch that runs on 0.1 % of the steps, and cost the whole kernel a wave of occupancy
+            float g_m025, g_m125 = 0.f, g_m4, g_m5;
+            if (g_pwx3 > 0.f) sx_pow_m025_m125(g_pwx3, &g_m025, &g_m125);
+            sx_pow_m4_m5(g_pwx1, &g_m4, &g_m5);
+            pwx3_b = (g_pwx3 <= 0.f) ? 0.f : -0.25f * g_m125 * pwr3_b;
+            pwr1_b = pwx3_b;
+            pwr2_b = -pwx3_b;
+            pwx1_b = -4.f * g_m5 * pwr1_b;
+            htb = htb + ct * pwx1_b - ct * pr_imd_b;
+            ct_b = ct_b + -4.f * ct_m5 * pwr2_b - ht * pr_imd_b + ht * pwx1_b;
+        }
     }
     ht_b = htb;
 }
