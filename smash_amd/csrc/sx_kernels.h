@@ -685,7 +685,11 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
     float a = 0.f, f = 0.f, den = 1.f, hlr = 0.f, ad = 0.f;
     bool hasup = false;
     // sub-levels of this wavefront's components (wave-uniform): the number of passes through a super-step's body
+#if defined(SX_ABL_ONE_SUBLEVEL)      // timing-only build: what the sub-level loop costs when every component is one level (the default schedule)
+    const int nsubw = 1;
+#else
     const int nsubw = __builtin_amdgcn_readfirstlane(m > 0 ? A.s_wsub[sb + min(j, m - 1)] : 1);
+#endif
     if (valid && A.s_cell[sb + j] == INT_MIN) valid = false;      // a hole of a partly filled wavefront
     if (valid) {
         const int c = A.s_cell[sb + j];
@@ -782,7 +786,7 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
                 const float4* row = sx_lds + (size_t)((w + 1 + (int)((e >> 15) & 1u)) & 1) * M;
                 return row[min((int)(e & 0x7fffu), M - 1)];
             };
-          for (int sl = 0; sl < nsubw; ++sl) {
+          auto sub_pass = [&](const int sl) {
             if (act && sub == sl) {
                 const int tl = tb * SX_BT;           // first step of the block, chunk-local
                 if (cell >= 0) {
@@ -860,10 +864,12 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
                     pub[j] = cur[u];
                 }
             }
+          };
+            // one level per component (the default schedule): the body once, no loop (route_adj 27.6 -> 26.5 ms at 1024^2 x 8760).  Else
             // the next sub-level of this wavefront reads what this one has just published: LDS operations of one wave complete in
             // order, the fence keeps the compiler from moving the reads up
-            if (sl + 1 < nsubw) sx_lds_wave_fence();
-          }
+            if (nsubw == 1) sub_pass(0);
+            else for (int sl = 0; sl < nsubw; ++sl) { sub_pass(sl); if (sl + 1 < nsubw) sx_lds_wave_fence(); }
             sx_lds_barrier();
             // every wave has passed this macro-step's vmcnt(0): what the roots (stage dmax) stored one macro-step
             // ago -- blocks below SX_MU (mw-1) - dmax -- has reached L2 and can be released
@@ -910,7 +916,11 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
     bool psame = false;                 // the parent sits in the same component (same wavefront, next sub-level up)
     float a = 0.f, f = 0.f, den = 1.f, lr = 1.f, hr_b = 0.f, lr_b = 0.f;
     bool hasup = false;
+#if defined(SX_ABL_ONE_SUBLEVEL)      // timing-only build: what the sub-level loop costs when every component is one level (the default schedule)
+    const int nsubw = 1;
+#else
     const int nsubw = __builtin_amdgcn_readfirstlane(m > 0 ? A.s_wsub[sb + min(j, m - 1)] : 1);
+#endif
     if (valid && A.s_cell[sb + j] == INT_MIN) valid = false;      // a hole of a partly filled wavefront
     if (valid) {
         const int c = A.s_cell[sb + j];
@@ -1015,7 +1025,7 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
             const bool act = valid && tbr >= 0 && tbr < nb;
             float4* pub = sx_lds + (size_t)(w & 1) * M;
             const float4* prev = sx_lds + (size_t)((w + 1) & 1) * M;
-          for (int sl = nsubw - 1; sl >= 0; --sl) {     // the reverse of the forward order: a component's top first
+          auto sub_pass = [&](const int sl) {
             if (act && sub == sl) {
                 const int tb = nb - 1 - tbr;
                 const int tl = tb * SX_BT;
@@ -1059,8 +1069,9 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
                     outq[u] = in4;
                 }
             }
-            if (sl > 0) sx_lds_wave_fence();
-          }
+          };
+            if (nsubw == 1) sub_pass(0);
+            else for (int sl = nsubw - 1; sl >= 0; --sl) { sub_pass(sl); if (sl > 0) sx_lds_wave_fence(); }     // the reverse of the forward order: a component's top first
             sx_lds_barrier();
             // inlet slots sit at reverse stage <= dmax: reverse blocks below SX_MU (mw-1) - dmax are complete
             if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0 && g != A.mute_group) sx_publish(A.prog + g, done); }
