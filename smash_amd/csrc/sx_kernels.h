@@ -444,12 +444,16 @@ __device__ __forceinline__ SxVicParams sx_vic_load(const SxDeviceArrays& A, int 
     SxVicParams P;
     P.b = A.ci[k]; P.cusl1 = A.cp[k]; P.cusl2 = A.cft[k]; P.clsl = A.cst[k]; P.ks = A.exc[k];
     P.ds = A.px[0][k]; P.dsm = A.px[1][k]; P.ws = A.px[2][k];
+    sx_vic_derive(P);
     return P;
 }
 // Same shape as the GR kernels: wave-uniform rows through buffer descriptors, forcing one step ahead (SxForcing), streaming stores
 // of the tapes, qt as one float4 per four steps; the reverse kernel prefetches the three taped levels and qt_b a step ahead.
+#ifndef SX_VFWD_WAVES_VIC
+#define SX_VFWD_WAVES_VIC 5       // taped (98-100 registers as compiled = 4 waves): asked for 5
+#endif
 template <bool TAPE, bool CF>
-__global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_vic(SxDeviceArrays A, int t0, int T) {
+__global__ __launch_bounds__(SX_VBLOCK, TAPE ? SX_VFWD_WAVES_VIC : 1) void sx_k_vert_fwd_vic(SxDeviceArrays A, int t0, int T) {
     SX_LIBM_INIT();      // exact-libm build: the tables of expf / logf / powf into LDS (sx_libm.h); nothing otherwise
     const int k = A.k0 + blockIdx.x * SX_VBLOCK + threadIdx.x;   // the vertical kernels can be launched on a cell range
     if (k >= A.k1) return;

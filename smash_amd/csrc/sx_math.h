@@ -243,14 +243,20 @@ SX_HD float sx_expf(float x) { return (float)exp((double)x); }
 struct SxLog2 { double l2; int special; };   // special: 0 = finite x > 0, 1 = x == 0, 2 = x < 0 or NaN, 3 = +inf
 SX_HD SxLog2 sx_log2_d(float x) {
     SxLog2 R; R.special = 0; R.l2 = 0.0;
-    if (!(x > 0.f)) { R.special = (x == 0.f) ? 1 : 2; return R; }
     uint32_t u = sx_f2u(x);
-    if (u >= 0x7f800000u) { R.special = 3; return R; }
     int e = 0;
-    if (u < 0x00800000u) { u = sx_f2u(x * 16777216.0f); e = -24; }      // subnormal
+#if defined(__HIP_DEVICE_COMPILE__) && SX_TANH_FAST
+    // every lane a positive normal number (always, for the bases the model raises): no branch at all -- the same operations
+    if (__builtin_amdgcn_ballot_w64(!(u - 0x00800000u < 0x7f000000u)) != 0ull)
+#endif
+    {
+        if (!(x > 0.f)) { R.special = (x == 0.f) ? 1 : 2; return R; }
+        if (u >= 0x7f800000u) { R.special = 3; return R; }
+        if (u < 0x00800000u) { u = sx_f2u(x * 16777216.0f); e = -24; }      // subnormal
+    }
     e += (int)(u >> 23) - 127;
     float m = sx_u2f((u & 0x007fffffu) | 0x3f800000u);                  // [1, 2)
-    if (m > 1.41421356f) { m *= 0.5f; e += 1; }                          // [sqrt(1/2), sqrt 2)
+    { const bool up = m > 1.41421356f; m = up ? m * 0.5f : m; e = up ? e + 1 : e; }   // [sqrt(1/2), sqrt 2)
     const double f = (double)m - 1.0;                                    // exact
     const double d = 2.0 + f;
     double r = (double)sx_seed_rcp((float)d);
@@ -266,8 +272,8 @@ SX_HD SxLog2 sx_log2_d(float x) {
 }
 // 2^t for |t| < 1100 (beyond: the ldexp saturates to 0 / inf)
 SX_HD double sx_exp2_d(double t) {
-    if (!(t > -1100.0)) t = -1100.0;
-    if (!(t < 1100.0)) t = 1100.0;
+    t = !(t > -1100.0) ? -1100.0 : t;
+    t = !(t < 1100.0) ? 1100.0 : t;
     const double n = rint(t);
     const double u = (t - n) * 0.6931471805599453;                        // r ln 2, |u| <= 0.3466
     double p = 2.505210838544172e-08;                                     // 1/11!
@@ -284,6 +290,10 @@ SX_HD float sx_logf(float x) {
 }
 // x^y given log2 x (several powers of one base share the logarithm: the vic-a adjoints need x^y, x^(y-1) and ln x)
 SX_HD float sx_pow_from(const SxLog2& L, float x, float y) {
+#if defined(__HIP_DEVICE_COMPILE__) && SX_TANH_FAST
+    // the ordinary case on every lane of the wavefront: straight to the exponential
+    if (__builtin_amdgcn_ballot_w64(L.special != 0 || y == 0.f || x == 1.f) == 0ull) return (float)sx_exp2_d((double)y * L.l2);
+#endif
     if (y == 0.f || x == 1.f) return 1.f;
     if (L.special == 1) return y > 0.f ? 0.f : sx_inff();
     if (L.special == 3) return y > 0.f ? sx_inff() : 0.f;

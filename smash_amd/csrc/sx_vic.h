@@ -17,11 +17,22 @@
 #define SX_DEV __device__ __forceinline__
 #endif
 
-struct SxVicParams { float b, cusl1, cusl2, clsl, ks, ds, dsm, ws; };
+struct SxVicParams {
+    float b, cusl1, cusl2, clsl, ks, ds, dsm, ws;
+    float qs, rdw, tw;      // per-cell invariants of vic_baseflow, set by sx_vic_derive: (ds dsm) / ws, ds / ws, dsm / (1 - ws)
+    SxDiv d1, d2, dl, d11, d22, dll;   // exact division by cusl1, cusl2, clsl and their squares (sx_div: 3 operations instead of 6)
+};
+SX_DEV void sx_vic_derive(SxVicParams& P) {
+    P.qs = sx_fdiv((P.ds * P.dsm), P.ws);
+    P.rdw = sx_fdiv(P.ds, P.ws);
+    P.tw = sx_fdiv(P.dsm, -P.ws + 1.f);
+    P.d1 = sx_mkdiv(P.cusl1); P.d2 = sx_mkdiv(P.cusl2); P.dl = sx_mkdiv(P.clsl);
+    P.d11 = sx_mkdiv(P.cusl1 * P.cusl1); P.d22 = sx_mkdiv(P.cusl2 * P.cusl2); P.dll = sx_mkdiv(P.clsl * P.clsl);
+}
 struct SxVicGrads { float b_b, cusl1_b, cusl2_b, clsl_b, ks_b, ds_b, dsm_b, ws_b, husl1_b, husl2_b, hlsl_b; };
 
 // ---------------------------------------------------------------- forward
-SX_DEV void sx_vic_infiltration(float prcp, float cusl1, float cusl2, float b, float& husl1, float& husl2, float& runoff) {
+SX_DEV void sx_vic_infiltration(const SxVicParams& P, float prcp, float cusl1, float cusl2, float b, float& husl1, float& husl2, float& runoff) {
     const float bp1 = b + 1.f;
     float ifl;
     if (prcp <= 0.f) ifl = 0.f;
@@ -40,14 +51,14 @@ SX_DEV void sx_vic_infiltration(float prcp, float cusl1, float cusl2, float b, f
     ifl = ifl - ifl_usl1;
     const float ifl_usl2 = fminf((1.f - husl2) * cusl2, ifl);
     ifl = ifl - ifl_usl2;
-    husl1 = husl1 + sx_fdiv(ifl_usl1, cusl1);
-    husl2 = husl2 + sx_fdiv(ifl_usl2, cusl2);
+    husl1 = husl1 + sx_div(ifl_usl1, P.d1);
+    husl2 = husl2 + sx_div(ifl_usl2, P.d2);
     runoff = prcp - (ifl_usl1 + ifl_usl2);
 }
 
 // residual = 0, porosity = 1, lambda = 1 at both call sites (md_vic_operator.f90:94,99): pwx1 = h_upper / 1, pwx1**1 = pwx1
 SX_DEV float sx_brooks_corey(float ks, float c_upper, float c_lower, float h_upper, float h_lower) {
-    const float flow = ks * (sx_fdiv((h_upper - 0.f), 1.f - 0.f));
+    const float flow = ks * (h_upper - 0.f);           // (h_upper - residual) / (porosity - residual): x / 1 is x
     const float w_upper = h_upper * c_upper * 1.f;
     const float w_lower = h_lower * c_lower * 1.f;
     const float max_flow = fminf(w_upper, c_lower - w_lower);
@@ -55,36 +66,37 @@ SX_DEV float sx_brooks_corey(float ks, float c_upper, float c_lower, float h_upp
 }
 SX_DEV float sx_linear_evap(float e, float c, float h) { return fminf(c * h, e * h); }
 
-SX_DEV void sx_vic_vertical_transfer(float pet, float cusl1, float cusl2, float clsl, float ks, float& husl1, float& husl2, float& hlsl) {
+SX_DEV void sx_vic_vertical_transfer(const SxVicParams& P, float pet, float cusl1, float cusl2, float clsl, float ks, float& husl1, float& husl2, float& hlsl) {
     float fbc = sx_brooks_corey(ks, cusl1, cusl2, husl1, husl2);
-    husl1 = husl1 - sx_fdiv(fbc, cusl1);
-    husl2 = husl2 + sx_fdiv(fbc, cusl2);
+    husl1 = husl1 - sx_div(fbc, P.d1);
+    husl2 = husl2 + sx_div(fbc, P.d2);
     fbc = sx_brooks_corey(ks, cusl2, clsl, husl2, hlsl);
-    husl2 = husl2 - sx_fdiv(fbc, cusl2);
-    hlsl = hlsl + sx_fdiv(fbc, clsl);
+    husl2 = husl2 - sx_div(fbc, P.d2);
+    hlsl = hlsl + sx_div(fbc, P.dl);
     float fe = sx_linear_evap(pet, cusl1, husl1);
-    husl1 = husl1 - sx_fdiv(fe, cusl1);
+    husl1 = husl1 - sx_div(fe, P.d1);
     float pet_remain = fmaxf(0.f, pet - fe);
     fe = sx_linear_evap(pet_remain, cusl2, husl2);
-    husl2 = husl2 - sx_fdiv(fe, cusl2);
+    husl2 = husl2 - sx_div(fe, P.d2);
     pet_remain = fmaxf(0.f, pet_remain - fe);
     fe = sx_linear_evap(pet_remain, clsl, hlsl);
-    hlsl = hlsl - sx_fdiv(fe, clsl);
+    hlsl = hlsl - sx_div(fe, P.dl);
 }
 
-SX_DEV void sx_vic_interflow(float cusl2, float cusl2_m4, float& husl2, float& qi) {   // n = 5
+SX_DEV void sx_vic_interflow(const SxVicParams& P, float cusl2, float cusl2_m4, float& husl2, float& qi) {   // n = 5
     const float husl2_imd = husl2;
-    husl2 = sx_fdiv(sx_pow_m025(sx_pow_m4(husl2_imd * cusl2) + cusl2_m4), cusl2);
+    husl2 = sx_div(sx_pow_m025(sx_pow_m4(husl2_imd * cusl2) + cusl2_m4), P.d2);
     qi = (husl2_imd - husl2) * cusl2;
 }
 
-SX_DEV void sx_vic_baseflow(float clsl, float ds, float dsm, float ws, float& hlsl, float& qb) {
+SX_DEV void sx_vic_baseflow(const SxVicParams& P, float& hlsl, float& qb) {
+    const float clsl = P.clsl, dsm = P.dsm, ws = P.ws;
     float q;
-    if (hlsl <= ws) q = sx_fdiv((ds * dsm), ws) * hlsl;
-    else q = sx_fdiv(dsm * (1.f - sx_fdiv(ds, ws)) * (hlsl - ws), 1.f - ws);
+    if (hlsl <= ws) q = P.qs * hlsl;
+    else q = sx_fdiv(dsm * (1.f - P.rdw) * (hlsl - ws), 1.f - ws);
     const float wlsl = clsl * hlsl;
     q = fminf(wlsl, q);
-    hlsl = hlsl - sx_fdiv(q, clsl);
+    hlsl = hlsl - sx_div(q, P.dl);
     qb = q;
 }
 
@@ -92,11 +104,11 @@ SX_DEV void sx_vic_baseflow(float clsl, float ds, float dsm, float ws, float& hl
 SX_DEV float sx_vic_step(const SxVicParams& P, float cusl2_m4, float prcp, float pet, float& husl1, float& husl2, float& hlsl) {
     float runoff = 0.f, qi, qb;
     if (prcp >= 0.f && pet >= 0.f) {
-        sx_vic_infiltration(prcp, P.cusl1, P.cusl2, P.b, husl1, husl2, runoff);
-        sx_vic_vertical_transfer(pet, P.cusl1, P.cusl2, P.clsl, P.ks, husl1, husl2, hlsl);
+        sx_vic_infiltration(P, prcp, P.cusl1, P.cusl2, P.b, husl1, husl2, runoff);
+        sx_vic_vertical_transfer(P, pet, P.cusl1, P.cusl2, P.clsl, P.ks, husl1, husl2, hlsl);
     }
-    sx_vic_interflow(P.cusl2, cusl2_m4, husl2, qi);
-    sx_vic_baseflow(P.clsl, P.ds, P.dsm, P.ws, hlsl, qb);
+    sx_vic_interflow(P, P.cusl2, cusl2_m4, husl2, qi);
+    sx_vic_baseflow(P, hlsl, qb);
     return (runoff + qi + qb);
 }
 
@@ -106,7 +118,7 @@ SX_DEV float sx_pow_guard_b(float x, float y, float r_b) {
     return y * sx_powf(x, y - 1.f) * r_b;
 }
 
-SX_DEV void sx_vic_infiltration_b(float prcp, float cusl1, float cusl2, float b, float husl1, float husl2, float runoff_b, SxVicGrads& G) {
+SX_DEV void sx_vic_infiltration_b(const SxVicParams& P, float prcp, float cusl1, float cusl2, float b, float husl1, float husl2, float runoff_b, SxVicGrads& G) {
     float bp1 = b + 1.f, ifl, cusl = 0.f, wusl = 0.f, iflm = 0.f, iflc = 0.f, pwx1 = 0.f, pwy1 = 0.f, pwr1 = 0.f, pwr1_first = 0.f;
     int c_prcp, c_w1 = 0, c_w2 = 0, c_full = 0, c_min;
     SxPowBase B1 = sx_powbase(1.f), B2 = B1;
@@ -139,10 +151,10 @@ SX_DEV void sx_vic_infiltration_b(float prcp, float cusl1, float cusl2, float b,
     if ((1.f - husl1) * cusl1 > ifl) { ifl_usl1 = ifl; c_u1 = 0; } else { ifl_usl1 = (1.f - husl1) * cusl1; c_u1 = 1; }
     ifl = ifl - ifl_usl1;
     if ((1.f - husl2) * cusl2 > ifl) { ifl_usl2 = ifl; c_u2 = 0; } else { ifl_usl2 = (1.f - husl2) * cusl2; c_u2 = 1; }
-    float ifl_usl1_b = sx_fdiv(G.husl1_b, cusl1) - runoff_b;
-    float ifl_usl2_b = sx_fdiv(G.husl2_b, cusl2) - runoff_b;
-    G.cusl2_b = G.cusl2_b - sx_fdiv(ifl_usl2 * G.husl2_b, cusl2 * cusl2);
-    G.cusl1_b = G.cusl1_b - sx_fdiv(ifl_usl1 * G.husl1_b, cusl1 * cusl1);
+    float ifl_usl1_b = sx_div(G.husl1_b, P.d1) - runoff_b;
+    float ifl_usl2_b = sx_div(G.husl2_b, P.d2) - runoff_b;
+    G.cusl2_b = G.cusl2_b - sx_div(ifl_usl2 * G.husl2_b, P.d22);
+    G.cusl1_b = G.cusl1_b - sx_div(ifl_usl1 * G.husl1_b, P.d11);
     float ifl_b;
     if (c_u2 == 0) ifl_b = ifl_usl2_b;
     else {
@@ -203,7 +215,7 @@ SX_DEV void sx_vic_infiltration_b(float prcp, float cusl1, float cusl2, float b,
 // residual = 0, porosity = 1, lambda = 1: pwr1 = pwx1, d(pwx1**1) = pwr1_b
 SX_DEV void sx_brooks_corey_b(float ks, float& ks_b, float c_upper, float& c_upper_b, float c_lower, float& c_lower_b, float h_upper,
                               float& h_upper_b, float h_lower, float& h_lower_b, float flow_b) {
-    const float pwx1 = sx_fdiv((h_upper - 0.f), 1.f - 0.f);
+    const float pwx1 = (h_upper - 0.f);                // / (1 - 0): x / 1 is x
     const float pwr1 = pwx1;
     const float flow = ks * pwr1;
     const float w_upper = h_upper * c_upper * 1.f;
@@ -219,7 +231,7 @@ SX_DEV void sx_brooks_corey_b(float ks, float& ks_b, float c_upper, float& c_upp
     const float pwx1_b = 1.f * 1.f * pwr1_b;          // lambda * pwx1**(lambda - 1) * pwr1_b
     h_lower_b = h_lower_b + c_lower * 1.f * w_lower_b;
     c_lower_b = c_lower_b + h_lower * 1.f * w_lower_b;
-    h_upper_b = h_upper_b + c_upper * 1.f * w_upper_b + sx_fdiv(pwx1_b, 1.f - 0.f);
+    h_upper_b = h_upper_b + c_upper * 1.f * w_upper_b + pwx1_b;
     c_upper_b = c_upper_b + h_upper * 1.f * w_upper_b;
     ks_b = ks_b + pwr1 * flow_b;
 }
@@ -235,16 +247,16 @@ SX_DEV void sx_linear_evap_b(float e, float& e_b, float c, float& c_b, float h, 
 }
 
 // husl1, husl2, hlsl: the levels on entry of vic_vertical_transfer
-SX_DEV void sx_vic_vertical_transfer_b(float pet, float cusl1, float cusl2, float clsl, float ks, float husl1, float husl2, float hlsl,
+SX_DEV void sx_vic_vertical_transfer_b(const SxVicParams& P, float pet, float cusl1, float cusl2, float clsl, float ks, float husl1, float husl2, float hlsl,
                                        SxVicGrads& G) {
     const float h1_0 = husl1, h2_0 = husl2;
     const float fbc1 = sx_brooks_corey(ks, cusl1, cusl2, husl1, husl2);
-    husl1 = husl1 - sx_fdiv(fbc1, cusl1);
-    husl2 = husl2 + sx_fdiv(fbc1, cusl2);
+    husl1 = husl1 - sx_div(fbc1, P.d1);
+    husl2 = husl2 + sx_div(fbc1, P.d2);
     const float h2_1 = husl2, hl_1 = hlsl;
     const float fbc2 = sx_brooks_corey(ks, cusl2, clsl, husl2, hlsl);
-    husl2 = husl2 - sx_fdiv(fbc2, cusl2);
-    hlsl = hlsl + sx_fdiv(fbc2, clsl);
+    husl2 = husl2 - sx_div(fbc2, P.d2);
+    hlsl = hlsl + sx_div(fbc2, P.dl);
     const float h1_2 = husl1, h2_2 = husl2, hl_2 = hlsl;
     const float fe1 = sx_linear_evap(pet, cusl1, husl1);
     float pet_remain1, pet_remain2;
@@ -253,33 +265,33 @@ SX_DEV void sx_vic_vertical_transfer_b(float pet, float cusl1, float cusl2, floa
     const float fe2 = sx_linear_evap(pet_remain1, cusl2, h2_2);
     if (0.f < pet_remain1 - fe2) { pet_remain2 = pet_remain1 - fe2; br2 = 0; } else { pet_remain2 = 0.f; br2 = 1; }
     const float fe3 = sx_linear_evap(pet_remain2, clsl, hl_2);
-    float fe_b = -(sx_fdiv(G.hlsl_b, clsl));
-    G.clsl_b = G.clsl_b + sx_fdiv(fe3 * G.hlsl_b, clsl * clsl);
+    float fe_b = -(sx_div(G.hlsl_b, P.dl));
+    G.clsl_b = G.clsl_b + sx_div(fe3 * G.hlsl_b, P.dll);
     float pet_remain_b = 0.f;
     sx_linear_evap_b(pet_remain2, pet_remain_b, clsl, G.clsl_b, hl_2, G.hlsl_b, fe_b);
     if (br2 == 0) fe_b = -pet_remain_b;
     else { pet_remain_b = 0.f; fe_b = 0.f; }
-    fe_b = fe_b - sx_fdiv(G.husl2_b, cusl2);
-    G.cusl2_b = G.cusl2_b + sx_fdiv(fe2 * G.husl2_b, cusl2 * cusl2);
+    fe_b = fe_b - sx_div(G.husl2_b, P.d2);
+    G.cusl2_b = G.cusl2_b + sx_div(fe2 * G.husl2_b, P.d22);
     sx_linear_evap_b(pet_remain1, pet_remain_b, cusl2, G.cusl2_b, h2_2, G.husl2_b, fe_b);
     if (br1 == 0) fe_b = -pet_remain_b;
     else fe_b = 0.f;
-    fe_b = fe_b - sx_fdiv(G.husl1_b, cusl1);
-    G.cusl1_b = G.cusl1_b + sx_fdiv(fe1 * G.husl1_b, cusl1 * cusl1);
+    fe_b = fe_b - sx_div(G.husl1_b, P.d1);
+    G.cusl1_b = G.cusl1_b + sx_div(fe1 * G.husl1_b, P.d11);
     float pet_b = 0.f;
     sx_linear_evap_b(pet, pet_b, cusl1, G.cusl1_b, h1_2, G.husl1_b, fe_b);
-    float fbc_b = sx_fdiv(G.hlsl_b, clsl) - sx_fdiv(G.husl2_b, cusl2);
-    G.clsl_b = G.clsl_b - sx_fdiv(fbc2 * G.hlsl_b, clsl * clsl);
-    G.cusl2_b = G.cusl2_b + sx_fdiv(fbc2 * G.husl2_b, cusl2 * cusl2);
+    float fbc_b = sx_div(G.hlsl_b, P.dl) - sx_div(G.husl2_b, P.d2);
+    G.clsl_b = G.clsl_b - sx_div(fbc2 * G.hlsl_b, P.dll);
+    G.cusl2_b = G.cusl2_b + sx_div(fbc2 * G.husl2_b, P.d22);
     sx_brooks_corey_b(ks, G.ks_b, cusl2, G.cusl2_b, clsl, G.clsl_b, h2_1, G.husl2_b, hl_1, G.hlsl_b, fbc_b);
-    fbc_b = sx_fdiv(G.husl2_b, cusl2) - sx_fdiv(G.husl1_b, cusl1);
-    G.cusl2_b = G.cusl2_b - sx_fdiv(fbc1 * G.husl2_b, cusl2 * cusl2);
-    G.cusl1_b = G.cusl1_b + sx_fdiv(fbc1 * G.husl1_b, cusl1 * cusl1);
+    fbc_b = sx_div(G.husl2_b, P.d2) - sx_div(G.husl1_b, P.d1);
+    G.cusl2_b = G.cusl2_b - sx_div(fbc1 * G.husl2_b, P.d22);
+    G.cusl1_b = G.cusl1_b + sx_div(fbc1 * G.husl1_b, P.d11);
     sx_brooks_corey_b(ks, G.ks_b, cusl1, G.cusl1_b, cusl2, G.cusl2_b, h1_0, G.husl1_b, h2_0, G.husl2_b, fbc_b);
 }
 
 // husl2: level on entry; n = 5
-SX_DEV void sx_vic_interflow_b(float cusl2, float cusl2_m4, float cusl2_m5, float husl2, float qi_b, SxVicGrads& G) {
+SX_DEV void sx_vic_interflow_b(const SxVicParams& P, float cusl2, float cusl2_m4, float cusl2_m5, float husl2, float qi_b, SxVicGrads& G) {
     const float husl2_imd = husl2;
     const float pwx1 = husl2_imd * cusl2;
     float pwr1, pwx1_m5;
@@ -287,36 +299,37 @@ SX_DEV void sx_vic_interflow_b(float cusl2, float cusl2_m4, float cusl2_m5, floa
     const float pwx3 = pwr1 + cusl2_m4;
     float pwr3, pwx3_m125;
     sx_pow_m025_m125(pwx3, &pwr3, &pwx3_m125);
-    const float husl2_new = sx_fdiv(pwr3, cusl2);
+    const float husl2_new = sx_div(pwr3, P.d2);
     const float hb = G.husl2_b - cusl2 * qi_b;
-    const float pwr3_b = sx_fdiv(hb, cusl2);
+    const float pwr3_b = sx_div(hb, P.d2);
     const float pwx3_b = (pwx3 <= 0.f) ? 0.f : -0.25f * pwx3_m125 * pwr3_b;
     const float pwr1_b = pwx3_b, pwr2_b = pwx3_b;
     const float pwx1_b = -4.f * pwx1_m5 * pwr1_b;
     const float husl2_imd_b = cusl2 * qi_b + cusl2 * pwx1_b;
-    G.cusl2_b = G.cusl2_b + (husl2_imd - husl2_new) * qi_b + -4.f * cusl2_m5 * pwr2_b - sx_fdiv(pwr3 * hb, cusl2 * cusl2) + husl2_imd * pwx1_b;
+    G.cusl2_b = G.cusl2_b + (husl2_imd - husl2_new) * qi_b + -4.f * cusl2_m5 * pwr2_b - sx_div(pwr3 * hb, P.d22) + husl2_imd * pwx1_b;
     G.husl2_b = husl2_imd_b;
 }
 
 // hlsl: level on entry
-SX_DEV void sx_vic_baseflow_b(float clsl, float ds, float dsm, float ws, float hlsl, float qb_b, SxVicGrads& G) {
+SX_DEV void sx_vic_baseflow_b(const SxVicParams& P, float hlsl, float qb_b, SxVicGrads& G) {
+    const float clsl = P.clsl, ds = P.ds, dsm = P.dsm, ws = P.ws;
     float qb;
     int br1, br2;
-    if (hlsl <= ws) { qb = sx_fdiv(ds * dsm, ws) * hlsl; br1 = 1; }
-    else { qb = sx_fdiv(dsm * (1.f - sx_fdiv(ds, ws)) * (hlsl - ws), 1.f - ws); br1 = 0; }
+    if (hlsl <= ws) { qb = P.qs * hlsl; br1 = 1; }
+    else { qb = sx_fdiv(dsm * (1.f - P.rdw) * (hlsl - ws), 1.f - ws); br1 = 0; }
     const float wlsl = clsl * hlsl;
     if (wlsl > qb) br2 = 0; else { qb = wlsl; br2 = 1; }
-    qb_b = qb_b - sx_fdiv(G.hlsl_b, clsl);
-    G.clsl_b = G.clsl_b + sx_fdiv(qb * G.hlsl_b, clsl * clsl);
+    qb_b = qb_b - sx_div(G.hlsl_b, P.dl);
+    G.clsl_b = G.clsl_b + sx_div(qb * G.hlsl_b, P.dll);
     float wlsl_b;
     if (br2 == 0) wlsl_b = 0.f;
     else { wlsl_b = qb_b; qb_b = 0.f; }
     G.clsl_b = G.clsl_b + hlsl * wlsl_b;
     G.hlsl_b = G.hlsl_b + clsl * wlsl_b;
     if (br1 == 0) {
-        const float temp = sx_fdiv(dsm, -ws + 1.f);
+        const float temp = P.tw;
         const float temp_b0 = -(sx_fdiv((hlsl - ws) * temp * qb_b, ws));
-        const float temp_b1 = (1.f - sx_fdiv(ds, ws)) * qb_b;
+        const float temp_b1 = (1.f - P.rdw) * qb_b;
         G.hlsl_b = G.hlsl_b + temp * temp_b1;
         const float temp_b = sx_fdiv((hlsl - ws) * temp_b1, 1.f - ws);
         G.ws_b = G.ws_b + temp * temp_b - temp * temp_b1 - sx_fdiv(ds * temp_b0, ws);
@@ -339,15 +352,15 @@ SX_DEV void sx_vic_step_b(const SxVicParams& P, float cusl2_m4, float cusl2_m5, 
     float h1 = husl1, h2 = husl2, hl = hlsl, runoff = 0.f;
     float h1_1 = h1, h2_1 = h2;
     if (wet) {
-        sx_vic_infiltration(prcp, P.cusl1, P.cusl2, P.b, h1, h2, runoff);
+        sx_vic_infiltration(P, prcp, P.cusl1, P.cusl2, P.b, h1, h2, runoff);
         h1_1 = h1; h2_1 = h2;
-        sx_vic_vertical_transfer(pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1, h2, hl);
+        sx_vic_vertical_transfer(P, pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1, h2, hl);
     }
-    sx_vic_baseflow_b(P.clsl, P.ds, P.dsm, P.ws, hl, qt_b, G);
-    sx_vic_interflow_b(P.cusl2, cusl2_m4, cusl2_m5, h2, qt_b, G);
+    sx_vic_baseflow_b(P, hl, qt_b, G);
+    sx_vic_interflow_b(P, P.cusl2, cusl2_m4, cusl2_m5, h2, qt_b, G);
     if (wet) {
-        sx_vic_vertical_transfer_b(pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1_1, h2_1, hlsl, G);
-        sx_vic_infiltration_b(prcp, P.cusl1, P.cusl2, P.b, husl1, husl2, qt_b, G);
+        sx_vic_vertical_transfer_b(P, pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1_1, h2_1, hlsl, G);
+        sx_vic_infiltration_b(P, prcp, P.cusl1, P.cusl2, P.b, husl1, husl2, qt_b, G);
     }
 }
 

@@ -9,7 +9,7 @@ for k in "$@"; do
   export SMASHX_LIB=$lib
   rm -rf /tmp/pv_$k
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU \
-      --output-format csv -d /tmp/pv_$k -- python3 bench.py --profile --grid 1024 --steps 1 --warmup 0 > gpurun_out/pv_$k.log 2>&1 || { echo "$k failed"; tail -3 gpurun_out/pv_$k.log; exit 1; }
+      --output-format csv -d /tmp/pv_$k -- python3 bench.py --profile --grid 1024 --steps 1 --warmup 0 ${PV_ARGS:-} > gpurun_out/pv_$k.log 2>&1 || { echo "$k failed"; tail -3 gpurun_out/pv_$k.log; exit 1; }
   python3 - "$k" <<'PY'
 import csv, glob, sys, collections
 k = sys.argv[1]
