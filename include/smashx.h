@@ -292,6 +292,12 @@ int smashx_debug_group_times(smashx_plan* plan, long long* out, int* round_of_gr
  * those, off by more than one ulp. */
 int smashx_selftest_math(int device, long long n, unsigned seed, float blo, float bhi, long long* out);
 
+/* Device self-test of the per-wavefront straight-line paths of sx_math.h (sx_tanhf for small arguments, the base-2 logarithm and the
+ * power for ordinary operands) against the branchy forms they shortcut, on n pseudo-random arguments, a wavefront at a time uniform
+ * (the fast path runs) or mixed with special operands (it must not): out[0] = tanh results that differ, out[1] = powers that differ.
+ * Both must be 0: the paths execute the same operations. */
+int smashx_selftest_paths(int device, long long n, unsigned seed, long long* out);
+
 /* ---- L-BFGS-B, the optimiser of the variational calibration (reference: lbfgsb.f driven by optimize_lbfgsb,
  * smash/solver/optimize/mw_optimize.f90:484-676: m = 10, factr, pgtol, bounds of the normalised control, reverse communication).
  * A from-the-paper implementation (Byrd-Lu-Nocedal-Zhu 1995, Morales-Nocedal 2011, More'-Thuente line search; smash_amd/csrc/

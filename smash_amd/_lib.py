@@ -23,7 +23,7 @@ SYMBOLS = [
     "smashx_set_forcing_layout", "smashx_forcing_info", "smashx_control_size", "smashx_control_set", "smashx_control_get",
     "smashx_control_gradient",
     "smashx_comm_unique_id", "smashx_comm_create", "smashx_comm_destroy", "smashx_comm_allreduce_sum", "smashx_set_exchange",
-    "smashx_set_median_slots",
+    "smashx_set_median_slots", "smashx_selftest_paths",
     "smashx_lbfgsb_create", "smashx_lbfgsb_step", "smashx_lbfgsb_destroy", "smashx_lbfgsb_iterations", "smashx_lbfgsb_message",
 ]
 

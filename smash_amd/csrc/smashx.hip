@@ -217,6 +217,38 @@ __global__ void k_selftest_div(unsigned long long n, unsigned seed, float blo, f
     if (bad2) atomicAdd(out + 1, bad2);
 }
 
+// self-test of the per-wavefront straight-line paths of sx_math.h against the branchy forms they shortcut: out[0] = tanh results that
+// differ (arguments a wavefront at a time: all small -> the fast path runs; every 7th wavefront mixed with large ones -> it must
+// not), out[1] = x^y results that differ (positive normal bases, ordinary exponents; every 7th wavefront mixed with 0, 1, inf, < 0)
+__global__ void k_selftest_paths(unsigned long long n, unsigned seed, unsigned long long* out) {
+    unsigned long long bad_t = 0, bad_p = 0;
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long h = (i + 1) * 0x9E3779B97F4A7C15ull + seed;
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; h *= 0x94D049BB133111EBull; h ^= h >> 29;
+        const bool mixed = ((i >> 6) % 7ull) == 6ull;                    // wave-uniform
+        const unsigned m1 = (unsigned)h & 0x7fffffu, m2 = (unsigned)(h >> 23) & 0x7fffffu;
+        // tanh argument: 2^[-70, -3) x [1, 2), either sign (|x| < ln2 / 4 = 0.173); mixed wavefronts: up to 2^5
+        const int e1 = (int)((h >> 46) % (mixed ? 75u : 67u)) - 70;
+        float x = ldexpf(__uint_as_float(0x3f800000u | m1), e1);
+        if ((h >> 63) & 1) x = -x;
+        if ((h >> 60) % 97ull == 0) x = 0.f;
+        if (__float_as_uint(sx_tanhf(x, true)) != __float_as_uint(sx_tanhf(x, false))) ++bad_t;
+        // power: base 2^[-30, 30) x [1, 2), exponent in (-6, 6)
+        const int e2 = (int)((h >> 52) % 60u) - 30;
+        float b = ldexpf(__uint_as_float(0x3f800000u | m2), e2);
+        float y = ((float)(m1 >> 3) * (1.0f / 1048576.0f) - 0.5f) * 12.0f;
+        if (mixed) { const unsigned k = (unsigned)(h >> 40) & 7u; if (k == 0) b = 0.f; else if (k == 1) b = 1.f; else if (k == 2) b = sx_inff(); else if (k == 3) b = -b; else if (k == 4) y = 0.f; else if (k == 5) b = 1e-41f; }
+#if !SX_EXACT_LIBM      // (the exact-libm build raises powers through glibc's own algorithm: no such path)
+        const float pf = sx_pow_from(sx_log2_d(b, true), b, y, true), pg = sx_pow_from(sx_log2_d(b, false), b, y, false);
+        if (__float_as_uint(pf) != __float_as_uint(pg) && !(pf != pf && pg != pg)) ++bad_p;
+#else
+        (void)b; (void)y;
+#endif
+    }
+    if (bad_t) atomicAdd(out, bad_t);
+    if (bad_p) atomicAdd(out + 1, bad_p);
+}
+
 // whole-domain outputs: T4 chunk buffer -> planes of `plane` floats per time step, cell k at idx[k]
 __global__ void k_domain_export(float* stage, const float* src4, const int* idx, int n, int npad, long plane, int tl0, int nb) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1760,6 +1792,21 @@ int smashx_selftest_math(int device, long long n, unsigned seed, float blo, floa
     HIPCHK(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
     HIPCHK(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(k_selftest_div, dim3(2048), dim3(256), 0, 0, (unsigned long long)n, seed, blo, bhi, d);
+    unsigned long long h[2] = {0, 0};
+    hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(SMASHX_E_HIP, hipGetErrorString(e));
+    out[0] = (long long)h[0]; out[1] = (long long)h[1];
+    return 0;
+}
+
+int smashx_selftest_paths(int device, long long n, unsigned seed, long long* out) {
+    if (!out || n <= 0) return fail(SMASHX_E_ARG, "bad argument");
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_selftest_paths, dim3(2048), dim3(256), 0, 0, (unsigned long long)n, seed, d);
     unsigned long long h[2] = {0, 0};
     hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     (void)hipFree(d);

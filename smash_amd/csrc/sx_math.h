@@ -241,13 +241,13 @@ SX_HD float sx_expf(float x) { return (float)exp((double)x); }
 // x^y = 2^(y log2 x) with 2^t = 2^n exp(r ln 2), r = t - n in [-1/2, 1/2].   tests/test_sx_math.py checks both against the
 // double-precision library on a few million arguments (|error| < 2^-44 relative) and the fp32 results against glibc's.
 struct SxLog2 { double l2; int special; };   // special: 0 = finite x > 0, 1 = x == 0, 2 = x < 0 or NaN, 3 = +inf
-SX_HD SxLog2 sx_log2_d(float x) {
+SX_HD SxLog2 sx_log2_d(float x, const bool fast = true) {
     SxLog2 R; R.special = 0; R.l2 = 0.0;
     uint32_t u = sx_f2u(x);
     int e = 0;
 #if defined(__HIP_DEVICE_COMPILE__) && SX_TANH_FAST
     // every lane a positive normal number (always, for the bases the model raises): no branch at all -- the same operations
-    if (__builtin_amdgcn_ballot_w64(!(u - 0x00800000u < 0x7f000000u)) != 0ull)
+    if (!fast || __builtin_amdgcn_ballot_w64(!(u - 0x00800000u < 0x7f000000u)) != 0ull)
 #endif
     {
         if (!(x > 0.f)) { R.special = (x == 0.f) ? 1 : 2; return R; }
@@ -289,10 +289,10 @@ SX_HD float sx_logf(float x) {
     return (float)(L.l2 * 0.6931471805599453);
 }
 // x^y given log2 x (several powers of one base share the logarithm: the vic-a adjoints need x^y, x^(y-1) and ln x)
-SX_HD float sx_pow_from(const SxLog2& L, float x, float y) {
+SX_HD float sx_pow_from(const SxLog2& L, float x, float y, const bool fast = true) {
 #if defined(__HIP_DEVICE_COMPILE__) && SX_TANH_FAST
     // the ordinary case on every lane of the wavefront: straight to the exponential
-    if (__builtin_amdgcn_ballot_w64(L.special != 0 || y == 0.f || x == 1.f) == 0ull) return (float)sx_exp2_d((double)y * L.l2);
+    if (fast && __builtin_amdgcn_ballot_w64(L.special != 0 || y == 0.f || x == 1.f) == 0ull) return (float)sx_exp2_d((double)y * L.l2);
 #endif
     if (y == 0.f || x == 1.f) return 1.f;
     if (L.special == 1) return y > 0.f ? 0.f : sx_inff();
@@ -403,7 +403,7 @@ SX_HD float sx_expm1f(float x) {
     return y;
 }
 
-SX_HD float sx_tanhf(float x) {
+SX_HD float sx_tanhf(float x, const bool fast = true) {      // fast = false: the branchy restatement only (device self-test)
 #if defined(SX_ABL_TANH) && defined(__HIP_DEVICE_COMPILE__)
     { const float e = __builtin_amdgcn_exp2f(2.885390082f * x); return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f); }   // timing-only build
 #endif
@@ -413,7 +413,7 @@ SX_HD float sx_tanhf(float x) {
     // Small arguments on every lane of the wavefront (evaporation or net rain against the store's capacity: en / cp ~ 1e-3): the same
     // operations as below along the one path such arguments take -- |x| < 2^-55: x (1 + x); else expm1f(-2|x|) with k = 0 (|2x| <
     // ln2 / 2), its |2x| < 2^-25 shortcut as a select -- without any branch.  Same bits by construction.
-    if (__builtin_amdgcn_ballot_w64(!(ix < 0x3e317218u)) == 0ull) {      // |x| < ln2 / 4: |2x| <= 0x3eb17218 (ln2 / 2), expm1f's k = 0 range
+    if (fast && __builtin_amdgcn_ballot_w64(!(ix < 0x3e317218u)) == 0ull) {      // |x| < ln2 / 4: |2x| <= 0x3eb17218 (ln2 / 2), expm1f's k = 0 range
         const float ax = sx_u2f(ix);
         const float x2 = -2.0f * ax;
         const float Q1 = -3.3333335072e-02f, Q2 = 1.5873016091e-03f, Q3 = -7.9365076090e-05f, Q4 = 4.0082177293e-06f, Q5 = -2.0109921195e-07f;

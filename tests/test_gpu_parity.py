@@ -253,6 +253,20 @@ def test_device_division_matches_ieee(blo, bhi):
     assert out[0] <= n * 1e-6, (out[0], n)
 
 
+def test_wavefront_fast_paths_equal_the_branchy_forms():
+    """The straight-line paths a wavefront takes when all its lanes hold ordinary operands (sx_tanhf for |x| < ln2 / 4, the fp64
+    log2 / pow of vic-a for positive normal bases) against the branchy restatements they shortcut, on the device, bit for bit --
+    wavefronts of uniform small arguments (the path runs) and wavefronts mixed with large / special operands (it must not)."""
+    import ctypes as C
+    from smash_amd import _lib
+    out = (C.c_longlong * 2)()
+    fn = _lib.lib().smashx_selftest_paths
+    fn.argtypes = [C.c_int, C.c_longlong, C.c_uint, C.POINTER(C.c_longlong)]
+    for seed in (1, 777):
+        _lib.check(fn(0, 100_000_000, seed, out))
+        assert out[0] == 0 and out[1] == 0, list(out)
+
+
 @pytest.mark.parametrize("name,sparse", [("gr_c_16x16x96_kge_se_log_mask", False), ("gr_b_16x16x96_nse_gaps", True)])
 def test_domain_outputs(name, sparse):
     """setup%save_qsim_domain / save_net_prcp_domain (md_forward_structure.f90:158-194): discharge and net rainfall of
