@@ -3,13 +3,16 @@
 #   here (container):   tools/anatomy.sh build                  -> variants/lib_<name>.so  (git-ignored, travels with gpurun)
 #   on the GPU box:     tools/anatomy.sh run [names...]          -> gpurun_out/anatomy_<name>.json (+ per-round routing traces)
 # Switches: smash_amd/csrc/sx_kernels.h (routing super-step), smash_amd/csrc/sx_math.h (faithful arithmetic).
-# Numbers quoted in DESIGN.md 12 and profiles/r2_routing_anatomy*.json come from this.
+# Numbers quoted in DESIGN.md 12 and profiles/r2_routing_anatomy*.json come from this.  The round-3 switches (still0, tanh0, wb15, onesub,
+# exact_*: valid results, different instruction streams) are compared on one box with tools/ab_variants.sh.
 set -u
 cd "$(dirname "$0")/.."
 declare -A V=(
   [base]="" [tanh]="-DSX_ABL_TANH" [div]="-DSX_ABL_DIV" [pow]="-DSX_ABL_POW" [arith]="-DSX_ABL_TANH -DSX_ABL_DIV -DSX_ABL_POW"
   [nobar]="-DSX_ABL_NOBAR" [norel]="-DSX_ABL_NOREL" [nolds]="-DSX_ABL_NOLDS" [nost]="-DSX_ABL_NOST=1" [nold]="-DSX_ABL_NOLD=1"
   [alu]="-DSX_ABL_NOLDS -DSX_ABL_NOST=1 -DSX_ABL_NOLD=1 -DSX_ABL_NOBAR"
+  [still0]="-DSX_STILL=0" [tanh0]="-DSX_TANH_FAST=0" [wb15]="-DSX_WAVE_BRANCH=15" [onesub]="-DSX_ABL_ONE_SUBLEVEL"
+  [exact]="-DSX_EXACT_LIBM=1" [exact_d0]="-DSX_EXACT_LIBM=1 -DSX_EXACT_DIV=0" [exact_d1]="-DSX_EXACT_LIBM=1 -DSX_EXACT_DIV=1" [exact_noguard]="-DSX_EXACT_LIBM=1 -DSX_ABL_NOGUARD"
   [anoq]="-DSX_ABL_A_NOQ=1" [anox]="-DSX_ABL_A_NOX=1" [anohr]="-DSX_ABL_A_NOHR=1" [pk4]="-DSX_PK=4" [pk64]="-DSX_PK=64" [mu2]="-DSX_MU=2" [mu8]="-DSX_MU=8"
 )
 case "${1:-}" in
