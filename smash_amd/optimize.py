@@ -24,6 +24,13 @@ def _normalize(obj, names, lb, ub):
         setattr(obj, k, np.asfortranarray(((a - np.float32(lb[i])) / (np.float32(ub[i]) - np.float32(lb[i]))).astype(np.float32)))
 
 
+class _Held:
+    """a trial point a worker rank has already received (Decomposition.bcast_point hands it back unchanged)"""
+
+    def __init__(self, x):
+        self.x = x
+
+
 class _Stop(Exception):
     pass
 
@@ -220,12 +227,21 @@ def auto_wjreg_cycles(run_cycle, restore, auto_wjreg, nb_wjreg_lcurve=6, verbose
 
 
 def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose=False, auto_wjreg=None, nb_wjreg_lcurve=6,
-                    return_lcurve=False):
+                    return_lcurve=False, decomposition=None):
     """In-place like the reference: parameters / states come back calibrated (denormalised), output holds the final run.
     Returns a dict with the cost trajectory.  setup.optimize.maxiter bounds the iterations (default 100).
     auto_wjreg = 'fast' | 'lcurve' (only with jreg_fun set): the weight of the regularisation term is found by calibration
     cycles first (auto_wjreg_cycles above) and left in setup.optimize.wjreg; the returned dict is the final cycle's, with
-    'wjreg' and, for return_lcurve, 'lcurve' added."""
+    'wjreg' and, for return_lcurve, 'lcurve' added.
+
+    decomposition (multi-GPU, smash_amd.tiles.Decomposition): the calibration over the ranks of a tile decomposition.  Every rank
+    calls this function with ITS setup / mesh (its gauges), whole-grid parameter planes and input_data._smashx_solver = the
+    plan of its part (exchange set).  The control vector is the whole grid's, in the reference's order; rank 0 runs L-BFGS-B and
+    hands every trial point to the others, each evaluation is one collective forward_b: the parts' cost_jobs are summed, the
+    regulariser's term -- evaluated over the whole grid by every rank -- counted once, every rank contributes the gradient of the
+    cells it owns.  The iterates are those of the single domain (the sweep is bit-identical, the sums are not reordered)."""
+    if decomposition is not None and auto_wjreg is not None:
+        raise ValueError("auto_wjreg over a decomposition: run the cycles with decomposition= on every rank yourself")
     if auto_wjreg is not None and setup.optimize.njr > 0:
         o = setup.optimize
         if auto_wjreg == "lcurve" and nb_wjreg_lcurve < 6:
@@ -295,9 +311,25 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
     hist = {"cost": [], "nfg": 0}
     x = to_control(parameters, states)
     moved = set(pf + sf)
+    dec = decomposition
+    if dec is not None:
+        own_f = np.asarray(dec.owned, bool).reshape(-1, order="F")[mask_f]          # control-vector order
+        own_ctl = np.tile(own_f, len(pf) + len(sf))
+
+    def whole_cost():
+        """the decomposition's cost from this rank's output: sum of the parts' cost_jobs + wjreg x the (common) cost_jreg"""
+        if dec is None:
+            return float(np.float32(output.cost))
+        v = np.array([float(output.cost_jobs)], np.float64)
+        dec.allreduce(v)
+        output.cost_jobs = np.float32(v[0])
+        output.cost = np.float32(np.float32(v[0]) + np.float32(o.wjreg) * np.float32(output.cost_jreg))
+        return float(output.cost)
+
     try:
         forward(setup, mesh, input_data, parameters, par_bgd, states, sta_bgd, output, np.float32(0))
         renormalize()
+        whole_cost()
         hist["cost_jobs_initial"], hist["cost_jreg_initial"] = output.cost_jobs, output.cost_jreg
         last = {}
         # every evaluation is one forward_b with denormalize_forward on (mw_optimize.f90:590-606).  The plan keeps the fields
@@ -306,9 +338,22 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
         sol = _solver_for(setup, mesh, input_data)
         sol.upload(parameters, states, par_bgd, sta_bgd)
 
-        device_pack = sol.control_size() == n       # control_to_var / var_to_control on the device (smashx_control_*)
+        device_pack = dec is None and sol.control_size() == n       # control_to_var / var_to_control on the device (smashx_control_*)
 
         def fg(xc):
+            if dec is not None:
+                # one collective evaluation: rank 0's trial point on every rank, the parts' costs and gradients put together
+                xc = dec.bcast_point(xc)
+                to_var(xc)
+                sol.upload(parameters, states, par_bgd, sta_bgd, only=moved)
+                sol.sweep(True, 1.0)
+                sol.download(True, None, None, output, par_b, sta_b, only_b=moved)
+                g = to_control(par_b, sta_b)
+                g[~own_ctl] = 0.0                                   # (cells of other parts carry the regulariser's gradient here too)
+                dec.allreduce(g)
+                hist["nfg"] += 1
+                last["f"], last["g"] = whole_cost(), g
+                return last["f"], g
             if device_pack:
                 # mw_optimize.f90:590-606 with the packing on the device: one contiguous fp64 vector goes up, the fields are
                 # unpacked, cast and denormalised there; cost + discharge and one contiguous gradient vector come back
@@ -335,15 +380,26 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
                 last["x"] = xk.copy()
                 raise _Stop
 
-        try:
-            x, f, info = _lbfgsb_box(fg, x, 10, 10.0, 1e-12, maxiter, 10 * maxiter + 20, cb)
-            hist["task"] = str(info.get("task", ""))
-        except _Stop:
-            x = last["x"]
-            hist["task"] = "STOP: THE PROJECTED GRADIENT IS SUFFICIENTLY SMALL"
+        if dec is None or dec.rank == 0:
+            try:
+                x, f, info = _lbfgsb_box(fg, x, 10, 10.0, 1e-12, maxiter, 10 * maxiter + 20, cb)
+                hist["task"] = str(info.get("task", ""))
+            except _Stop:
+                x = last["x"]
+                hist["task"] = "STOP: THE PROJECTED GRADIENT IS SUFFICIENTLY SMALL"
+            if dec is not None:
+                x = dec.bcast_point(x, done=True)
+        else:
+            # the other ranks evaluate what rank 0 asks for until it says the search is over
+            while True:
+                xw = dec.bcast_point(None)
+                if xw is None:
+                    break
+                fg(_Held(xw))
+            x = dec.final_point
         to_var(x)
         forward(setup, mesh, input_data, parameters, par_bgd, states, sta_bgd, output, np.float32(0))
-        hist["final_cost"] = float(output.cost)
+        hist["final_cost"] = whole_cost()
     finally:
         o.denormalize_forward = was
     return hist

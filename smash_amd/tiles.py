@@ -95,6 +95,100 @@ def decomposition_cost(cost_jobs_per_rank, cost_jreg, wjreg):
     return float(np.sum(np.asarray(cost_jobs_per_rank, np.float64)) + float(wjreg) * float(cost_jreg))
 
 
+class Decomposition:
+    """What smash_amd.optimize_lbfgsb(decomposition=...) needs from the ranks of a tile decomposition (the calibration over several
+    GPUs): rank, the cells this rank owns, a sum over the ranks and rank 0's trial points on every rank.  Subclasses supply the
+    transport: TorchDecomposition (torch.distributed: RCCL on GPUs, gloo in rehearsals), ThreadDecomposition (plans of one process,
+    tests)."""
+
+    def __init__(self, rank, world, owned):
+        self.rank, self.world = int(rank), int(world)
+        self.owned = np.asarray(owned, bool)             # (nrow, ncol): active cells of this rank's part
+        self.final_point = None
+
+    def allreduce(self, v):                              # in place, float64
+        raise NotImplementedError
+
+    def _bcast(self, head, x):                           # rank 0: sends (head, x); others: return (head, x)
+        raise NotImplementedError
+
+    def bcast_point(self, x, done=False):
+        """rank 0: hand the trial point x (done: the final iterate) to the other ranks, returns x.  Other ranks: called with None,
+        return the next point to evaluate, or None once rank 0 is done (the final iterate is then in final_point)."""
+        if hasattr(x, "x"):                              # a point this rank has already received
+            return x.x
+        if self.rank == 0:
+            x = np.ascontiguousarray(x, np.float64)
+            self._bcast(0 if done else 1, x)
+            return x
+        head, xr = self._bcast(None, None)
+        if head == 0:
+            self.final_point = xr
+            return None
+        return xr
+
+
+class TorchDecomposition(Decomposition):
+    """The ranks of a torch.distributed process group (backend nccl = RCCL: device tensors; gloo: host tensors)."""
+
+    def __init__(self, owned, n_control, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        super().__init__(dist.get_rank(group), dist.get_world_size(group), owned)
+        self.torch, self.dist, self.group = torch, dist, group
+        self.dev = device if dist.get_backend(group) == "nccl" else "cpu"
+        self.n = int(n_control)
+
+    def allreduce(self, v):
+        t = self.torch.from_numpy(v).to(self.dev)
+        self.dist.all_reduce(t, group=self.group)
+        v[:] = t.cpu().numpy()
+
+    def _bcast(self, head, x):
+        buf = self.torch.zeros(self.n + 1, dtype=self.torch.float64, device=self.dev)
+        if self.rank == 0:
+            buf[0] = float(head)
+            buf[1:] = self.torch.from_numpy(x).to(self.dev)
+        self.dist.broadcast(buf, 0, group=self.group)
+        if self.rank == 0:
+            return head, x
+        b = buf.cpu().numpy()
+        return int(b[0]), b[1:].copy()
+
+
+class ThreadDecomposition(Decomposition):
+    """Plans of ONE process, one thread per rank (tests/test_gpu_tiles.py): make(world) returns the shared state, then one
+    ThreadDecomposition(shared, rank, owned) per thread."""
+
+    @staticmethod
+    def make(world):
+        import threading
+        return {"world": world, "bar": threading.Barrier(world), "lock": threading.Lock(), "acc": None, "msg": None}
+
+    def __init__(self, shared, rank, owned):
+        super().__init__(rank, shared["world"], owned)
+        self.sh = shared
+
+    def allreduce(self, v):
+        sh = self.sh
+        with sh["lock"]:
+            sh["acc"] = v.copy() if sh["acc"] is None else sh["acc"] + v
+        sh["bar"].wait(timeout=300)
+        v[:] = sh["acc"]
+        if sh["bar"].wait(timeout=300) == 0:
+            sh["acc"] = None
+        sh["bar"].wait(timeout=300)
+
+    def _bcast(self, head, x):
+        sh = self.sh
+        if self.rank == 0:
+            sh["msg"] = (head, x.copy())
+        sh["bar"].wait(timeout=300)
+        head, x = sh["msg"]
+        sh["bar"].wait(timeout=300)
+        return head, x.copy()
+
+
 class PeerLists:
     """For one tile: which rows of the out / in message buffers go to / come from which peer rank.
     owner: optional (nrow, ncol) part id per cell (partition_subcatchments) instead of the pr x pc rectangles."""

@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--cut", default="rect")
     ap.add_argument("--opts", action="store_true", help="the fixture's own calibration options (criteria, normalisation, regularisers, "
                     "gauge weights incl. the median over gauges) instead of the plain nse of the short window")
+    ap.add_argument("--calibrate", type=int, default=0, help="with --opts: also run N iterations of optimize_lbfgsb over the decomposition "
+                    "(tiles.TorchDecomposition over this process group) and compare with the single-domain calibration")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 
@@ -120,6 +122,38 @@ def main():
     cost = tiles.decomposition_cost([jobs], out.cost_jreg, float(g.opts.get("wjreg", 0.0)) if a.opts else 0.0)
     if abs(cost - ref_out.cost) > 1e-6 * abs(ref_out.cost) + 1e-7:
         bad.append(("cost", cost, ref_out.cost))
+    if a.calibrate:
+        # the distributed calibration (mw_optimize.f90:484-676) over the ranks: rank 0 runs L-BFGS-B, every trial point is one collective
+        # forward_b over RCCL; against the same calibration on the single domain (every rank computes that reference itself)
+        from test_gpu_parity import _types
+        s1, m1, i1, p1, t1, o1 = _types(g)
+        s1.optimize.maxiter = a.calibrate
+        href = smash_amd.optimize_lbfgsb(s1, m1, i1, p1, t1, o1)
+        say(f"single-domain calibration: {href['cost']}")
+        setup.optimize.maxiter = a.calibrate
+        ip = smash_amd.Input_DataDT(setup, mesh)
+        ip.prcp, ip.pet = g.prcp, g.pet
+        ip.qobs = np.asfortranarray(g.qobs[loc]) if loc else np.zeros((0, g.nt), np.float32, order="F")
+        ip._smashx_solver = sol
+        owned = np.zeros((nrow, ncol), bool)
+        owned[rows, cols] = True
+        o = setup.optimize
+        nctl = int(np.count_nonzero(np.asarray(o.optim_parameters) > 0) + np.count_nonzero(np.asarray(o.optim_states) > 0)) * int(np.count_nonzero(np.asarray(g.mesh.active_cell) == 1))
+        dec = tiles.TorchDecomposition(owned, nctl, device=dev)
+        pt, tt = smash_amd.ParametersDT.from_dict(mesh, g.params), smash_amd.StatesDT.from_dict(mesh, g.states)
+        ot = smash_amd.OutputDT(setup, mesh)
+        h = smash_amd.optimize_lbfgsb(setup, mesh, ip, pt, tt, ot, decomposition=dec)
+        say(f"calibration over {world} ranks: {h['cost'] if rank == 0 else h['final_cost']}")
+        if rank == 0 and (len(h["cost"]) != len(href["cost"]) or h["nfg"] != href["nfg"] or not np.allclose(h["cost"], href["cost"], rtol=2e-6, atol=0)):
+            bad.append(("calibration", h["cost"], href["cost"], h["nfg"], href["nfg"]))
+        if abs(h["final_cost"] - href["final_cost"]) > 2e-6 * abs(href["final_cost"]):
+            bad.append(("final cost", h["final_cost"], href["final_cost"]))
+        act = np.asarray(g.mesh.active_cell) == 1
+        for i, k in enumerate(gu.PARAM_NAMES if hasattr(gu, "PARAM_NAMES") else smash_amd.synth.PARAM_NAMES):
+            if o.optim_parameters[i] > 0:
+                d = float(np.max(np.abs(getattr(pt, k)[act] - getattr(p1, k)[act])))
+                if d > 1e-4 * float(np.max(np.abs(getattr(p1, k)[act]))):
+                    bad.append(("field", k, d))
     n_out, n_in = sol.halo_counts()
     print(f"rank {rank}/{world} [{a.exchange}, {a.cut}]: cells {sol.ncells}, edges out {n_out} in {n_in}, chunking {sol.chunking()}, "
           f"{'BIT-IDENTICAL' if not bad else 'MISMATCH ' + str(bad[:6])}", flush=True)

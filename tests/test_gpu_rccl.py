@@ -47,6 +47,13 @@ def test_regularisation_and_median_across_ranks_over_rccl():
     _launch(2, ["--case", "gr_b_16x16x96_median2", "--opts", "--cut", "sub", "--chunk", "96", "--pipe", "32"], 13)
 
 
+def test_calibration_across_ranks_over_rccl():
+    """smash_amd.optimize_lbfgsb(decomposition=tiles.TorchDecomposition) on two processes: rank 0 runs the library's L-BFGS-B, every
+    trial point is one collective forward_b (boundary series over RCCL, costs and gradients put together by all-reduce), with the
+    normalised control and the regularisers of the fixture -- same iterations, evaluations and costs as the single-domain calibration."""
+    _launch(2, ["--case", "gr_b_24x24x120_norm_jreg", "--opts", "--calibrate", "2", "--chunk", "64", "--pipe", "16"], 17)
+
+
 def test_bench_self_launch_two_ranks():
     """python bench.py --gpus 2 with no launcher starts both ranks itself and prints one JSON line with n_gpus = 2."""
     import json

@@ -242,3 +242,88 @@ def test_tile_refuses_self_sized_chunks():
     with pytest.raises(smash_amd.SmashxError) as e:
         sol.chunking()
     assert e.value.code == _lib.E_ARG and "chunk_steps" in str(e.value)
+
+
+@pytest.mark.parametrize("world,with_jreg", [(4, False), (2, True)])
+def test_calibration_over_tiles_follows_the_single_domain(world, with_jreg):
+    """smash_amd.optimize_lbfgsb(decomposition=...): the distributed L-BFGS-B calibration (mw_optimize.f90:484-676) over the plans of
+    a tile decomposition -- rank 0 runs the optimiser, every trial point is one collective forward_b, the parts' costs are summed,
+    every part contributes the gradient of its own cells (the regulariser's term, evaluated over the whole grid by every part,
+    counted once).  Against the same calibration on the single domain: same number of iterations and evaluations, costs and
+    calibrated fields equal to the rounding of the cost sum (parts' fp32 costs added in double)."""
+    import os
+    import torch
+    torch.zeros(1, device="cuda")
+    import smash_amd
+    from smash_amd import synth, tiles
+    from smash_amd.solver import Solver
+    from test_gpu_parity import _types
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "opt_gr_b_24x24x120.npz"))
+    g = gu.load("gr_b_24x24x120_norm_jreg")
+    if not with_jreg:
+        g.opts = dict(jobs_fun=("nse",), wjobs_fun=(1.0,))
+    else:
+        g.opts = {k: v for k, v in g.opts.items() if k not in ("params_bgd", "states_bgd")}
+    g.params, g.states, g.qobs = synth.make_parameters(24, 24), synth.make_states(24, 24, warm=True), z["qobs"]
+    op = np.asarray(z["optim_parameters"], np.int32)
+    maxiter = 3
+
+    setup, mesh, inp, par, sta, out = _types(g)
+    setup.optimize.optim_parameters, setup.optimize.maxiter = op, maxiter
+    setup.optimize.optim_states = np.zeros_like(np.asarray(setup.optimize.optim_states))
+    href = smash_amd.optimize_lbfgsb(setup, mesh, inp, par, sta, out)
+
+    pr, pc = tiles.tile_grid(world)
+    nrow, ncol = g.mesh.nrow, g.mesh.ncol
+    box = {(a, b, k): queue.Queue() for a in range(world) for b in range(world) for k in "fa"}
+    shared = tiles.ThreadDecomposition.make(world)
+    summer = _SumOverTiles(world)
+    res, errs = {}, []
+
+    def run(rank):
+        try:
+            rect = tiles.tile_rect(rank, nrow, ncol, pr, pc)
+            st, ms, loc = _tile_inputs(g, rect, g.mesh.ng)
+            nslots, slots = _apply_opts(st, g, loc)
+            st.optimize.optim_parameters, st.optimize.maxiter = op, maxiter
+            st.optimize.optim_states = np.zeros_like(np.asarray(st.optimize.optim_states))
+            sol = Solver(st, ms, chunk_steps=64, pipe_steps=16, group_size=128, tile=rect)
+            if nslots:
+                sol.set_median_slots(nslots, slots, summer)
+            ex = Loopback(rank, sol, nrow, ncol, pr, pc, box)
+            ip = smash_amd.Input_DataDT(st, ms)
+            ip.prcp, ip.pet = g.prcp, g.pet
+            ip.qobs = np.asfortranarray(g.qobs[loc]) if loc else np.zeros((0, g.nt), np.float32, order="F")
+            ip._smashx_solver = sol
+            rows, cols = sol.cell_order()
+            owned = np.zeros((nrow, ncol), bool)
+            owned[rows, cols] = True
+            dec = tiles.ThreadDecomposition(shared, rank, owned)
+            pt = smash_amd.ParametersDT.from_dict(ms, g.params)
+            stt = smash_amd.StatesDT.from_dict(ms, g.states)
+            ot = smash_amd.OutputDT(st, ms)
+            h = smash_amd.optimize_lbfgsb(st, ms, ip, pt, stt, ot, decomposition=dec)
+            res[rank] = (h, pt, ot, ex.calls)
+        except Exception as e:  # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            errs.append(e)
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not errs and len(res) == world
+    h0 = res[0][0]
+    assert len(h0["cost"]) == len(href["cost"]) == maxiter and h0["nfg"] == href["nfg"]
+    assert np.allclose(h0["cost"], href["cost"], rtol=2e-6, atol=0), (h0["cost"], href["cost"])
+    assert abs(h0["final_cost"] - href["final_cost"]) <= 2e-6 * abs(href["final_cost"])
+    act = np.asarray(g.mesh.active_cell) == 1
+    for rank, (h, pt, ot, calls) in res.items():
+        assert h["final_cost"] == h0["final_cost"] and calls > 0             # every rank ends with the same cost and really exchanged
+        for i, k in enumerate(synth.PARAM_NAMES):
+            if op[i] > 0:                                                     # every rank holds the whole calibrated field
+                a, b = getattr(pt, k)[act], getattr(par, k)[act]
+                assert np.max(np.abs(a - b)) <= 1e-4 * np.max(np.abs(b)), (rank, k, float(np.max(np.abs(a - b))))

@@ -141,3 +141,73 @@ def test_two_ranks_agree_over_gloo(cut):
     for p in procs:
         p.join(timeout=60)
     assert res == {0: 1, 1: 1}
+
+
+def _calib_problem(n):
+    rng = np.random.default_rng(11)
+    tgt, w = rng.uniform(-0.2, 1.2, n), 10.0 ** rng.uniform(-1, 1, n)
+
+    def part(x, sel):              # cost and gradient of the variables in sel only
+        d = x[sel] - tgt[sel]
+        g = np.zeros(n)
+        g[sel] = 2 * w[sel] * d
+        return float(np.sum(w[sel] * d * d)), g
+    return part
+
+
+def _gloo_calibration_worker(rank, world, port, q):
+    """The protocol of optimize_lbfgsb(decomposition=...) with the sweep replaced by a separable function: rank 0 runs the library's
+    L-BFGS-B, the others evaluate what it asks for until it says the search is over."""
+    import torch.distributed as dist
+    from smash_amd.optimize import _Held, _lbfgsb_native
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 60
+        part = _calib_problem(n)
+        mine = np.arange(n) % world == rank
+        dec = tiles.TorchDecomposition(mine.reshape(n, 1), n)
+        evals = []
+
+        def fg(xc):
+            x = dec.bcast_point(xc)
+            f, g = part(x, mine)
+            v = np.array([f])
+            dec.allreduce(v)
+            dec.allreduce(g)
+            evals.append(float(v[0]))
+            return float(v[0]), g
+        if rank == 0:
+            x, f, info = _lbfgsb_native(fg, np.full(n, 0.5), 10, 10.0, 1e-12, 30, 400, None)
+            x = dec.bcast_point(x, done=True)
+        else:
+            while True:
+                xw = dec.bcast_point(None)
+                if xw is None:
+                    break
+                fg(_Held(xw))
+            x = dec.final_point
+        q.put((rank, evals, x.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_calibration_protocol_over_gloo():
+    """tiles.TorchDecomposition (gloo, world_size 2) under the library's L-BFGS-B: both ranks see the same evaluations and end on
+    the same point, which is the one a single process finds."""
+    import torch.multiprocessing as mp
+    from smash_amd.optimize import _lbfgsb_native
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 23
+    procs = [ctx.Process(target=_gloo_calibration_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (e, x) for r, e, x in (q.get(timeout=180) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and len(res[0][0]) > 5
+    n = 60
+    part = _calib_problem(n)
+    xs, fs, info = _lbfgsb_native(lambda x: part(x, np.ones(n, bool)), np.full(n, 0.5), 10, 10.0, 1e-12, 30, 400, None)
+    assert info["funcalls"] == len(res[0][0]) and np.allclose(xs, res[0][1], rtol=0, atol=1e-12)
