@@ -147,3 +147,61 @@ def test_native_lbfgsb_argument_and_limit_behaviour():
     fg, log = make()
     _lbfgsb_native(fg, np.full(50, 1.5), 10, 10.0, 1e-14, 1, 50, None)
     assert np.all(log[0][1] == 1.0)
+
+
+def _native_minimize(fg, x0, lo, up, m=10, factr=1e7, pgtol=1e-8, maxiter=2000):
+    """smashx_lbfgsb_* through ctypes with general bounds (None = no bound): (x, f, iterations, evaluations, message)."""
+    import ctypes as C
+    from smash_amd import _lib
+    L = _lib.lib()
+    n = len(x0)
+    lo = np.array([-np.inf if v is None else v for v in lo], np.float64)
+    up = np.array([np.inf if v is None else v for v in up], np.float64)
+    h = C.c_void_p()
+    _lib.check(L.smashx_lbfgsb_create(n, m, lo.ctypes.data, up.ctypes.data, factr, pgtol, C.byref(h)))
+    x = np.array(x0, np.float64)
+    g = np.zeros(n)
+    f, task, nit, nfev = 0.0, C.c_int(0), 0, 0
+    while True:
+        _lib.check(L.smashx_lbfgsb_step(h, x.ctypes.data, float(f), g.ctypes.data, C.byref(task)))
+        if task.value == 1:
+            f, g = fg(x.copy())
+            g = np.ascontiguousarray(g, np.float64)
+            nfev += 1
+        elif task.value == 2:
+            nit += 1
+            if nit >= maxiter:
+                break
+        else:
+            break
+    msg = L.smashx_lbfgsb_message(h).decode()
+    L.smashx_lbfgsb_destroy(h)
+    return x, f, nit, nfev, msg
+
+
+@pytest.mark.parametrize("kind", ["none", "lower", "upper", "mixed"])
+def test_native_lbfgsb_with_general_bounds_against_the_reference_code(kind):
+    """Variables without bounds, with one bound and with two (nbd = 0, 1, 3, 2 of lbfgsb.f) on the extended Rosenbrock function:
+    the library's L-BFGS-B against scipy's build of the reference's code -- same minimum, iteration and evaluation counts within a
+    few (the unit first step of the unconstrained case, the Cauchy search with infinite breakpoints)."""
+    from scipy.optimize import fmin_l_bfgs_b
+    n = 12
+
+    def fg(x):
+        f = float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+        g = np.zeros_like(x)
+        g[:-1] = -400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200.0 * (x[1:] - x[:-1] ** 2)
+        return f, g
+    lo = {"none": [None] * n, "lower": [0.3 if i % 3 == 0 else None for i in range(n)], "upper": [None] * n,
+          "mixed": [(-0.5 if i % 2 else None) for i in range(n)]}[kind]
+    up = {"none": [None] * n, "lower": [None] * n, "upper": [0.7 if i % 4 == 1 else None for i in range(n)],
+          "mixed": [(0.6 if i % 3 == 0 else None) for i in range(n)]}[kind]
+    x0 = np.linspace(-0.4, 0.9, n)
+    xs, fs, d = fmin_l_bfgs_b(fg, x0, m=10, factr=1e7, pgtol=1e-8, bounds=list(zip(lo, up)), maxiter=2000, maxfun=5000)
+    xn, fn, nit, nfev, msg = _native_minimize(fg, x0, lo, up)
+    assert msg.startswith("CONVERGENCE"), msg
+    assert abs(fn - fs) <= 1e-6 * max(1.0, abs(fs)) and np.max(np.abs(xn - xs)) <= 2e-3, (fn, fs, float(np.max(np.abs(xn - xs))))
+    assert abs(nit - d["nit"]) <= max(4, d["nit"] // 8) and abs(nfev - d["funcalls"]) <= max(5, d["funcalls"] // 8), (nit, d["nit"], nfev, d["funcalls"])
+    lo_a = np.array([-np.inf if v is None else v for v in lo]); up_a = np.array([np.inf if v is None else v for v in up])
+    assert np.all(xn >= lo_a) and np.all(xn <= up_a)
