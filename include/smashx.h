@@ -208,7 +208,8 @@ int smashx_control_gradient(smashx_plan* plan, double* g);
  * written at md_forward_structure.f90:158-194 when setup%save_qsim_domain / save_net_prcp_domain): caller-owned host
  * arrays (nrow, ncol, nt) column-major -- inactive cells are set to -99 like OutputDT_initialise does -- or, with
  * sparse != 0, the (nac, nt) sparse_ forms.  They are filled by every following smashx_forward / forward sweep
- * until reset with NULL; adjoint sweeps do not touch them. */
+ * until reset with NULL; adjoint sweeps do not touch them.  A tiled plan fills the cells of its own part in the dense form (-99
+ * everywhere else: the caller overlays the parts) and refuses the sparse form, which numbers the whole grid's active cells. */
 int smashx_set_domain_outputs(smashx_plan* plan, float* qsim_domain, float* net_prcp_domain, int sparse);
 
 /* base_forward_d (forward_db.f90:10517-10601), the tangent-linear model behind mw_forward::forward_d

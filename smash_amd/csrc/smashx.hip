@@ -1764,8 +1764,10 @@ int smashx_set_domain_outputs(smashx_plan* p, float* qsim_domain, float* net_prc
     if (!p) return fail(SMASHX_E_ARG, "null plan");
     if (sparse && !p->d_sparse_idx && (qsim_domain || net_prcp_domain))
         return fail(SMASHX_E_ARG, "sparse domain outputs need mesh.path (the sparse cell numbering)");
-    if (p->tiled && (qsim_domain || net_prcp_domain))
-        return fail(SMASHX_E_UNSUPPORTED, "whole-domain outputs on a tiled plan");
+    // a tiled plan fills the cells of its own part (dense form: -99 everywhere else, the caller overlays the parts); the sparse form
+    // numbers the WHOLE grid's active cells, which a part does not hold
+    if (p->tiled && sparse && (qsim_domain || net_prcp_domain))
+        return fail(SMASHX_E_UNSUPPORTED, "sparse whole-domain outputs on a tiled plan (use the dense form: each part fills its own cells)");
     p->h_qsim_domain = qsim_domain; p->h_net_prcp_domain = net_prcp_domain; p->dom_sparse = sparse ? 1 : 0;
     return 0;
 }

@@ -327,3 +327,66 @@ def test_calibration_over_tiles_follows_the_single_domain(world, with_jreg):
             if op[i] > 0:                                                     # every rank holds the whole calibrated field
                 a, b = getattr(pt, k)[act], getattr(par, k)[act]
                 assert np.max(np.abs(a - b)) <= 1e-4 * np.max(np.abs(b)), (rank, k, float(np.max(np.abs(a - b))))
+
+
+def test_domain_outputs_of_the_parts_overlay_to_the_single_domain():
+    """setup%save_qsim_domain / save_net_prcp_domain (md_forward_structure.f90:158-194) on a decomposition: every part fills the cells
+    it owns in the dense (nrow, ncol, nt) arrays and leaves -99 elsewhere; overlaid, the parts give the single domain's arrays bit
+    for bit (forward sweep in storage chunks and pipeline sub-chunks, boundary series through the in-process exchange)."""
+    import torch
+    torch.zeros(1, device="cuda")
+    import smash_amd
+    from smash_amd import tiles
+    from smash_amd.solver import Solver
+    from test_gpu_parity import _types
+    g = _short("gr_b_64x64x720_nse", 96)
+    world = 4
+    setup, mesh, inp, par, sta, out = _types(g)
+    setup.save_qsim_domain = setup.save_net_prcp_domain = True
+    out = smash_amd.OutputDT(setup, mesh)
+    s0 = Solver(setup, mesh, chunk_steps=32)
+    s0.set_forcing(inp.prcp, inp.pet)
+    inp._smashx_solver = s0
+    smash_amd.forward(setup, mesh, inp, par, par.copy(), sta, sta.copy(), out, np.float32(0))
+    ref_q, ref_p = out.qsim_domain.copy(), out.net_prcp_domain.copy()
+    pr, pc = tiles.tile_grid(world)
+    nrow, ncol = g.mesh.nrow, g.mesh.ncol
+    box = {(a, b, k): queue.Queue() for a in range(world) for b in range(world) for k in "fa"}
+    res, errs = {}, []
+
+    def run(rank):
+        try:
+            rect = tiles.tile_rect(rank, nrow, ncol, pr, pc)
+            st, ms, loc = _tile_inputs(g, rect, g.mesh.ng)
+            sol = Solver(st, ms, chunk_steps=32, pipe_steps=16, group_size=128, tile=rect)
+            sol.set_forcing(g.prcp, g.pet)
+            if loc:
+                sol.set_qobs(np.asfortranarray(g.qobs[loc]))
+            sol.set_options(st.optimize)
+            Loopback(rank, sol, nrow, ncol, pr, pc, box)
+            q = np.zeros((nrow, ncol, g.nt), np.float32, order="F")
+            pn = np.zeros((nrow, ncol, g.nt), np.float32, order="F")
+            sol.set_domain_outputs(q, pn)
+            sol.upload(smash_amd.ParametersDT.from_dict(ms, g.params), smash_amd.StatesDT.from_dict(ms, g.states))
+            sol.sweep(False, 0.0)
+            rows, cols = sol.cell_order()
+            res[rank] = (q, pn, rows, cols)
+        except Exception as e:  # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs and len(res) == world
+    q_all = np.full_like(ref_q, -99.0)
+    p_all = np.full_like(ref_p, -99.0)
+    for rank, (q, pn, rows, cols) in res.items():
+        own = np.zeros((nrow, ncol), bool)
+        own[rows, cols] = True
+        assert np.all(q[~own] == -99.0) and np.all(pn[~own] == -99.0)          # a part writes its own cells only
+        q_all[own], p_all[own] = q[own], pn[own]
+    assert np.array_equal(q_all, ref_q) and np.array_equal(p_all, ref_p)
