@@ -47,6 +47,38 @@ class Task:
         self.done_at, self.left, self.started = None, work, None
 
 
+def ramp_schedule(T, pipe, ramp):
+    """Sub-chunk lengths of a storage chunk of T steps (multiples of 16 except the last): `pipe` steps each, but the first and the last
+    `pipe` steps are cut into ramp pieces each -- short sub-chunks where a sweep direction starts (the rank pipeline fills faster),
+    long ones in between (fewer fills of the chained routing rounds).  ramp <= 1: equal lengths (what smashx_sweep does).  Evaluated
+    with this model and NOT built: every extra sub-chunk pays the fill of a chained launch (6 + 7 ms on a 2048 x 1024
+    tile), which is what a short sub-chunk saves the rank pipeline: N = 8 at sub-chunks of 2192 steps 601 -> 603 / 646 / 696 ms for
+    ramp 2 / 3 / 4."""
+    n = max(1, (T + pipe // 2) // pipe)
+    tp = -(-T // n)
+    tp = -(-tp // 16) * 16
+    if ramp <= 1 or n < 2:
+        return [min(tp, T - j * tp) for j in range(n) if T - j * tp > 0]
+    small = max(16, (tp // ramp) // 16 * 16)
+    head = [small] * ramp
+    head[-1] = tp - small * (ramp - 1)
+    mid = T - 2 * tp
+    out = list(head)
+    while mid > 0:
+        out.append(min(tp, mid))
+        mid -= tp
+    out += head[::-1]
+    # fix the total (rounding): the piece before the tail absorbs the difference
+    d = T - sum(out)
+    out[len(head)] += d if len(out) > 2 * len(head) else 0
+    if len(out) == 2 * len(head):
+        out[len(head) - 1] += d
+    return [v for v in out if v > 0]
+
+
+SCHEDULE = {"ramp": 1}
+
+
 def build(N, tile, nt, chunk, pipe, graph, lat, delta):
     """Tasks of one sweep for every rank.  graph[r] = ranks upstream of r (it receives their boundary discharge)."""
     nr, nc = tile
@@ -70,6 +102,8 @@ def build(N, tile, nt, chunk, pipe, graph, lat, delta):
 
     def subs(c):
         T = min(chunk, nt - c * chunk)
+        if SCHEDULE["ramp"] > 1:
+            return ramp_schedule(T, pipe, SCHEDULE["ramp"])
         n = max(1, (T + pipe // 2) // pipe)
         tp = -(-T // n)
         return [min(tp, T - j * tp) for j in range(n)]
