@@ -30,11 +30,15 @@ CS = 9.185525760e9            # cell-steps of the 1024^2 x 8760 case: the unit t
 # measured kernel times, ms per CS cell-steps (profiles/r3_rocprofv3_kernel_stats_2048.csv: launches of 2192 steps x 4.19 M cells;
 # profiles/r2_rocprofv3_kernel_stats.csv for the store-all 1024^2 case)
 RATES = {
-    "vf_u": 29.9, "vf_t": 35.7, "va": 64.5,                  # vertical: forward untaped / taped, reverse (hi tape on)
-    "r0f_u": 8.27, "r0f_t": 12.9, "r0a": 15.5,               # round 0 at 548 time blocks per launch (2048^2), forward untaped / taped, reverse
+    "vf_u": 28.6, "vf_t": 35.6, "va": 63.2,                  # vertical: forward untaped / taped, reverse (hi tape on) -- final round-3 build
+    "r0f_u": 8.68, "r0f_t": 13.94, "r0a": 17.0,              # round 0 at 548 time blocks per launch (2048^2), forward untaped / taped, reverse
     "r0_nb_ref": 548, "r0_depth": 160,                       # ... whose groups are up to 160 stages deep: a launch of nb blocks runs nb + depth super-steps
-    "tau_f": 1.434e-3, "tau_a": 1.788e-3,                    # ms per super-step of a chained launch (1024^2: 7.3 / 9.1 ms for 2190 blocks + 2900 stages)
+    "tau_f": 1.366e-3, "tau_a": 1.658e-3,                    # ms per super-step of a chained launch (2048^2: 8.3 / 10.1 ms for 548 blocks + 5530 stages)
     "path_per_side": 1.35,                                   # longest cell path of a tile ~ 1.35 x (rows + cols) stages (2900 at 1024^2, 5250 at 2048^2)
+    # ... except where the chained launches of the very tile were timed (per-round timelines, --trace-groups): the 2048 x 1024 tile of
+    # the 8-rank split has 7 routing rounds and its chained launch of a 1104-step sub-chunk takes 2.7 ms forward / 3.2 ms reverse
+    # = 276 blocks + ~1680 stages (the rule above would say 4147 and made the model 11 % pessimistic on that tile's sub-chunks)
+    "path_measured": {(2048, 1024): 1680.0},
 }
 
 
@@ -84,7 +88,7 @@ def build(N, tile, nt, chunk, pipe, graph, lat, delta):
     nr, nc = tile
     cells = nr * nc
     nch = -(-nt // chunk)
-    P = RATES["path_per_side"] * (nr + nc)
+    P = RATES["path_measured"].get((nr, nc), RATES["path_per_side"] * (nr + nc))
     down = {r: [s for s in range(N) if r in graph[s]] for r in range(N)}
     tasks = []
     last = {}            # (rank, stream) -> last task queued on that stream
@@ -255,14 +259,14 @@ def sweep_ms(N, pr, pc, tile, nt, chunk, pipe, shared, p):
 
 # measurements the model is held to: (label, N, pr, pc, tile, chunk, pipe, shared GPU, measured ms, source)
 MEASURED = [
-    ("solo 2048x1024 tile, no sub-chunks", 1, 1, 1, (2048, 1024), 4384, 4384, True, 336.2, "profiles/r3_solo_rank0_pipe4384_before.json"),
-    ("solo 2048x1024 tile, sub-chunks of 2192", 1, 1, 1, (2048, 1024), 4384, 2192, True, 344.1, "profiles/r3_solo_rank0_pipe2192_before.json"),
-    ("solo 2048x1024 tile, sub-chunks of 1104", 1, 1, 1, (2048, 1024), 4384, 1104, True, 357.2, "profiles/r3_bench_2048x2048x8760_first.json (tile_solo 363.8), r3c run 357.2"),
-    ("2048^2 single domain, 4 storage chunks", 1, 1, 1, (2048, 2048), 2192, 2192, True, 738.0, "gpurun r3b (hi tape kept)"),
-    ("1024^2 single domain, store-all", 1, 1, 1, (1024, 1024), 8768, 8768, True, 161.5, "profiles/r3_bench_2048x2048x8760_first.json (secondary)"),
-    ("rehearsal: 2 ranks on ONE GPU, 1x2 tiles of 1024x512", 2, 1, 2, (1024, 512), 8768, 2192, True, 164.3, "profiles/r2_rehearsal_2ranks_one_gpu.json"),
-    ("rehearsal: 4 ranks on ONE GPU, 2x2 tiles of 512x512", 4, 2, 2, (512, 512), 8768, 2192, True, 172.5, "profiles/r2_rehearsal_4ranks_one_gpu.json"),
-    ("rehearsal: 6 ranks on ONE GPU, 1x6 tiles of 1024x176", 6, 1, 6, (1024, 176), 8768, 1104, True, 260.6, "profiles/r2_rehearsal_6ranks_one_gpu.json"),
+    ("solo 2048x1024 tile, no sub-chunks", 1, 1, 1, (2048, 1024), 4384, 4384, True, 319.5, "profiles/r3_solo_rank0_pipe4384.json"),
+    ("solo 2048x1024 tile, sub-chunks of 2192", 1, 1, 1, (2048, 1024), 4384, 2192, True, 327.5, "profiles/r3_solo_rank0_pipe2192.json"),
+    ("solo 2048x1024 tile, sub-chunks of 1104", 1, 1, 1, (2048, 1024), 4384, 1104, True, 342.2, "profiles/r3_solo_rank0_pipe1104.json"),
+    ("2048^2 single domain, 4 storage chunks", 1, 1, 1, (2048, 2048), 2192, 2192, True, 726.0, "profiles/r3_bench_2048x2048x8760*.json (716-733)"),
+    ("1024^2 single domain, store-all", 1, 1, 1, (1024, 1024), 8768, 8768, True, 151.6, "profiles/r3_bench_2048x2048x8760.json (secondary 150.5-152.7)"),
+    ("rehearsal: 2 ranks on ONE GPU, 1x2 tiles of 1024x512", 2, 1, 2, (1024, 512), 8768, 2192, True, 157.4, "profiles/r3_rehearsal_2ranks_one_gpu.json"),
+    ("rehearsal: 4 ranks on ONE GPU, 2x2 tiles of 512x512", 4, 2, 2, (512, 512), 8768, 2192, True, 159.8, "profiles/r3_rehearsal_4ranks_one_gpu.json"),
+    ("rehearsal: 6 ranks on ONE GPU, 1x6 tiles of 1024x176", 6, 1, 6, (1024, 176), 8768, 1104, True, 259.5, "profiles/r3_rehearsal_6ranks_one_gpu.json"),
 ]
 
 
@@ -284,7 +288,7 @@ def main():
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     score, p, err = fit()
-    rep = {"what": __doc__.split("\n\n")[0], "rates_ms_per_9.19e9_cellsteps": RATES, "fitted": p, "rms_relative_error": score, "validation": [], "prediction": []}
+    rep = {"what": __doc__.split("\n\n")[0], "rates_ms_per_9.19e9_cellsteps": {k: (v if not isinstance(v, dict) else {str(a): b for a, b in v.items()}) for k, v in RATES.items()}, "fitted": p, "rms_relative_error": score, "validation": [], "prediction": []}
     for (label, N, pr, pc, tile, chunk, pipe, shared, ms, src), e in zip(MEASURED, err):
         rep["validation"].append({"case": label, "measured_ms": ms, "model_ms": round(ms * (1.0 + e), 1), "error": round(e, 3), "source": src})
     # the metric's decomposition: 2048 x 1024 cells per GPU, 2 storage chunks; N = 1 x 2, 2 x 2, 2 x 4 tiles
