@@ -149,7 +149,8 @@ def main():
         if abs(h["final_cost"] - href["final_cost"]) > 2e-6 * abs(href["final_cost"]):
             bad.append(("final cost", h["final_cost"], href["final_cost"]))
         act = np.asarray(g.mesh.active_cell) == 1
-        for i, k in enumerate(gu.PARAM_NAMES if hasattr(gu, "PARAM_NAMES") else smash_amd.synth.PARAM_NAMES):
+        from smash_amd.synth import PARAM_NAMES
+        for i, k in enumerate(PARAM_NAMES):
             if o.optim_parameters[i] > 0:
                 d = float(np.max(np.abs(getattr(pt, k)[act] - getattr(p1, k)[act])))
                 if d > 1e-4 * float(np.max(np.abs(getattr(p1, k)[act]))):
