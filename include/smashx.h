@@ -315,6 +315,8 @@ typedef struct smashx_lbfgsb smashx_lbfgsb;
 int smashx_lbfgsb_create(long n, int m, const double* lower, const double* upper, double factr, double pgtol, smashx_lbfgsb** out);
 int smashx_lbfgsb_step(smashx_lbfgsb* opt, double* x, double f, const double* g, int* task);
 long smashx_lbfgsb_iterations(const smashx_lbfgsb* opt);
+long smashx_lbfgsb_evaluations(const smashx_lbfgsb* opt);              /* f / g evaluations so far (isave(34) of lbfgsb.f) */
+double smashx_lbfgsb_projected_gradient(const smashx_lbfgsb* opt);     /* infinity norm of the projected gradient at the last iterate (dsave(13)) */
 const char* smashx_lbfgsb_message(const smashx_lbfgsb* opt);
 int smashx_lbfgsb_destroy(smashx_lbfgsb* opt);
 

@@ -60,6 +60,28 @@ build_dropin () {
   echo "built $OUT/libsmash_dropin.so"
 }
 build_dropin
+
+# The same two libraries with `setulb` of lbfgsb.f replaced by fortran/smashx_setulb.f90 (the library's own L-BFGS-B behind the
+# reference's argument list): the reference's setulb_ is weakened in a copy of lbfgsb.o, the shim's definition takes over, and
+# mw_optimize's loop runs unchanged.  libsmash_ref_lbfgsb.so = all-CPU reference + that optimiser (CPU tests: the golden cost
+# trajectory), libsmash_dropin_lbfgsb.so = GPU sweeps + that optimiser (the whole calibration on the new library).
+build_native_lbfgsb () {
+  local repo OC=/opt/rocm/lib/llvm/bin/llvm-objcopy
+  repo="$(cd "$HERE/../.." && pwd)"
+  [ -f "$repo/smash_amd/libsmashx.so" ] || { echo "build_ref: libsmashx.so not built yet, skipping the setulb variants"; return 0; }
+  for pair in "obj_parity:obj_parity_lb:libsmash_ref_lbfgsb.so" "obj_dropin:obj_dropin_lb:libsmash_dropin_lbfgsb.so"; do
+    IFS=: read -r src dst lib <<< "$pair"
+    [ -d "$OUT/$src" ] || continue
+    rm -rf "$OUT/$dst"; mkdir -p "$OUT/$dst"
+    cp "$OUT/$src"/*.o "$OUT/$src"/*.mod "$OUT/$dst"/
+    $OC --weaken-symbol=setulb_ "$OUT/$dst/lbfgsb.o"
+    $FC -cpp -O2 -ffp-contract=off -fPIC -c "$repo/fortran/smashx_setulb.f90" -o "$OUT/$dst/smashx_setulb.o"
+    $FC -shared -o "$OUT/$lib" "$OUT/$dst/smashx_setulb.o" $(ls "$OUT/$dst"/*.o | grep -v smashx_setulb.o) \
+        -L"$repo/smash_amd" -lsmashx -Wl,-rpath,'$ORIGIN/../../smash_amd'
+    echo "built $OUT/$lib"
+  done
+}
+build_native_lbfgsb
 if [ "${REF_FAST:-1}" = "1" ]; then
   build_variant obj_fast   libsmash_ref_fast.so -O3 -march=x86-64-v3 -funroll-loops
 fi

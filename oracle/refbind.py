@@ -27,7 +27,8 @@ GUB_S = np.array([0.999999] * 7 + [10000.0], dtype=np.float32)
 def lib_path(fast=False) -> str:
     """fast: False -> parity build (-O2 -ffp-contract=off); True -> the reference's own optimisation level;
     "dropin" -> the reference with base_forward/base_forward_b replaced by fortran/smashx_dropin.f90 (GPU)."""
-    name = {False: "libsmash_ref.so", True: "libsmash_ref_fast.so", "dropin": "libsmash_dropin.so"}[fast]
+    name = {False: "libsmash_ref.so", True: "libsmash_ref_fast.so", "dropin": "libsmash_dropin.so",
+            "ref_lbfgsb": "libsmash_ref_lbfgsb.so", "dropin_lbfgsb": "libsmash_dropin_lbfgsb.so"}[fast]
     return os.path.join(_HERE, "_ref", name)
 
 

@@ -25,6 +25,7 @@ SYMBOLS = [
     "smashx_comm_unique_id", "smashx_comm_create", "smashx_comm_destroy", "smashx_comm_allreduce_sum", "smashx_set_exchange",
     "smashx_set_median_slots", "smashx_selftest_paths",
     "smashx_lbfgsb_create", "smashx_lbfgsb_step", "smashx_lbfgsb_destroy", "smashx_lbfgsb_iterations", "smashx_lbfgsb_message",
+    "smashx_lbfgsb_evaluations", "smashx_lbfgsb_projected_gradient",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
@@ -97,9 +98,11 @@ def lib():
             getattr(L, s).restype = C.c_int
         L.smashx_lbfgsb_message.restype = C.c_char_p
         L.smashx_lbfgsb_iterations.restype = C.c_long
+        L.smashx_lbfgsb_evaluations.restype = C.c_long
+        L.smashx_lbfgsb_projected_gradient.restype = C.c_double
         L.smashx_lbfgsb_create.argtypes = [C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_void_p)]
         L.smashx_lbfgsb_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
-        for s in ("smashx_lbfgsb_destroy", "smashx_lbfgsb_iterations", "smashx_lbfgsb_message"):
+        for s in ("smashx_lbfgsb_destroy", "smashx_lbfgsb_iterations", "smashx_lbfgsb_message", "smashx_lbfgsb_evaluations", "smashx_lbfgsb_projected_gradient"):
             getattr(L, s).argtypes = [C.c_void_p]
         _lib = L
     return _lib

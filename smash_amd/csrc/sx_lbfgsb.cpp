@@ -643,5 +643,7 @@ int smashx_lbfgsb_step(smashx_lbfgsb* o, double* x, double f, const double* g, i
 }
 
 long smashx_lbfgsb_iterations(const smashx_lbfgsb* o) { return o ? o->iter : 0; }
+long smashx_lbfgsb_evaluations(const smashx_lbfgsb* o) { return o ? o->total_fev : 0; }
+double smashx_lbfgsb_projected_gradient(const smashx_lbfgsb* o) { return o ? o->sbgnrm : 0.0; }
 
 }  // extern "C"

@@ -65,6 +65,28 @@ def test_reference_lbfgsb_loop_through_dropin():
     assert abs(costs[-1] - ref[-1]) <= 0.02 * abs(ref[0]), (costs, ref)
 
 
+def test_reference_calibration_entirely_on_the_library():
+    """The reference's optimize_lbfgsb with BOTH halves replaced: GPU forward / forward_b sweeps through fortran/smashx_dropin.f90 and
+    `setulb` through fortran/smashx_setulb.f90 (the library's own L-BFGS-B): oracle/_ref/libsmash_dropin_lbfgsb.so.  Against the same
+    loop on the reference's lbfgsb.f (libsmash_dropin.so): the sweeps are the same deterministic kernels, so the costs agree to the
+    rounding of the optimiser's inner products."""
+    from smash_amd import synth
+    if not refbind.available("dropin_lbfgsb"):
+        pytest.skip("oracle/_ref/libsmash_dropin_lbfgsb.so not built")
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "opt_gr_b_24x24x120.npz"))
+    g = gu.load("gr_b_24x24x120_norm_jreg")
+    P = synth.make_parameters(24, 24)
+    S = synth.make_states(24, 24, warm=True)
+    for it in (1, 4):
+        kw = dict(optimize_maxiter=it, optim_parameters=z["optim_parameters"], jobs_fun=("nse",), wjobs_fun=(1.0,))
+        a = refbind.run("gr-b", g.mesh, g.dt, g.prcp, g.pet, z["qobs"], P, S, fast="dropin", **kw)
+        b = refbind.run("gr-b", g.mesh, g.dt, g.prcp, g.pet, z["qobs"], P, S, fast="dropin_lbfgsb", **kw)
+        assert abs(a["cost"] - b["cost"]) <= 1e-6 * abs(a["cost"]), (it, a["cost"], b["cost"])
+        for k in ("cp", "cft", "exc", "lr"):
+            if k in a.get("parameters", {}):
+                assert np.max(np.abs(a["parameters"][k] - b["parameters"][k])) <= 1e-4 * np.max(np.abs(a["parameters"][k])), k
+
+
 def test_reference_lbfgsb_on_cance_through_dropin():
     """The user guide's distributed calibration on the real Cance data (real_case_cance.rst:470-552): the reference's
     optimize_lbfgsb over cp, cft, exc, lr from the uniform SBS optimum, GPU sweeps through the drop-in, against the

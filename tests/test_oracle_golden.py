@@ -173,3 +173,22 @@ def test_fp64_truth_oracle_agrees_with_the_fp32_oracle_to_rounding():
     for k in ("cp", "cft", "exc", "lr"):
         e = gu.rel_l2(r32["parameters_b"][k], r64["parameters_b"][k])
         assert 1e-8 < e < 1e-3, (k, e)        # close, and not identical: the fp32 program's own rounding error is what is measured
+
+
+def test_reference_optimize_lbfgsb_on_the_library_setulb():
+    """fortran/smashx_setulb.f90: `setulb` of the reference's lbfgsb.f (argument list, task strings, isave(30) / isave(34) /
+    dsave(13)) on top of the library's own L-BFGS-B.  oracle/_ref/libsmash_ref_lbfgsb.so is the unmodified reference with only that
+    one symbol replaced (oracle/ref/build_ref.sh): its own mw_optimize::optimize_lbfgsb loop, all on the CPU, must walk the golden
+    cost trajectory (tests/golden/lbfgsb, made with the reference's lbfgsb.f) -- bit for bit, 0 to 4 iterations."""
+    import os
+    from oracle import refbind
+    from smash_amd import synth
+    if not refbind.available("ref_lbfgsb"):
+        pytest.skip("oracle/_ref/libsmash_ref_lbfgsb.so not built")
+    z = np.load(os.path.join(gu.GOLDEN_DIR, "lbfgsb", "opt_gr_b_24x24x120.npz"))
+    g = gu.load("gr_b_24x24x120_norm_jreg")
+    P, S = synth.make_parameters(24, 24), synth.make_states(24, 24, warm=True)
+    for it, ref in zip(z["maxiters"], z["costs"]):
+        r = refbind.run("gr-b", g.mesh, g.dt, g.prcp, g.pet, z["qobs"], P, S, optimize_maxiter=int(it),
+                        optim_parameters=z["optim_parameters"], jobs_fun=("nse",), wjobs_fun=(1.0,), fast="ref_lbfgsb")
+        assert np.float32(r["cost"]) == np.float32(ref), (int(it), r["cost"], float(ref))
