@@ -323,6 +323,13 @@ SX_HD SxPowBase sx_powbase(float x) {
 #endif
     return B;
 }
+SX_HD SxPowBase sx_powbase_one() {       // the base 1 (log2 = 0) without evaluating anything: a placeholder for a base that is not raised
+    SxPowBase B; B.x = 1.f;
+#if !SX_EXACT_LIBM
+    B.L.l2 = 0.0; B.L.special = 0;
+#endif
+    return B;
+}
 SX_HD float sx_powb(const SxPowBase& B, float y) {
 #if SX_EXACT_LIBM
     return sx_powf(B.x, y);

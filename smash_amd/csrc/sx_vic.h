@@ -32,7 +32,13 @@ SX_DEV void sx_vic_derive(SxVicParams& P) {
 struct SxVicGrads { float b_b, cusl1_b, cusl2_b, clsl_b, ks_b, ds_b, dsm_b, ws_b, husl1_b, husl2_b, hlsl_b; };
 
 // ---------------------------------------------------------------- forward
-SX_DEV void sx_vic_infiltration(const SxVicParams& P, float prcp, float cusl1, float cusl2, float b, float& husl1, float& husl2, float& runoff) {
+// What the forward infiltration of a reverse step hands to its adjoint (round 3): the two bases' logarithms and the two powers.  The
+// adjoint used to evaluate all of them again (and x**y a second time inside d/dy): 4 log2 + 8 exp2 in fp64 per rain step instead of
+// 2 + 4.  Same values by construction -- sx_powb is a pure function of (base, exponent).
+struct SxVicInfKeep { SxPowBase B1, B2; float pwr1a, pwr1b; };
+template <bool KEEP>
+SX_DEV void sx_vic_infiltration_k(const SxVicParams& P, float prcp, float cusl1, float cusl2, float b, float& husl1, float& husl2, float& runoff,
+                                  SxVicInfKeep& K) {
     const float bp1 = b + 1.f;
     float ifl;
     if (prcp <= 0.f) ifl = 0.f;
@@ -42,9 +48,17 @@ SX_DEV void sx_vic_infiltration(const SxVicParams& P, float prcp, float cusl1, f
         wusl = fmaxf(1.e-6f, wusl);
         wusl = fminf(cusl - 1e-6f, wusl);
         const float iflm = cusl * bp1;
-        const float iflc = iflm * (1.f - sx_powf(1.f - (sx_fdiv(wusl, cusl)), sx_fdiv(1.f, bp1)));
+        const SxPowBase B1 = sx_powbase(1.f - (sx_fdiv(wusl, cusl)));
+        const float pa = sx_powb(B1, sx_fdiv(1.f, bp1));
+        if (KEEP) { K.B1 = B1; K.pwr1a = pa; }
+        const float iflc = iflm * (1.f - pa);
         if (iflc + prcp >= iflm) ifl = cusl - wusl;
-        else ifl = (cusl - wusl) - cusl * sx_powf(1.f - (sx_fdiv((iflc + prcp), iflm)), bp1);
+        else {
+            const SxPowBase B2 = sx_powbase(1.f - (sx_fdiv((iflc + prcp), iflm)));
+            const float pb = sx_powb(B2, bp1);
+            if (KEEP) { K.B2 = B2; K.pwr1b = pb; }
+            ifl = (cusl - wusl) - cusl * pb;
+        }
         ifl = fminf(prcp, ifl);
     }
     const float ifl_usl1 = fminf((1.f - husl1) * cusl1, ifl);
@@ -54,6 +68,10 @@ SX_DEV void sx_vic_infiltration(const SxVicParams& P, float prcp, float cusl1, f
     husl1 = husl1 + sx_div(ifl_usl1, P.d1);
     husl2 = husl2 + sx_div(ifl_usl2, P.d2);
     runoff = prcp - (ifl_usl1 + ifl_usl2);
+}
+SX_DEV void sx_vic_infiltration(const SxVicParams& P, float prcp, float cusl1, float cusl2, float b, float& husl1, float& husl2, float& runoff) {
+    SxVicInfKeep K;
+    sx_vic_infiltration_k<false>(P, prcp, cusl1, cusl2, b, husl1, husl2, runoff, K);
 }
 
 // residual = 0, porosity = 1, lambda = 1 at both call sites (md_vic_operator.f90:94,99): pwx1 = h_upper / 1, pwx1**1 = pwx1
@@ -118,10 +136,10 @@ SX_DEV float sx_pow_guard_b(float x, float y, float r_b) {
     return y * sx_powf(x, y - 1.f) * r_b;
 }
 
-SX_DEV void sx_vic_infiltration_b(const SxVicParams& P, float prcp, float cusl1, float cusl2, float b, float husl1, float husl2, float runoff_b, SxVicGrads& G) {
-    float bp1 = b + 1.f, ifl, cusl = 0.f, wusl = 0.f, iflm = 0.f, iflc = 0.f, pwx1 = 0.f, pwy1 = 0.f, pwr1 = 0.f, pwr1_first = 0.f;
+// K: from sx_vic_infiltration_k<true> on the same (prcp, husl1, husl2)
+SX_DEV void sx_vic_infiltration_b(const SxVicParams& P, const SxVicInfKeep& K, float prcp, float cusl1, float cusl2, float b, float husl1, float husl2, float runoff_b, SxVicGrads& G) {
+    float bp1 = b + 1.f, ifl, cusl = 0.f, wusl = 0.f, iflm = 0.f, iflc = 0.f, pwx1 = 0.f, pwy1 = 0.f, pwr1 = 0.f, pwr1_first = 0.f, pwr1_second = 0.f;
     int c_prcp, c_w1 = 0, c_w2 = 0, c_full = 0, c_min;
-    SxPowBase B1 = sx_powbase(1.f), B2 = B1;
     if (prcp <= 0.f) { ifl = 0.f; c_prcp = 0; c_min = 0; }
     else {
         c_prcp = 1;
@@ -132,15 +150,14 @@ SX_DEV void sx_vic_infiltration_b(const SxVicParams& P, float prcp, float cusl1,
         iflm = cusl * bp1;
         pwx1 = 1.f - sx_fdiv(wusl, cusl);
         pwy1 = sx_fdiv(1.f, bp1);
-        B1 = sx_powbase(pwx1);                     // one logarithm per base: the adjoint below raises each base three times
-        pwr1 = sx_powb(B1, pwy1);
+        pwr1 = K.pwr1a;                            // sx_powb(K.B1, pwy1), K.B1 = sx_powbase(pwx1): evaluated by the forward part of this step
         iflc = iflm * (1.f - pwr1);
         if (iflc + prcp >= iflm) { ifl = cusl - wusl; c_full = 1; }
         else {
             pwx1 = 1.f - sx_fdiv((iflc + prcp), iflm);
             pwr1_first = pwr1;
-            B2 = sx_powbase(pwx1);
-            pwr1 = sx_powb(B2, bp1);
+            pwr1 = K.pwr1b;                        // sx_powb(K.B2, bp1), K.B2 = sx_powbase(pwx1)
+            pwr1_second = pwr1;
             ifl = cusl - wusl - cusl * pwr1;
             c_full = 0;
         }
@@ -179,9 +196,9 @@ SX_DEV void sx_vic_infiltration_b(const SxVicParams& P, float prcp, float cusl1,
             pwr1_b = -(cusl * ifl_b);
             pwr1 = pwr1_first;
             if (pwx1 <= 0.0f && (bp1 == 0.0f || bp1 != (float)(int)bp1)) pwx1_b = 0.f;
-            else pwx1_b = bp1 * sx_powb(B2, bp1 - 1.f) * pwr1_b;
+            else pwx1_b = bp1 * sx_powb(K.B2, bp1 - 1.f) * pwr1_b;
             if (pwx1 <= 0.0f) bp1_b = 0.f;
-            else bp1_b = sx_powb(B2, bp1) * sx_logb(B2) * pwr1_b;
+            else bp1_b = pwr1_second * sx_logb(K.B2) * pwr1_b;          // pwx1**bp1 is the forward value
             iflc_b = -(sx_fdiv(pwx1_b, iflm));
             iflm_b = sx_fdiv((prcp + iflc) * pwx1_b, iflm * iflm);
             pwy1 = sx_fdiv(1.f, bp1);
@@ -196,9 +213,9 @@ SX_DEV void sx_vic_infiltration_b(const SxVicParams& P, float prcp, float cusl1,
         iflm_b = iflm_b + (1.f - pwr1) * iflc_b;
         pwr1_b = -(iflm * iflc_b);
         if (pwx1 <= 0.0f && (pwy1 == 0.0f || pwy1 != (float)(int)pwy1)) pwx1_b = 0.f;
-        else pwx1_b = pwy1 * sx_powb(B1, pwy1 - 1.f) * pwr1_b;
+        else pwx1_b = pwy1 * sx_powb(K.B1, pwy1 - 1.f) * pwr1_b;
         if (pwx1 <= 0.0f) pwy1_b = 0.f;
-        else pwy1_b = sx_powb(B1, pwy1) * sx_logb(B1) * pwr1_b;
+        else pwy1_b = pwr1 * sx_logb(K.B1) * pwr1_b;                      // pwx1**pwy1 is the forward value (pwr1 holds it here)
         bp1_b = bp1_b + cusl * iflm_b - sx_fdiv(pwy1_b, bp1 * bp1);
         wusl_b = wusl_b - sx_fdiv(pwx1_b, cusl);
         cusl_b = cusl_b + sx_fdiv(wusl * pwx1_b, cusl * cusl) + bp1 * iflm_b;
@@ -351,8 +368,10 @@ SX_DEV void sx_vic_step_b(const SxVicParams& P, float cusl2_m4, float cusl2_m5, 
     const bool wet = (prcp >= 0.f && pet >= 0.f);
     float h1 = husl1, h2 = husl2, hl = hlsl, runoff = 0.f;
     float h1_1 = h1, h2_1 = h2;
+    SxVicInfKeep K;
+    K.B1 = sx_powbase_one(); K.B2 = K.B1; K.pwr1a = 0.f; K.pwr1b = 0.f;
     if (wet) {
-        sx_vic_infiltration(P, prcp, P.cusl1, P.cusl2, P.b, h1, h2, runoff);
+        sx_vic_infiltration_k<true>(P, prcp, P.cusl1, P.cusl2, P.b, h1, h2, runoff, K);
         h1_1 = h1; h2_1 = h2;
         sx_vic_vertical_transfer(P, pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1, h2, hl);
     }
@@ -360,7 +379,7 @@ SX_DEV void sx_vic_step_b(const SxVicParams& P, float cusl2_m4, float cusl2_m5, 
     sx_vic_interflow_b(P, P.cusl2, cusl2_m4, cusl2_m5, h2, qt_b, G);
     if (wet) {
         sx_vic_vertical_transfer_b(P, pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1_1, h2_1, hlsl, G);
-        sx_vic_infiltration_b(P, prcp, P.cusl1, P.cusl2, P.b, husl1, husl2, qt_b, G);
+        sx_vic_infiltration_b(P, K, prcp, P.cusl1, P.cusl2, P.b, husl1, husl2, qt_b, G);
     }
 }
 
