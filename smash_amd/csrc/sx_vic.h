@@ -84,21 +84,56 @@ SX_DEV float sx_brooks_corey(float ks, float c_upper, float c_lower, float h_upp
 }
 SX_DEV float sx_linear_evap(float e, float c, float h) { return fminf(c * h, e * h); }
 
-SX_DEV void sx_vic_vertical_transfer(const SxVicParams& P, float pet, float cusl1, float cusl2, float clsl, float ks, float& husl1, float& husl2, float& hlsl) {
+// Steps without evaporative demand (pet = 0: every night hour of the reference's hourly PET disaggregation, core/_constant.py:47-75)
+// leave the three linear_evapotranspiration stages with nothing to do when the layers hold water: fe = min(c h, 0 h) = +0, the level
+// keeps its value (h - (+0) / c), pet_remain stays 0.  When that holds on EVERY lane of the wavefront (a ballot, a scalar branch,
+// nothing is predicated) the stages are skipped, forward and reverse -- the general code with the zeros carried through by hand: in
+// VIC_VERTICAL_TRANSFER_B every term of the three stages is then a product with fe = 0 or with w_b = 0 (c h > 0 = e h), br1 = br2 = 1
+// zero pet_remain_b: the gradients keep their values (only the sign of a zero gradient, or a NaN the general code would have spread
+// from an already infinite adjoint, can differ -- as for the still steps of the GR structures, sx_ops.h).
+//   needs, per lane: pet == 0 and husl1, husl2, hlsl > 0 after the two brooks_and_corey exchanges (h = 0 takes the general code: there
+//   c h > e h fails and linear_evapotranspiration_b routes the adjoint through w = c h).
+#ifndef SX_VIC_NIGHT
+#define SX_VIC_NIGHT 1
+#endif
+// what the forward vertical transfer of a reverse step hands to its adjoint (the levels each operator saw, the flows, the branches)
+struct SxVicVT { float h1_0, h2_0, hl_0, fbc1, h2_1, fbc2, h1_2, h2_2, hl_2, fe1, fe2, fe3, pr1, pr2; bool br1, br2, night; };
+template <bool KEEP>
+SX_DEV void sx_vic_vertical_transfer_k(const SxVicParams& P, float pet, float cusl1, float cusl2, float clsl, float ks, float& husl1, float& husl2,
+                                       float& hlsl, SxVicVT& K) {
+    if (KEEP) { K.h1_0 = husl1; K.h2_0 = husl2; K.hl_0 = hlsl; }
     float fbc = sx_brooks_corey(ks, cusl1, cusl2, husl1, husl2);
+    if (KEEP) K.fbc1 = fbc;
     husl1 = husl1 - sx_div(fbc, P.d1);
     husl2 = husl2 + sx_div(fbc, P.d2);
+    if (KEEP) K.h2_1 = husl2;
     fbc = sx_brooks_corey(ks, cusl2, clsl, husl2, hlsl);
+    if (KEEP) K.fbc2 = fbc;
     husl2 = husl2 - sx_div(fbc, P.d2);
     hlsl = hlsl + sx_div(fbc, P.dl);
+    if (KEEP) { K.h1_2 = husl1; K.h2_2 = husl2; K.hl_2 = hlsl; K.fe1 = 0.f; K.fe2 = 0.f; K.fe3 = 0.f; K.pr1 = 0.f; K.pr2 = 0.f; K.br1 = true; K.br2 = true; }
+    // (the reverse step only: in the forward kernel the three stages are ~25 instructions and the test costs what it saves --
+    // measured 47.0 -> 47.5 ms with it; the two forms give the same bits, so the kernels need not agree on which one runs)
+    const bool night = SX_VIC_NIGHT && KEEP && __builtin_amdgcn_ballot_w64(!(pet == 0.f && husl1 > 0.f && husl2 > 0.f && hlsl > 0.f)) == 0ull;   // over the active lanes
+    if (KEEP) K.night = night;
+    if (night) return;
     float fe = sx_linear_evap(pet, cusl1, husl1);
     husl1 = husl1 - sx_div(fe, P.d1);
-    float pet_remain = fmaxf(0.f, pet - fe);
+    float pet_remain;
+    if (KEEP) { K.fe1 = fe; K.br1 = !(0.f < pet - fe); }
+    pet_remain = fmaxf(0.f, pet - fe);
+    if (KEEP) K.pr1 = (0.f < pet - fe) ? pet - fe : 0.f;
     fe = sx_linear_evap(pet_remain, cusl2, husl2);
     husl2 = husl2 - sx_div(fe, P.d2);
+    if (KEEP) { K.fe2 = fe; K.br2 = !(0.f < pet_remain - fe); K.pr2 = (0.f < pet_remain - fe) ? pet_remain - fe : 0.f; }
     pet_remain = fmaxf(0.f, pet_remain - fe);
     fe = sx_linear_evap(pet_remain, clsl, hlsl);
+    if (KEEP) K.fe3 = fe;
     hlsl = hlsl - sx_div(fe, P.dl);
+}
+SX_DEV void sx_vic_vertical_transfer(const SxVicParams& P, float pet, float cusl1, float cusl2, float clsl, float ks, float& husl1, float& husl2, float& hlsl) {
+    SxVicVT K;
+    sx_vic_vertical_transfer_k<false>(P, pet, cusl1, cusl2, clsl, ks, husl1, husl2, hlsl, K);
 }
 
 SX_DEV void sx_vic_interflow(const SxVicParams& P, float cusl2, float cusl2_m4, float& husl2, float& qi) {   // n = 5
@@ -263,40 +298,28 @@ SX_DEV void sx_linear_evap_b(float e, float& e_b, float c, float& c_b, float h, 
     e_b = e_b + h * flow_b;
 }
 
-// husl1, husl2, hlsl: the levels on entry of vic_vertical_transfer
-SX_DEV void sx_vic_vertical_transfer_b(const SxVicParams& P, float pet, float cusl1, float cusl2, float clsl, float ks, float husl1, float husl2, float hlsl,
-                                       SxVicGrads& G) {
-    const float h1_0 = husl1, h2_0 = husl2;
-    const float fbc1 = sx_brooks_corey(ks, cusl1, cusl2, husl1, husl2);
-    husl1 = husl1 - sx_div(fbc1, P.d1);
-    husl2 = husl2 + sx_div(fbc1, P.d2);
-    const float h2_1 = husl2, hl_1 = hlsl;
-    const float fbc2 = sx_brooks_corey(ks, cusl2, clsl, husl2, hlsl);
-    husl2 = husl2 - sx_div(fbc2, P.d2);
-    hlsl = hlsl + sx_div(fbc2, P.dl);
-    const float h1_2 = husl1, h2_2 = husl2, hl_2 = hlsl;
-    const float fe1 = sx_linear_evap(pet, cusl1, husl1);
-    float pet_remain1, pet_remain2;
-    int br1, br2;
-    if (0.f < pet - fe1) { pet_remain1 = pet - fe1; br1 = 0; } else { pet_remain1 = 0.f; br1 = 1; }
-    const float fe2 = sx_linear_evap(pet_remain1, cusl2, h2_2);
-    if (0.f < pet_remain1 - fe2) { pet_remain2 = pet_remain1 - fe2; br2 = 0; } else { pet_remain2 = 0.f; br2 = 1; }
-    const float fe3 = sx_linear_evap(pet_remain2, clsl, hl_2);
-    float fe_b = -(sx_div(G.hlsl_b, P.dl));
-    G.clsl_b = G.clsl_b + sx_div(fe3 * G.hlsl_b, P.dll);
-    float pet_remain_b = 0.f;
-    sx_linear_evap_b(pet_remain2, pet_remain_b, clsl, G.clsl_b, hl_2, G.hlsl_b, fe_b);
-    if (br2 == 0) fe_b = -pet_remain_b;
-    else { pet_remain_b = 0.f; fe_b = 0.f; }
-    fe_b = fe_b - sx_div(G.husl2_b, P.d2);
-    G.cusl2_b = G.cusl2_b + sx_div(fe2 * G.husl2_b, P.d22);
-    sx_linear_evap_b(pet_remain1, pet_remain_b, cusl2, G.cusl2_b, h2_2, G.husl2_b, fe_b);
-    if (br1 == 0) fe_b = -pet_remain_b;
-    else fe_b = 0.f;
-    fe_b = fe_b - sx_div(G.husl1_b, P.d1);
-    G.cusl1_b = G.cusl1_b + sx_div(fe1 * G.husl1_b, P.d11);
-    float pet_b = 0.f;
-    sx_linear_evap_b(pet, pet_b, cusl1, G.cusl1_b, h1_2, G.husl1_b, fe_b);
+// K: from sx_vic_vertical_transfer_k<true> on the levels on entry of vic_vertical_transfer
+SX_DEV void sx_vic_vertical_transfer_b(const SxVicParams& P, const SxVicVT& K, float pet, float cusl1, float cusl2, float clsl, float ks, SxVicGrads& G) {
+    const float h1_0 = K.h1_0, h2_0 = K.h2_0, hl_1 = K.hl_0, fbc1 = K.fbc1, h2_1 = K.h2_1, fbc2 = K.fbc2;
+    if (!K.night) {        // wave-uniform
+        const float h1_2 = K.h1_2, h2_2 = K.h2_2, hl_2 = K.hl_2, fe1 = K.fe1, fe2 = K.fe2, fe3 = K.fe3;
+        const float pet_remain1 = K.pr1, pet_remain2 = K.pr2;
+        float fe_b = -(sx_div(G.hlsl_b, P.dl));
+        G.clsl_b = G.clsl_b + sx_div(fe3 * G.hlsl_b, P.dll);
+        float pet_remain_b = 0.f;
+        sx_linear_evap_b(pet_remain2, pet_remain_b, clsl, G.clsl_b, hl_2, G.hlsl_b, fe_b);
+        if (!K.br2) fe_b = -pet_remain_b;
+        else { pet_remain_b = 0.f; fe_b = 0.f; }
+        fe_b = fe_b - sx_div(G.husl2_b, P.d2);
+        G.cusl2_b = G.cusl2_b + sx_div(fe2 * G.husl2_b, P.d22);
+        sx_linear_evap_b(pet_remain1, pet_remain_b, cusl2, G.cusl2_b, h2_2, G.husl2_b, fe_b);
+        if (!K.br1) fe_b = -pet_remain_b;
+        else fe_b = 0.f;
+        fe_b = fe_b - sx_div(G.husl1_b, P.d1);
+        G.cusl1_b = G.cusl1_b + sx_div(fe1 * G.husl1_b, P.d11);
+        float pet_b = 0.f;
+        sx_linear_evap_b(pet, pet_b, cusl1, G.cusl1_b, h1_2, G.husl1_b, fe_b);
+    }
     float fbc_b = sx_div(G.hlsl_b, P.dl) - sx_div(G.husl2_b, P.d2);
     G.clsl_b = G.clsl_b - sx_div(fbc2 * G.hlsl_b, P.dll);
     G.cusl2_b = G.cusl2_b + sx_div(fbc2 * G.husl2_b, P.d22);
@@ -367,18 +390,19 @@ SX_DEV void sx_vic_step_b(const SxVicParams& P, float cusl2_m4, float cusl2_m5, 
                           float qt_b, SxVicGrads& G) {
     const bool wet = (prcp >= 0.f && pet >= 0.f);
     float h1 = husl1, h2 = husl2, hl = hlsl, runoff = 0.f;
-    float h1_1 = h1, h2_1 = h2;
     SxVicInfKeep K;
     K.B1 = sx_powbase_one(); K.B2 = K.B1; K.pwr1a = 0.f; K.pwr1b = 0.f;
+    SxVicVT V;
+    V.h1_0 = V.h2_0 = V.hl_0 = V.fbc1 = V.h2_1 = V.fbc2 = V.h1_2 = V.h2_2 = V.hl_2 = V.fe1 = V.fe2 = V.fe3 = V.pr1 = V.pr2 = 0.f;
+    V.br1 = V.br2 = V.night = true;
     if (wet) {
         sx_vic_infiltration_k<true>(P, prcp, P.cusl1, P.cusl2, P.b, h1, h2, runoff, K);
-        h1_1 = h1; h2_1 = h2;
-        sx_vic_vertical_transfer(P, pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1, h2, hl);
+        sx_vic_vertical_transfer_k<true>(P, pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1, h2, hl, V);
     }
     sx_vic_baseflow_b(P, hl, qt_b, G);
     sx_vic_interflow_b(P, P.cusl2, cusl2_m4, cusl2_m5, h2, qt_b, G);
     if (wet) {
-        sx_vic_vertical_transfer_b(P, pet, P.cusl1, P.cusl2, P.clsl, P.ks, h1_1, h2_1, hlsl, G);
+        sx_vic_vertical_transfer_b(P, V, pet, P.cusl1, P.cusl2, P.clsl, P.ks, G);
         sx_vic_infiltration_b(P, K, prcp, P.cusl1, P.cusl2, P.b, husl1, husl2, qt_b, G);
     }
 }
