@@ -134,7 +134,8 @@ int smashx_plan_ncells(const smashx_plan* plan);
 int smashx_plan_cell_order(const smashx_plan* plan, int* rows, int* cols);
 
 /* forcing: Input_DataDT%prcp/pet (nrow,ncol,nt) [sparse = 0] or %sparse_prcp/pet (nac,nt) numbered along
- * path over active cells [sparse = 1] (mwd_input_data.f90:32-50, mw_sparse_storage.f90:12-49).
+ * path over active cells [sparse = 1] (mwd_input_data.f90:32-50, mw_sparse_storage.f90:12-49); nac counts the WHOLE grid's
+ * active cells, also on a tiled plan (which reads the rows of its own cells at their whole-grid positions).
  * Stays resident in HBM across sweeps. */
 int smashx_set_forcing(smashx_plan* plan, const float* prcp, const float* pet, int sparse);
 /* device-resident block: d_prcp/d_pet are DEVICE pointers to (t1-t0, ncells) arrays, cell index in
@@ -208,8 +209,8 @@ int smashx_control_gradient(smashx_plan* plan, double* g);
  * written at md_forward_structure.f90:158-194 when setup%save_qsim_domain / save_net_prcp_domain): caller-owned host
  * arrays (nrow, ncol, nt) column-major -- inactive cells are set to -99 like OutputDT_initialise does -- or, with
  * sparse != 0, the (nac, nt) sparse_ forms.  They are filled by every following smashx_forward / forward sweep
- * until reset with NULL; adjoint sweeps do not touch them.  A tiled plan fills the cells of its own part in the dense form (-99
- * everywhere else: the caller overlays the parts) and refuses the sparse form, which numbers the whole grid's active cells. */
+ * until reset with NULL; adjoint sweeps do not touch them.  A tiled plan fills the cells of its own part and leaves -99 everywhere
+ * else (the caller overlays the parts), in either form: nac of the sparse form is the whole grid's. */
 int smashx_set_domain_outputs(smashx_plan* plan, float* qsim_domain, float* net_prcp_domain, int sparse);
 
 /* base_forward_d (forward_db.f90:10517-10601), the tangent-linear model behind mw_forward::forward_d

@@ -369,6 +369,7 @@ struct smashx_plan {
     // extra device storage
     int* d_cell_flat = nullptr;      // k -> flat (row + col*nrow)
     int* d_sparse_idx = nullptr;     // k -> index in the sparse (nac) vectors
+    long n_sparse = 0;               // length of a sparse vector = the WHOLE grid's active cells along path (= n on an untiled plan)
     float* d_stage = nullptr;        // staging for full planes
     long stage_planes = 0;
     float* d_fullP[SMASHX_GNP] = {nullptr};
@@ -943,7 +944,7 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         }
         bool ok = true;
         for (int k = 0; k < p->n; ++k) ok &= sp[k] >= 0;
-        if (ok) TRY(p->upload_vec(&p->d_sparse_idx, sp));
+        if (ok) { TRY(p->upload_vec(&p->d_sparse_idx, sp)); p->n_sparse = ind; }
     }
     // parameters, states, routing invariants
     float** pf[NPS] = {&A.ci, &A.cp, &A.cft, &A.cst, &A.exc, &A.lr, &A.px[0], &A.px[1], &A.px[2]};
@@ -1097,7 +1098,9 @@ int smashx_set_forcing(smashx_plan* p, const float* prcp, const float* pet, int 
     if (!p || !prcp || !pet) return fail(SMASHX_E_ARG, "null argument");
     int rc = set_device(p); if (rc) return rc;
     if (sparse && !p->d_sparse_idx) return fail(SMASHX_E_ARG, "sparse forcing needs mesh.path at plan creation");
-    const long plane = sparse ? p->n : p->n2;
+    // a sparse vector is numbered over the whole grid's active cells: on a tiled plan it is longer than the part (the part's cells
+    // keep their whole-grid positions in it)
+    const long plane = sparse ? p->n_sparse : p->n2;
     const int* idx = sparse ? p->d_sparse_idx : p->d_cell_flat;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if ((rc = alloc_forcing(p))) return rc;
@@ -1565,7 +1568,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
         const int t0c = c * p->Tc, Tcur = chunk_len(p, c);
         HIPCHK(hipStreamSynchronize(sV));
         HIPCHK(hipStreamSynchronize(sR));
-        const long plane = p->dom_sparse ? (long)p->n : p->n2;
+        const long plane = p->dom_sparse ? p->n_sparse : p->n2;
         const int* idx = p->dom_sparse ? p->d_sparse_idx : p->d_cell_flat;
         const int nbmax = (int)std::max<long>(1, std::min<long>(p->stage_planes * p->n2 / plane, 1 << 15));
         for (int which = 0; which < 2; ++which) {
@@ -1574,7 +1577,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
             if (!host || !src) continue;
             for (int tl0 = 0; tl0 < Tcur; tl0 += nbmax) {
                 const int nb = std::min(nbmax, Tcur - tl0);
-                if (!p->dom_sparse)
+                if (!p->dom_sparse || p->tiled)      // cells this plan does not write: inactive ones (dense form), other parts' (tiles)
                     hipLaunchKernelGGL(k_fill, dim3((unsigned)(((size_t)nb * plane + 255) / 256)), dim3(256), 0, sV, p->d_stage, -99.f, (size_t)nb * plane);
                 hipLaunchKernelGGL(k_domain_export, dim3((p->n + 255) / 256, nb), dim3(256), 0, sV, p->d_stage, src, idx, p->n, p->npad, plane, tl0, nb);
                 HIPCHK(hipMemcpyAsync(host + (size_t)(t0c + tl0) * plane, p->d_stage, (size_t)nb * plane * 4, hipMemcpyDeviceToHost, sV));
@@ -1764,10 +1767,8 @@ int smashx_set_domain_outputs(smashx_plan* p, float* qsim_domain, float* net_prc
     if (!p) return fail(SMASHX_E_ARG, "null plan");
     if (sparse && !p->d_sparse_idx && (qsim_domain || net_prcp_domain))
         return fail(SMASHX_E_ARG, "sparse domain outputs need mesh.path (the sparse cell numbering)");
-    // a tiled plan fills the cells of its own part (dense form: -99 everywhere else, the caller overlays the parts); the sparse form
-    // numbers the WHOLE grid's active cells, which a part does not hold
-    if (p->tiled && sparse && (qsim_domain || net_prcp_domain))
-        return fail(SMASHX_E_UNSUPPORTED, "sparse whole-domain outputs on a tiled plan (use the dense form: each part fills its own cells)");
+    // a tiled plan fills the cells of its own part and leaves -99 everywhere else (the caller overlays the parts): dense form
+    // (nrow, ncol, nt), or sparse form (nac, nt) with nac the WHOLE grid's active cells -- a part's cells keep their whole-grid numbers
     p->h_qsim_domain = qsim_domain; p->h_net_prcp_domain = net_prcp_domain; p->dom_sparse = sparse ? 1 : 0;
     return 0;
 }

@@ -329,10 +329,13 @@ def test_calibration_over_tiles_follows_the_single_domain(world, with_jreg):
                 assert np.max(np.abs(a - b)) <= 1e-4 * np.max(np.abs(b)), (rank, k, float(np.max(np.abs(a - b))))
 
 
-def test_domain_outputs_of_the_parts_overlay_to_the_single_domain():
+@pytest.mark.parametrize("sparse", [False, True])
+def test_domain_outputs_of_the_parts_overlay_to_the_single_domain(sparse):
     """setup%save_qsim_domain / save_net_prcp_domain (md_forward_structure.f90:158-194) on a decomposition: every part fills the cells
     it owns in the dense (nrow, ncol, nt) arrays and leaves -99 elsewhere; overlaid, the parts give the single domain's arrays bit
-    for bit (forward sweep in storage chunks and pipeline sub-chunks, boundary series through the in-process exchange)."""
+    for bit (forward sweep in storage chunks and pipeline sub-chunks, boundary series through the in-process exchange).
+    sparse: the same with setup%sparse_storage -- the parts READ the forcing from the whole grid's (nac, nt) sparse vectors
+    (mw_sparse_storage.f90:12-49) and WRITE the (nac, nt) sparse_ output forms, a part's cells at their whole-grid numbers."""
     import torch
     torch.zeros(1, device="cuda")
     import smash_amd
@@ -353,20 +356,34 @@ def test_domain_outputs_of_the_parts_overlay_to_the_single_domain():
     nrow, ncol = g.mesh.nrow, g.mesh.ncol
     box = {(a, b, k): queue.Queue() for a in range(world) for b in range(world) for k in "fa"}
     res, errs = {}, []
+    # the sparse numbering: active cells in the order of mesh%path (all cells are active in this fixture's mask or not: take the mask)
+    path = np.asarray(g.mesh.path)
+    act = np.asarray(g.mesh.active_cell)
+    pr_, pc_ = path[0], path[1]
+    keep = (pr_ >= 0) & (pc_ >= 0)
+    keep[keep] &= act[pr_[keep], pc_[keep]] == 1
+    srow, scol = pr_[keep], pc_[keep]
+    nac = int(keep.sum())
+    sp_prcp = np.asfortranarray(g.prcp[srow, scol, :]) if sparse else None
+    sp_pet = np.asfortranarray(g.pet[srow, scol, :]) if sparse else None
 
     def run(rank):
         try:
             rect = tiles.tile_rect(rank, nrow, ncol, pr, pc)
             st, ms, loc = _tile_inputs(g, rect, g.mesh.ng)
             sol = Solver(st, ms, chunk_steps=32, pipe_steps=16, group_size=128, tile=rect)
-            sol.set_forcing(g.prcp, g.pet)
+            if sparse:
+                sol.set_forcing(sp_prcp, sp_pet, sparse=True)
+            else:
+                sol.set_forcing(g.prcp, g.pet)
             if loc:
                 sol.set_qobs(np.asfortranarray(g.qobs[loc]))
             sol.set_options(st.optimize)
             Loopback(rank, sol, nrow, ncol, pr, pc, box)
-            q = np.zeros((nrow, ncol, g.nt), np.float32, order="F")
-            pn = np.zeros((nrow, ncol, g.nt), np.float32, order="F")
-            sol.set_domain_outputs(q, pn)
+            shp = (nac, g.nt) if sparse else (nrow, ncol, g.nt)
+            q = np.zeros(shp, np.float32, order="F")
+            pn = np.zeros(shp, np.float32, order="F")
+            sol.set_domain_outputs(q, pn, sparse=sparse)
             sol.upload(smash_amd.ParametersDT.from_dict(ms, g.params), smash_amd.StatesDT.from_dict(ms, g.states))
             sol.sweep(False, 0.0)
             rows, cols = sol.cell_order()
@@ -382,11 +399,15 @@ def test_domain_outputs_of_the_parts_overlay_to_the_single_domain():
     for t in th:
         t.join(timeout=300)
     assert not errs and len(res) == world
+    if sparse:
+        ref_q, ref_p = ref_q[srow, scol, :], ref_p[srow, scol, :]              # the single domain's dense arrays in the sparse numbering
     q_all = np.full_like(ref_q, -99.0)
     p_all = np.full_like(ref_p, -99.0)
     for rank, (q, pn, rows, cols) in res.items():
         own = np.zeros((nrow, ncol), bool)
         own[rows, cols] = True
+        if sparse:
+            own = own[srow, scol]
         assert np.all(q[~own] == -99.0) and np.all(pn[~own] == -99.0)          # a part writes its own cells only
         q_all[own], p_all[own] = q[own], pn[own]
     assert np.array_equal(q_all, ref_q) and np.array_equal(p_all, ref_p)
