@@ -239,9 +239,8 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
     plan of its part (exchange set).  The control vector is the whole grid's, in the reference's order; rank 0 runs L-BFGS-B and
     hands every trial point to the others, each evaluation is one collective forward_b: the parts' cost_jobs are summed, the
     regulariser's term -- evaluated over the whole grid by every rank -- counted once, every rank contributes the gradient of the
-    cells it owns.  The iterates are those of the single domain (the sweep is bit-identical, the sums are not reordered)."""
-    if decomposition is not None and auto_wjreg is not None:
-        raise ValueError("auto_wjreg over a decomposition: run the cycles with decomposition= on every rank yourself")
+    cells it owns.  The iterates are those of the single domain (the sweep is bit-identical, the sums are not reordered).
+    auto_wjreg works over a decomposition too: every cycle is a collective calibration and every rank takes the same decisions."""
     if auto_wjreg is not None and setup.optimize.njr > 0:
         o = setup.optimize
         if auto_wjreg == "lcurve" and nb_wjreg_lcurve < 6:
@@ -257,7 +256,10 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
 
         def run_cycle(w):
             o.wjreg = float(w)
-            h = optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose=verbose)
+            # over a decomposition every cycle is a collective calibration; what the cycles decide on -- the decomposition's cost_jobs
+            # (all-reduced), the common cost_jreg, the initial cost_jobs -- is the same numbers on every rank, so every rank tries the
+            # same weights and picks the same one
+            h = optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose=verbose, decomposition=decomposition)
             last["h"] = h
             return dict(cost=output.cost, cost_jobs=output.cost_jobs, cost_jreg=output.cost_jreg, cost_jobs_initial=h["cost_jobs_initial"])
 
@@ -266,6 +268,11 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
             # no corner found: the model is run as it is; like the reference, wjreg stays at the last weight a cycle tried
             # (core/simulation/_optimize.py:434-450 does not reset it), so output.cost carries that weight's regularisation term
             forward(setup, mesh, input_data, parameters, parameters.copy(), states, states.copy(), output, np.float32(0))
+            if decomposition is not None:
+                v = np.array([float(output.cost_jobs)], np.float64)
+                decomposition.allreduce(v)
+                output.cost_jobs = np.float32(v[0])
+                output.cost = np.float32(np.float32(v[0]) + np.float32(o.wjreg) * np.float32(output.cost_jreg))
         h = dict(last["h"], wjreg=w)
         if return_lcurve and lcurve is not None:
             h["lcurve"] = lcurve

@@ -244,13 +244,15 @@ def test_tile_refuses_self_sized_chunks():
     assert e.value.code == _lib.E_ARG and "chunk_steps" in str(e.value)
 
 
-@pytest.mark.parametrize("world,with_jreg", [(4, False), (2, True)])
-def test_calibration_over_tiles_follows_the_single_domain(world, with_jreg):
+@pytest.mark.parametrize("world,with_jreg,auto", [(4, False, None), (2, True, None), (2, True, "fast"), (2, True, "lcurve")])
+def test_calibration_over_tiles_follows_the_single_domain(world, with_jreg, auto):
     """smash_amd.optimize_lbfgsb(decomposition=...): the distributed L-BFGS-B calibration (mw_optimize.f90:484-676) over the plans of
     a tile decomposition -- rank 0 runs the optimiser, every trial point is one collective forward_b, the parts' costs are summed,
     every part contributes the gradient of its own cells (the regulariser's term, evaluated over the whole grid by every part,
     counted once).  Against the same calibration on the single domain: same number of iterations and evaluations, costs and
-    calibrated fields equal to the rounding of the cost sum (parts' fp32 costs added in double)."""
+    calibrated fields equal to the rounding of the cost sum (parts' fp32 costs added in double).
+    auto = 'fast' | 'lcurve': the cycles that choose the regularisation weight (core/simulation/_optimize.py:257-453) over the
+    decomposition -- every rank must try the same weights, pick the same one and end with the single domain's."""
     import os
     import torch
     torch.zeros(1, device="cuda")
@@ -271,7 +273,7 @@ def test_calibration_over_tiles_follows_the_single_domain(world, with_jreg):
     setup, mesh, inp, par, sta, out = _types(g)
     setup.optimize.optim_parameters, setup.optimize.maxiter = op, maxiter
     setup.optimize.optim_states = np.zeros_like(np.asarray(setup.optimize.optim_states))
-    href = smash_amd.optimize_lbfgsb(setup, mesh, inp, par, sta, out)
+    href = smash_amd.optimize_lbfgsb(setup, mesh, inp, par, sta, out, auto_wjreg=auto, return_lcurve=True)
 
     pr, pc = tiles.tile_grid(world)
     nrow, ncol = g.mesh.nrow, g.mesh.ncol
@@ -302,7 +304,8 @@ def test_calibration_over_tiles_follows_the_single_domain(world, with_jreg):
             pt = smash_amd.ParametersDT.from_dict(ms, g.params)
             stt = smash_amd.StatesDT.from_dict(ms, g.states)
             ot = smash_amd.OutputDT(st, ms)
-            h = smash_amd.optimize_lbfgsb(st, ms, ip, pt, stt, ot, decomposition=dec)
+            h = smash_amd.optimize_lbfgsb(st, ms, ip, pt, stt, ot, decomposition=dec, auto_wjreg=auto, return_lcurve=True)
+            h["wjreg_left"] = float(st.optimize.wjreg)
             res[rank] = (h, pt, ot, ex.calls)
         except Exception as e:  # pragma: no cover
             import traceback
@@ -317,6 +320,20 @@ def test_calibration_over_tiles_follows_the_single_domain(world, with_jreg):
         t.join(timeout=600)
     assert not errs and len(res) == world
     h0 = res[0][0]
+    if auto is not None:
+        # the weight every rank ended with is one number, and the single domain's to the rounding of the cost sums it is a ratio of;
+        # the L-curve tried the same weights and chose the same corner
+        ws = [res[r][0]["wjreg"] for r in range(world)]
+        assert all(w == ws[0] for w in ws) and all(res[r][0]["wjreg_left"] == res[0][0]["wjreg_left"] for r in range(world))
+        assert (ws[0] is None) == (href["wjreg"] is None)
+        if ws[0] is not None:
+            assert abs(ws[0] - href["wjreg"]) <= 1e-4 * abs(href["wjreg"]), (ws[0], href["wjreg"])
+        if auto == "lcurve":
+            assert np.allclose(h0["lcurve"]["wjreg"], href["lcurve"]["wjreg"], rtol=1e-4)
+            assert np.allclose(h0["lcurve"]["cost_jobs"], href["lcurve"]["cost_jobs"], rtol=1e-4)
+            assert np.array_equal(np.isnan(h0["lcurve"]["distance"]), np.isnan(href["lcurve"]["distance"]))
+        assert abs(h0["final_cost"] - href["final_cost"]) <= 1e-4 * abs(href["final_cost"]), (h0["final_cost"], href["final_cost"])
+        return
     assert len(h0["cost"]) == len(href["cost"]) == maxiter and h0["nfg"] == href["nfg"]
     assert np.allclose(h0["cost"], href["cost"], rtol=2e-6, atol=0), (h0["cost"], href["cost"])
     assert abs(h0["final_cost"] - href["final_cost"]) <= 2e-6 * abs(href["final_cost"])
