@@ -223,6 +223,11 @@ int smashx_set_domain_outputs(smashx_plan* plan, float* qsim_domain, float* net_
 int smashx_forward_d(smashx_plan* plan, smashx_parameters* params, const smashx_parameters* params_d,
                      const smashx_parameters* params_bgd, smashx_states* states, const smashx_states* states_d,
                      const smashx_states* states_bgd, float* qsim, float* qsim_d, smashx_costs* costs, float* cost_d);
+/* The two terms of the last smashx_forward_d's cost_d = jobs_d + wjreg x jreg_d (COMPUTE_COST_D, forward_db.f90:3248).  On a tiled
+ * plan smashx_forward_d is collective like the sweeps (the boundary series of the value pass, then of the tangent pass, travel through
+ * the plan's exchange, a message per pipeline sub-chunk); jobs_d then covers the gauges of this part and jreg_d the whole grid, so the
+ * decomposition's cost_d is the sum of the parts' jobs_d + wjreg x jreg_d of any one part. */
+int smashx_tangent_terms(const smashx_plan* plan, float* jobs_d, float* jreg_d);
 
 /* ---- multi-GPU tiles: discharge series that cross the tile boundary -------------------
  * A cell whose D8 receiver lies in another tile publishes its discharge series ("out" edge); a cell of another

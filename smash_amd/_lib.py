@@ -19,7 +19,7 @@ SYMBOLS = [
     "smashx_last_error", "smashx_abi_sizes", "smashx_device_count", "smashx_plan_create", "smashx_plan_destroy", "smashx_plan_ncells",
     "smashx_plan_cell_order", "smashx_set_forcing", "smashx_set_forcing_device_block", "smashx_set_qobs",
     "smashx_set_options", "smashx_forward", "smashx_forward_b", "smashx_upload", "smashx_sweep", "smashx_download",
-    "smashx_get_timing", "smashx_halo_counts", "smashx_halo_edges", "smashx_plan_chunking", "smashx_set_halo", "smashx_tile_probe", "smashx_debug_group_times", "smashx_set_domain_outputs", "smashx_forward_d", "smashx_selftest_math",
+    "smashx_get_timing", "smashx_halo_counts", "smashx_halo_edges", "smashx_plan_chunking", "smashx_set_halo", "smashx_tile_probe", "smashx_debug_group_times", "smashx_set_domain_outputs", "smashx_forward_d", "smashx_tangent_terms", "smashx_selftest_math",
     "smashx_set_forcing_layout", "smashx_forcing_info", "smashx_control_size", "smashx_control_set", "smashx_control_get",
     "smashx_control_gradient",
     "smashx_comm_unique_id", "smashx_comm_create", "smashx_comm_destroy", "smashx_comm_allreduce_sum", "smashx_set_exchange",

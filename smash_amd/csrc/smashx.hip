@@ -369,6 +369,7 @@ struct smashx_plan {
     // extra device storage
     int* d_cell_flat = nullptr;      // k -> flat (row + col*nrow)
     int* d_sparse_idx = nullptr;     // k -> index in the sparse (nac) vectors
+    float last_jobs_d = 0.f, last_jreg_d = 0.f;      // the two terms of the last smashx_forward_d's cost_d (smashx_tangent_terms)
     long n_sparse = 0;               // length of a sparse vector = the WHOLE grid's active cells along path (= n on an untiled plan)
     float* d_stage = nullptr;        // staging for full planes
     long stage_planes = 0;
@@ -583,6 +584,8 @@ SxDeviceArrays view_at(const smashx_plan* p, int off) {
     if (p->A.hrT) B.hrT = p->A.hrT + q * p->npad * 4;
     if (p->A.qdT) B.qdT = p->A.qdT + q * p->npad * 4;
     B.xT = p->A.xT + q * p->A.nx * 4;
+    if (p->A.qtdT) B.qtdT = p->A.qtdT + q * p->npad * 4;      // tangent sweep (smashx_forward_d)
+    if (p->A.xdT) B.xdT = p->A.xdT + q * p->A.nx * 4;
     if (p->A.tape_hp) B.tape_hp = p->A.tape_hp + (size_t)off * p->npad;
     if (p->A.tape_hft) B.tape_hft = p->A.tape_hft + (size_t)off * p->npad;
     if (p->A.tape_hi) B.tape_hi = p->A.tape_hi + (size_t)off * p->npad;
@@ -1385,6 +1388,58 @@ int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     return stalled ? fail(SMASHX_E_HIP, "routing stalled without chained rounds (internal error)") : 0;
 }
 
+// ---- boundary-series exchange of a tiled plan (used by the sweep and by the tangent model) ---------------------------------
+// move the boundary series of one sub-chunk between the exchange rows (xarr: xT, or xdT for the tangents) and the message buffers
+// (the caller's, or the plan's own in peer-grouped edge order when RCCL carries them)
+static void sx_halo_move(smashx_plan* p, bool native, float* xarr, bool pack, bool out_edges, int off, int T, hipStream_t st) {
+    const int nedge = out_edges ? p->n_out : p->n_in;
+    if (nedge == 0) return;
+    const int Tq = (T + 3) / 4;
+    float4* x4 = reinterpret_cast<float4*>(xarr) + (size_t)(off / 4) * p->A.nx;
+    float4* buf = reinterpret_cast<float4*>(native ? (out_edges ? p->x_out : p->x_in) : (out_edges ? p->halo_out : p->halo_in));
+    const int* slots = native ? (out_edges ? p->d_out_xp : p->d_in_xp) : (out_edges ? p->d_out_x : p->d_in_x);
+    const dim3 g((nedge * Tq + 255) / 256), b(256);
+    if (pack) hipLaunchKernelGGL(k_halo_pack, g, b, 0, st, buf, x4, slots, nedge, p->A.nx, Tq);
+    else hipLaunchKernelGGL(k_halo_unpack, g, b, 0, st, x4, buf, slots, nedge, p->A.nx, Tq);
+}
+// one grouped send or recv per sub-chunk: a message per peer = its edges x the sub-chunk's steps, stream-ordered on st
+static int sx_halo_xfer(smashx_plan* p, bool send, bool out_edges, int T, hipStream_t st) {
+    const std::vector<PeerSeg>& segs = out_edges ? p->out_segs : p->in_segs;
+    if (segs.empty()) return 0;
+    RcclApi& R = rccl();
+    float* buf = out_edges ? p->x_out : p->x_in;
+    const size_t per_edge = (size_t)((T + 3) / 4) * 4;
+    static const bool trace = getenv("SMASHX_TRACE_XFER") != nullptr;     // debugging aid: one line per posted group, completion awaited
+    if (trace) {
+        std::string peers;
+        for (const PeerSeg& sg : segs) peers += " " + std::to_string(sg.rank) + ":" + std::to_string(sg.count);
+        fprintf(stderr, "[smashx rank %d] %s %s edges, %d steps, peers(rank:edges)%s\n", p->xcomm->rank, send ? "send" : "recv",
+                out_edges ? "out" : "in", T, peers.c_str());
+    }
+    NCCLCHK(R.GroupStart());
+    for (const PeerSeg& sg : segs) {
+        float* b = buf + (size_t)sg.first * per_edge;
+        const ncclResult_t r = send ? R.Send(b, (size_t)sg.count * per_edge, ncclFloat, sg.rank, p->xcomm->comm, st)
+                                    : R.Recv(b, (size_t)sg.count * per_edge, ncclFloat, sg.rank, p->xcomm->comm, st);
+        if (r != ncclSuccess) { (void)R.GroupEnd(); return fail(SMASHX_E_HIP, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(r)); }
+    }
+    NCCLCHK(R.GroupEnd());
+    if (trace) {
+        HIPCHK(hipStreamSynchronize(st));
+        fprintf(stderr, "[smashx rank %d]   ... completed\n", p->xcomm->rank);
+    }
+    return 0;
+}
+// phases as in smashx_halo_fn: 0 FWD_RECV (in), 1 FWD_SEND (out), 2 ADJ_RECV (out), 3 ADJ_SEND (in)
+static int sx_halo_hook(smashx_plan* p, bool native, int phase, int t0, int T, hipStream_t st) {
+    if (native) return sx_halo_xfer(p, phase == 1 || phase == 3, phase == 1 || phase == 2, T, st);
+    // host callback: the packed buffer must be complete before the host moves it; the unpack of the previous message must have
+    // consumed the receive buffer before the host fills it again
+    HIPCHK(hipStreamSynchronize(st));
+    const int rc2 = p->halo_fn(p->halo_user, phase, t0, T);
+    return rc2 ? fail(SMASHX_E_ARG, "halo callback failed") : 0;
+}
+
 static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_out) {
     *stalled_out = false;
     if (!p) return fail(SMASHX_E_ARG, "null plan");
@@ -1412,56 +1467,8 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     // forward over one storage chunk: V(j) on the V stream, R(j) on the R stream as soon as V(j) is done
     const bool native = p->xcomm != nullptr;
     const bool halo = (p->halo_fn || native) && (p->n_out > 0 || p->n_in > 0);
-    // move the boundary series of one sub-chunk between the exchange rows and the message buffers (the caller's, or the
-    // plan's own in peer-grouped edge order when RCCL carries them)
-    auto halo_move = [&](bool pack, bool out_edges, int off, int T, hipStream_t st) {
-        const int nedge = out_edges ? p->n_out : p->n_in;
-        if (nedge == 0) return;
-        const int Tq = (T + 3) / 4;
-        float4* x4 = reinterpret_cast<float4*>(p->A.xT) + (size_t)(off / 4) * p->A.nx;
-        float4* buf = reinterpret_cast<float4*>(native ? (out_edges ? p->x_out : p->x_in) : (out_edges ? p->halo_out : p->halo_in));
-        const int* slots = native ? (out_edges ? p->d_out_xp : p->d_in_xp) : (out_edges ? p->d_out_x : p->d_in_x);
-        const dim3 g((nedge * Tq + 255) / 256), b(256);
-        if (pack) hipLaunchKernelGGL(k_halo_pack, g, b, 0, st, buf, x4, slots, nedge, p->A.nx, Tq);
-        else hipLaunchKernelGGL(k_halo_unpack, g, b, 0, st, x4, buf, slots, nedge, p->A.nx, Tq);
-    };
-    // one grouped send or recv per sub-chunk: a message per peer = its edges x the sub-chunk's steps, stream-ordered on st
-    auto xfer = [&](bool send, bool out_edges, int T, hipStream_t st) -> int {
-        const std::vector<PeerSeg>& segs = out_edges ? p->out_segs : p->in_segs;
-        if (segs.empty()) return 0;
-        RcclApi& R = rccl();
-        float* buf = out_edges ? p->x_out : p->x_in;
-        const size_t per_edge = (size_t)((T + 3) / 4) * 4;
-        static const bool trace = getenv("SMASHX_TRACE_XFER") != nullptr;     // debugging aid: one line per posted group, completion awaited
-        if (trace) {
-            std::string peers;
-            for (const PeerSeg& sg : segs) peers += " " + std::to_string(sg.rank) + ":" + std::to_string(sg.count);
-            fprintf(stderr, "[smashx rank %d] %s %s edges, %d steps, peers(rank:edges)%s\n", p->xcomm->rank, send ? "send" : "recv",
-                    out_edges ? "out" : "in", T, peers.c_str());
-        }
-        NCCLCHK(R.GroupStart());
-        for (const PeerSeg& sg : segs) {
-            float* b = buf + (size_t)sg.first * per_edge;
-            const ncclResult_t r = send ? R.Send(b, (size_t)sg.count * per_edge, ncclFloat, sg.rank, p->xcomm->comm, st)
-                                        : R.Recv(b, (size_t)sg.count * per_edge, ncclFloat, sg.rank, p->xcomm->comm, st);
-            if (r != ncclSuccess) { (void)R.GroupEnd(); return fail(SMASHX_E_HIP, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(r)); }
-        }
-        NCCLCHK(R.GroupEnd());
-        if (trace) {
-            HIPCHK(hipStreamSynchronize(st));
-            fprintf(stderr, "[smashx rank %d]   ... completed\n", p->xcomm->rank);
-        }
-        return 0;
-    };
-    // phases as in smashx_halo_fn: 0 FWD_RECV (in), 1 FWD_SEND (out), 2 ADJ_RECV (out), 3 ADJ_SEND (in)
-    auto hook = [&](int phase, int t0, int T, hipStream_t st) -> int {
-        if (native) return xfer(phase == 1 || phase == 3, phase == 1 || phase == 2, T, st);
-        // host callback: the packed buffer must be complete before the host moves it; the unpack of the previous message must have
-        // consumed the receive buffer before the host fills it again
-        HIPCHK(hipStreamSynchronize(st));
-        const int rc2 = p->halo_fn(p->halo_user, phase, t0, T);
-        return rc2 ? fail(SMASHX_E_ARG, "halo callback failed") : 0;
-    };
+    auto halo_move = [&](bool pack, bool out_edges, int off, int T, hipStream_t st) { sx_halo_move(p, native, p->A.xT, pack, out_edges, off, T, st); };
+    auto hook = [&](int phase, int t0, int T, hipStream_t st) -> int { return sx_halo_hook(p, native, phase, t0, T, st); };
     const bool split = p->split_v && !halo && p->sch.nrounds > 1 && p->n0 > 0 && p->n0 < p->n;
     // SMASHX_PERSIST=1: ONE gated chained launch per storage chunk instead of one per pipeline sub-chunk (persistent workgroups, tickets
     // and the gate of sx_kernels.h).  Built to take the fill of the chained rounds out of every sub-chunk of a tile; measured and left
@@ -2286,7 +2293,10 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
                      smashx_states* states, const smashx_states* states_d, const smashx_states* states_bgd, float* qsim,
                      float* qsim_d, smashx_costs* costs, float* cost_d) {
     if (!p || !params || !states || !params_d || !states_d || !cost_d) return fail(SMASHX_E_ARG, "null argument");
-    if (p->tiled) return fail(SMASHX_E_UNSUPPORTED, "tangent model on a tiled plan");
+    // a tiled plan: the boundary series of the value pass and then of the tangent pass travel like the forward sweep's (same hooks,
+    // same phases), a message per pipeline sub-chunk; the criteria's tangent covers this part's gauges, the regulariser's the whole grid
+    // (smashx_tangent_terms gives the two apart: a decomposition adds the parts' first terms and counts the second once)
+    if (p->tiled && p->med_nslots > 0) return fail(SMASHX_E_UNSUPPORTED, "tangent model on a tiled plan with the median over gauges of several parts");
     int rc = smashx_upload(p, params, params_bgd, states, states_bgd); if (rc) return rc;
     if (!p->have_forcing) return fail(SMASHX_E_STATE, "forcing not set");
     if ((rc = set_device(p))) return rc;
@@ -2403,14 +2413,31 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
         }
         p->mark_end();
         hipEvent_t e = p->event(); HIPCHK(hipEventRecord(e, sV)); HIPCHK(hipStreamWaitEvent(sR, e, 0));
-        SxDeviceArrays Bt = B; Bt.qdT = nullptr;
-        for (int pass = 1; pass <= 2; ++pass)                           // values (forward_d's primal forms, hr_imd tape on), then tangents
-            for (int r = 0; r < p->sch.nrounds; ++r) {                  // one launch per round
-                const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
-                p->mark_begin(1, sR);
-                if (pass == 1) hipLaunchKernelGGL((sx_k_route_fwd<true, false, 1>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c, Tcur, 0);
-                else           hipLaunchKernelGGL((sx_k_route_fwd<false, false, 2>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c, Tcur, 0);
-                p->mark_end();
+        // routing: values (forward_d's primal forms, hr_imd tape on), then tangents; one launch per round.  A plan with boundary series
+        // (tiles) cuts each pass into the pipeline sub-chunks its message buffers hold: receive + unpack, route, pack + send
+        const bool native = p->xcomm != nullptr;
+        const bool halo = (p->halo_fn || native) && (p->n_out > 0 || p->n_in > 0);
+        const int Tsub = halo ? p->Tp : Tcur;
+        for (int pass = 1; pass <= 2; ++pass)
+            for (int off = 0; off < Tcur; off += Tsub) {
+                const int T = std::min(Tsub, Tcur - off);
+                SxDeviceArrays Bt = view_at(p, off); Bt.qdT = nullptr;
+                float* xarr = pass == 1 ? p->A.xT : p->A.xdT;
+                if (halo && p->n_in > 0) {
+                    if ((rc = sx_halo_hook(p, native, 0, t0c + off, T, sR))) return rc;
+                    sx_halo_move(p, native, xarr, false, false, off, T, sR);
+                }
+                for (int r = 0; r < p->sch.nrounds; ++r) {
+                    const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
+                    p->mark_begin(1, sR);
+                    if (pass == 1) hipLaunchKernelGGL((sx_k_route_fwd<true, false, 1>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c + off, T, 0);
+                    else           hipLaunchKernelGGL((sx_k_route_fwd<false, false, 2>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c + off, T, 0);
+                    p->mark_end();
+                }
+                if (halo && p->n_out > 0) {
+                    sx_halo_move(p, native, xarr, true, true, off, T, sR);
+                    if ((rc = sx_halo_hook(p, native, 1, t0c + off, T, sR))) return rc;
+                }
             }
     }
     // cost (values) and its tangent in the reference's summation order
@@ -2431,6 +2458,7 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
         if (stalled) return fail(SMASHX_E_HIP, "chained routing launch stalled");
     }
     *cost_d = jobs_d + p->opt.wjreg * jreg_d;                        // COMPUTE_COST_D (forward_db.f90:3248)
+    p->last_jobs_d = jobs_d; p->last_jreg_d = jreg_d;
     if (qsim_d && p->ng > 0) {
         std::vector<float> qd((size_t)p->ng * p->nt);
         HIPCHK(hipMemcpy(qd.data(), p->d_qsim_d, qd.size() * 4, hipMemcpyDeviceToHost));
@@ -2440,6 +2468,12 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
     p->last_adjoint = 0;
     // primal outputs exactly like base_forward (parameters / states denormalised + round trip, states restored)
     return smashx_download(p, 0, params, states, qsim, costs, nullptr, nullptr, nullptr);
+}
+
+int smashx_tangent_terms(const smashx_plan* p, float* jobs_d, float* jreg_d) {
+    if (!p || !jobs_d || !jreg_d) return fail(SMASHX_E_ARG, "null argument");
+    *jobs_d = p->last_jobs_d; *jreg_d = p->last_jreg_d;
+    return 0;
 }
 
 int smashx_forward_b(smashx_plan* p, smashx_parameters* params, const smashx_parameters* params_bgd, smashx_states* states,

@@ -203,6 +203,13 @@ class Solver:
         _lib.check(fn(self._h, None if qsim_domain is None else qsim_domain.ctypes.data,
                       None if net_prcp_domain is None else net_prcp_domain.ctypes.data, int(bool(sparse))))
 
+    def tangent_terms(self):
+        """(jobs_d, jreg_d) of the last forward_d on this plan (include/smashx.h smashx_tangent_terms): over a decomposition the
+        parts' jobs_d add up and jreg_d -- the whole grid's on every part -- enters once."""
+        a, b = C.c_float(0.0), C.c_float(0.0)
+        _lib.check(_lib.lib().smashx_tangent_terms(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
     def group_times(self):
         """Diagnostics (SMASHX_TRACE_GROUPS=1): (ticks[2][groups][2] at 100 MHz, round_of_group[groups])."""
         ng = self.timing()["n_groups"]

@@ -27,6 +27,8 @@ def main():
                     "gauge weights incl. the median over gauges) instead of the plain nse of the short window")
     ap.add_argument("--calibrate", type=int, default=0, help="with --opts: also run N iterations of optimize_lbfgsb over the decomposition "
                     "(tiles.TorchDecomposition over this process group) and compare with the single-domain calibration")
+    ap.add_argument("--tangent", action="store_true", help="also run the tangent model (smashx_forward_d) over the decomposition and "
+                    "compare discharge tangents and cost_d with the single domain's")
     a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 
@@ -155,6 +157,48 @@ def main():
                 d = float(np.max(np.abs(getattr(pt, k)[act] - getattr(p1, k)[act])))
                 if d > 1e-4 * float(np.max(np.abs(getattr(p1, k)[act]))):
                     bad.append(("field", k, d))
+    if a.tangent:
+        # base_forward_d over the ranks: value and tangent boundary series through the same exchange; direction = 1 on every parameter
+        from smash_amd.solver import _tangent_call
+        from smash_amd.synth import PARAM_NAMES, STATE_NAMES
+        from test_gpu_parity import _types
+
+        def direction(m_):
+            pd_, sd_ = smash_amd.ParametersDT.from_dict(m_, g.params), smash_amd.StatesDT.from_dict(m_, g.states)
+            for k in PARAM_NAMES:
+                getattr(pd_, k)[...] = 1.0
+            for k in STATE_NAMES:
+                getattr(sd_, k)[...] = 0.0
+            return pd_, sd_
+        if not a.opts:
+            g.opts = {}
+        s1, m1, i1, p1, t1, o1 = _types(g)
+        r0 = Solver(s1, m1, chunk_steps=a.chunk, device=local)
+        r0.set_forcing(g.prcp, g.pet)
+        r0.set_qobs(g.qobs)
+        r0.set_options(s1.optimize)
+        pd1, sd1 = direction(m1)
+        od1 = smash_amd.OutputDT(s1, m1)
+        _, cost_d_ref = _tangent_call(r0, p1, pd1, p1.copy(), t1, sd1, t1.copy(), o1, od1)
+        jobs_d_ref, jreg_d_ref = r0.tangent_terms()
+        r0.close()
+        for rep in range(2):
+            pt, tt = smash_amd.ParametersDT.from_dict(mesh, g.params), smash_amd.StatesDT.from_dict(mesh, g.states)
+            ptd, ttd = direction(mesh)
+            ot, otd = smash_amd.OutputDT(setup, mesh), smash_amd.OutputDT(setup, mesh)
+            _tangent_call(sol, pt, ptd, pt.copy(), tt, ttd, tt.copy(), ot, otd)
+            say(f"tangent sweep {rep} done")
+            jd, jr = sol.tangent_terms()
+            for i, gi in enumerate(loc):
+                if not np.array_equal(ot.qsim[i], o1.qsim[gi]) or not np.array_equal(otd.qsim[i], od1.qsim[gi]):
+                    bad.append(("tangent qsim / qsim_d", gi, rep))
+            if jr != jreg_d_ref:
+                bad.append(("jreg_d", jr, jreg_d_ref))
+            ct = torch.tensor([jd], dtype=torch.float64, device=dev)
+            dist.all_reduce(ct)
+            total = float(ct.item()) + float(setup.optimize.wjreg) * jr
+            if abs(total - cost_d_ref) > 2e-5 * abs(cost_d_ref) + 1e-12:
+                bad.append(("cost_d", total, cost_d_ref))
     n_out, n_in = sol.halo_counts()
     print(f"rank {rank}/{world} [{a.exchange}, {a.cut}]: cells {sol.ncells}, edges out {n_out} in {n_in}, chunking {sol.chunking()}, "
           f"{'BIT-IDENTICAL' if not bad else 'MISMATCH ' + str(bad[:6])}", flush=True)

@@ -54,6 +54,14 @@ def test_calibration_across_ranks_over_rccl():
     _launch(2, ["--case", "gr_b_24x24x120_norm_jreg", "--opts", "--calibrate", "2", "--chunk", "64", "--pipe", "16"], 17)
 
 
+def test_tangent_model_across_ranks_over_rccl():
+    """smashx_forward_d on a decomposition with one process per part: the boundary series of the value pass and of the tangent pass as
+    grouped ncclSend / ncclRecv on the routing stream (rectangles, and sub-catchment parts of a D8 mesh); discharge and its tangent at
+    every rank's gauges bit-identical to the single domain, cost_d to the rounding of the sum over the ranks."""
+    _launch(2, ["--chunk", "32", "--pipe", "16", "--tangent"], 19)
+    _launch(3, ["--case", "gr_c_32x32x240_d8_ragged", "--cut", "sub", "--chunk", "96", "--pipe", "16", "--tangent"], 23)
+
+
 def test_bench_self_launch_two_ranks():
     """python bench.py --gpus 2 with no launcher starts both ranks itself and prints one JSON line with n_gpus = 2."""
     import json

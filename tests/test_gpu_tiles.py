@@ -428,3 +428,94 @@ def test_domain_outputs_of_the_parts_overlay_to_the_single_domain(sparse):
         assert np.all(q[~own] == -99.0) and np.all(pn[~own] == -99.0)          # a part writes its own cells only
         q_all[own], p_all[own] = q[own], pn[own]
     assert np.array_equal(q_all, ref_q) and np.array_equal(p_all, ref_p)
+
+
+@pytest.mark.parametrize("name,world,nt,cut", [("gr_b_64x64x720_nse", 4, 96, None), ("gr_c_32x32x240_d8_ragged", 3, 96, "sub"),
+                                              ("gr_b_24x24x120_norm_jreg", 2, 120, None)])
+def test_tangent_model_over_tiles_equals_single_domain(name, world, nt, cut):
+    """smashx_forward_d (base_forward_d, forward_db.f90:10517-10601) on a decomposition: the boundary series of the value pass and of
+    the tangent pass travel through the plans' exchange, a message per pipeline sub-chunk.  Against the single domain along the same
+    direction (1 on every parameter field, as mw_adjoint_test's scalar product test): discharge and its tangent at every part's
+    gauges bit for bit; cost_d = the parts' criteria terms + the regulariser's term once, to the rounding of that sum."""
+    import torch
+    torch.zeros(1, device="cuda")
+    import smash_amd
+    from smash_amd import synth, tiles
+    from smash_amd.solver import Solver, _tangent_call
+    from test_gpu_parity import _types
+    g = gu.load(name)
+    keep_opts = dict(g.opts) if "jreg" in name else {}
+    if nt < g.nt:
+        g = _short(name, nt)
+    g.opts = {k: v for k, v in keep_opts.items() if k not in ("params_bgd", "states_bgd")}
+
+    def direction(mesh):
+        pd = smash_amd.ParametersDT.from_dict(mesh, g.params)
+        sd = smash_amd.StatesDT.from_dict(mesh, g.states)
+        for k in synth.PARAM_NAMES:
+            getattr(pd, k)[...] = 1.0
+        for k in synth.STATE_NAMES:
+            getattr(sd, k)[...] = 0.0
+        return pd, sd
+
+    setup, mesh, inp, par, sta, out = _types(g)
+    s0 = Solver(setup, mesh, chunk_steps=32)
+    s0.set_forcing(g.prcp, g.pet)
+    s0.set_qobs(g.qobs)
+    s0.set_options(setup.optimize)
+    pd, sd = direction(mesh)
+    out_d = smash_amd.OutputDT(setup, mesh)
+    cost0, cost_d0 = _tangent_call(s0, par, pd, par.copy(), sta, sd, sta.copy(), out, out_d)
+    jobs_d0, jreg_d0 = s0.tangent_terms()
+    ref_q, ref_qd = np.array(out.qsim), np.array(out_d.qsim)
+
+    nrow, ncol = g.mesh.nrow, g.mesh.ncol
+    pr, pc = tiles.tile_grid(world)
+    owner = tiles.partition_subcatchments(g.mesh, world) if cut == "sub" else None
+    box = {(a, b, k): queue.Queue() for a in range(world) for b in range(world) for k in "fa"}
+    res, errs = {}, []
+
+    def run(rank):
+        try:
+            if owner is not None:
+                mine = np.asarray(owner) == rank
+                st, ms, loc = _tile_inputs(g, None, g.mesh.ng, mine)
+                sol = Solver(st, ms, chunk_steps=32, pipe_steps=16, group_size=128, owner_mask=mine)
+            else:
+                rect = tiles.tile_rect(rank, nrow, ncol, pr, pc)
+                st, ms, loc = _tile_inputs(g, rect, g.mesh.ng)
+                sol = Solver(st, ms, chunk_steps=32, pipe_steps=16, group_size=128, tile=rect)
+            _apply_opts(st, g, loc)
+            sol.set_forcing(g.prcp, g.pet)
+            if loc:
+                sol.set_qobs(np.asfortranarray(g.qobs[loc]))
+            sol.set_options(st.optimize)
+            ex = Loopback(rank, sol, nrow, ncol, pr, pc, box, owner)
+            pt, stt = smash_amd.ParametersDT.from_dict(ms, g.params), smash_amd.StatesDT.from_dict(ms, g.states)
+            ptd, std = direction(ms)
+            ot, otd = smash_amd.OutputDT(st, ms), smash_amd.OutputDT(st, ms)
+            _tangent_call(sol, pt, ptd, pt.copy(), stt, std, stt.copy(), ot, otd)
+            res[rank] = (loc, np.array(ot.qsim) if loc else None, np.array(otd.qsim) if loc else None, sol.tangent_terms(), ex.calls)
+        except Exception as e:  # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs and len(res) == world
+    jobs_d, seen = 0.0, 0
+    for rank, (loc, q, qd, (jd, jr), calls) in res.items():
+        assert calls > 0
+        jobs_d += jd
+        assert jr == jreg_d0                                   # the regulariser's tangent: the whole grid's, bit for bit, on every part
+        if loc:
+            seen += len(loc)
+            assert np.array_equal(q, ref_q[loc]) and np.array_equal(qd, ref_qd[loc]), rank
+    assert seen == g.mesh.ng
+    assert abs(jobs_d - jobs_d0) <= 2e-5 * abs(jobs_d0) + 1e-12, (jobs_d, jobs_d0)
+    total = jobs_d + float(setup.optimize.wjreg) * jreg_d0
+    assert abs(total - cost_d0) <= 2e-5 * abs(cost_d0) + 1e-12, (total, cost_d0)
