@@ -55,13 +55,20 @@ def _lbfgsb_native(fg, x0, m, factr, pgtol, maxiter, maxfun, callback):
         while True:
             _lib.check(L.smashx_lbfgsb_step(h, x.ctypes.data, float(f), g.ctypes.data, C.byref(task)))
             if task.value == 1:                              # f and g wanted at x
-                f, g = fg(np.copy(x))
+                # (x itself, not a copy: fg reads it before it returns and the optimiser only moves it in its next step -- 134 MB
+                # per evaluation at 1.7e7 variables)
+                f, g = fg(x)
                 g = np.ascontiguousarray(g, np.float64)
                 nfev += 1
             elif task.value == 2:                            # new iterate
                 nit += 1
                 if callback is not None:
-                    callback(np.copy(x))
+                    if getattr(callback, "wants_pg", False):
+                        # the optimiser's own |projected gradient| at this iterate (lbfgsb.f dsave(13)) saves the callback five passes
+                        # over x; such a callback copies x itself if it keeps it
+                        callback(x, float(L.smashx_lbfgsb_projected_gradient(h)))
+                    else:
+                        callback(np.copy(x))
                 if nit >= maxiter:
                     stop = "STOP: TOTAL NO. of ITERATIONS REACHED LIMIT"
                     break
@@ -378,15 +385,17 @@ def optimize_lbfgsb(setup, mesh, input_data, parameters, states, output, verbose
             last["f"], last["g"] = float(np.float32(output.cost)), g
             return last["f"], g
 
-        def cb(xk):
+        def cb(xk, pg=None):
             hist["cost"].append(last["f"])
             if verbose:
                 print(f"    At iterate {len(hist['cost']):3d}    nfg = {hist['nfg']:5d}    J = {last['f']:14.6f}")
-            pg = np.max(np.abs(xk - np.clip(xk - last["g"], 0.0, 1.0)))       # |proj g| (lbfgsb.f projgr)
+            if pg is None:
+                pg = np.max(np.abs(xk - np.clip(xk - last["g"], 0.0, 1.0)))   # |proj g| (lbfgsb.f projgr)
             if pg <= 1e-10 * (1.0 + abs(last["f"])):
                 last["x"] = xk.copy()
                 raise _Stop
 
+        cb.wants_pg = True
         if dec is None or dec.rank == 0:
             try:
                 x, f, info = _lbfgsb_box(fg, x, 10, 10.0, 1e-12, maxiter, 10 * maxiter + 20, cb)

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import zlib
+
 import numpy as np
 
 from . import _lib
@@ -105,7 +107,13 @@ class Solver:
     @staticmethod
     def signature(setup, mesh):
         """Everything a cached plan was built from: sizes, dt, dx and the contents of the mesh arrays."""
-        h = hash(tuple(np.ascontiguousarray(getattr(mesh, k)).tobytes() for k in ("flwdir", "flwacc", "active_cell", "gauge_pos", "area")))
+        # (checksums of the arrays in their own memory order: no transposed copy of a Fortran-ordered 2048^2 plane per call)
+        def crc(a):
+            a = np.asarray(a)
+            if not (a.flags.c_contiguous or a.flags.f_contiguous):
+                a = np.ascontiguousarray(a)
+            return (a.shape, a.dtype.str, bool(a.flags.f_contiguous and not a.flags.c_contiguous), zlib.crc32(memoryview(a.ravel(order="K")).cast("B")))
+        h = hash(tuple(crc(getattr(mesh, k)) for k in ("flwdir", "flwacc", "active_cell", "gauge_pos", "area")))
         return (setup.structure, setup.ntime_step, float(setup.dt), mesh.nrow, mesh.ncol, mesh.ng, float(mesh.dx), bool(setup.sparse_storage), h)
 
     FULL_HASH_ELEMENTS = 1 << 24        # fields up to 64 MB are hashed whole

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--grid", type=int, default=2048)
     ap.add_argument("--nt", type=int, default=8760)
     ap.add_argument("--maxiter", type=int, default=3)
+    ap.add_argument("--cprofile", default="", help="write the host-side profile of the loop (cProfile, top functions by cumulative time) here")
     ap.add_argument("--host-pack", action="store_true", help="run the loop through the code path of a calibration over a decomposition "
                     "(a decomposition of ONE part): control vector packed on the host, whole-grid planes up and down per evaluation -- "
                     "what that path costs per evaluation against the device-side packing")
@@ -101,9 +102,22 @@ def main():
                 host["pack_s"] += time.perf_counter() - t
                 return r
             setattr(sol, name, wrap2)
+    prof = None
+    if a.cprofile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     h = smash_amd.optimize_lbfgsb(setup, mesh, inp, par, sta, out, decomposition=dec)
     wall = time.perf_counter() - t0
+    if prof is not None:
+        import io
+        import pstats
+        prof.disable()
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats("cumulative").print_stats(45)
+        with open(a.cprofile, "w") as f:
+            f.write(buf.getvalue())
     print(json.dumps({"grid": a.grid, "nt": a.nt, "control_variables": int(4 * sol.ncells), "iterations": len(h["cost"]),
                       "nfg": h["nfg"], "cost": h["cost"], "final_cost": h["final_cost"], "loop_s": wall, "setup_s": t_setup,
                       "gpu_sweeps": sweeps["n"], "gpu_sweep_s": sweeps["ms"] * 1e-3,
