@@ -1114,7 +1114,11 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDevice
 #endif
 template <int ST, bool CF>
 #ifndef SX_VADJ_WAVES_GRC
-#define SX_VADJ_WAVES_GRC 1       // gr-c, compact: 124 registers = 4 waves as compiled
+#if SX_EXACT_LIBM
+#define SX_VADJ_WAVES_GRC 1       // (the exact-libm build keeps what the compiler chooses)
+#else
+#define SX_VADJ_WAVES_GRC 5       // gr-c, compact: 122 registers = 4 waves as compiled; held to 96 = 5 waves (about 20 values spilled):
+#endif                            // vert_adj 80.2 -> 79.1 ms at 1024^2 x 8760, twice on one box (round 3, last session; bit-identical)
 #endif
 __global__ __launch_bounds__(SX_VBLOCK, (ST == 2 && CF) ? SX_VADJ_WAVES : (ST == 3 && CF) ? SX_VADJ_WAVES_GRC : 1)
 void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
