@@ -598,8 +598,8 @@ def main():
                                text=True, timeout=600)
             e = json.loads(r.stdout.strip().splitlines()[-1])
             line["exact_libm"] = {"what": "the 1024x1024 workload of `secondary` on libsmashx_exact.so (-DSX_EXACT_LIBM=1: glibc 2.35 expf/logf/powf/tanhf restated, IEEE divisions): "
-                                          "bit-identical to the reference Fortran on all 318 golden outputs (profiles/r2_parity_exact.md); the "
-                                          "default build differs from it by libm rounding only (profiles/r2_parity_default.md)",
+                                          "bit-identical to the reference Fortran on all 318 golden outputs (profiles/r3_parity_exact.md); the "
+                                          "default build differs from it by libm rounding only (profiles/r3_parity_default.md)",
                                   "value": e["value"], "ms_per_step": e["ms_per_step"], "steps": 2, "warmup": 1, "cost": e["cost"],
                                   "kernel_ms_per_step": e["kernel_ms_per_step"]}
         except Exception as ex:  # pragma: no cover
