@@ -43,7 +43,7 @@ VALU_CYCLES_F64, VALU_CYCLES_TRANS = 4.0, 8.0    # fp64 at half rate; v_rcp / v_
 KERNELS = ("vert_fwd", "route_fwd", "route_adj", "vert_adj")
 
 
-def pmc_profile(grid, n_chunks):
+def pmc_profile(grid, n_chunks, forward_only=False):
     """Counters of the committed rocprofv3 --pmc passes over this very command (tools/profile_round.sh): bench.py cannot
     collect PMC itself.  Per kernel: HBM bytes per cell-step (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md)
     and VALU wave-instructions per cell-step (SQ_INSTS_VALU).  The newest profiles/r*_pmc_traffic*.json taken on THIS workload
@@ -56,7 +56,8 @@ def pmc_profile(grid, n_chunks):
         except Exception:
             continue
         w = d.get("workload", {"grid": [1024, 1024], "n_chunks": 1})
-        if list(w.get("grid", [])) == list(grid) and int(w.get("n_chunks", 0)) == int(n_chunks):
+        if (list(w.get("grid", [])) == list(grid) and int(w.get("n_chunks", 0)) == int(n_chunks)
+                and bool(w.get("forward_only", False)) == bool(forward_only)):
             return os.path.relpath(f, ROOT), d
     return None, {}
 
@@ -94,7 +95,8 @@ def parse(argv=None):
     ap.add_argument("--no-inclusive", action="store_true", help="N = 1: skip the upload + sweep + download calls (inclusive_ms_per_step)")
     ap.add_argument("--profile", action="store_true", help="the headline case only, nothing attached and no child process: what "
                     "tools/profile_round.sh runs under rocprofv3")
-    ap.add_argument("--no-exact", action="store_true", help="N = 1: skip the run of the exact-libm build attached to the line")
+    ap.add_argument("--no-exact", action="store_true", help="N = 1: skip the runs of the exact-libm build attached to the line")
+    ap.add_argument("--no-forward-only", action="store_true", help="N = 1: skip the forward-only case (BASELINE.json configs[1]) attached to the line")
     ap.add_argument("--secondary-grid", type=int, default=1024)
     ap.add_argument("--cpu-grid", type=int, default=256)
     ap.add_argument("--cpu-nt", type=int, default=360)
@@ -103,7 +105,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-solo-nt", type=int, default=160)
     a = ap.parse_args(argv)
     if a.profile:
-        a.no_secondary = a.no_tile_solo = a.no_exact = a.no_cpu_baseline = a.no_inclusive = True
+        a.no_secondary = a.no_tile_solo = a.no_exact = a.no_cpu_baseline = a.no_inclusive = a.no_forward_only = True
         if a.gpus != 1:
             ap.error("--profile is a single-process run")
     return a
@@ -222,7 +224,7 @@ def chunk_plan(nt, cells, hbm_bytes, forcing_bytes, structure, forced=0):
 class Case:
     """One benchmark workload: plan + forcing resident in HBM + observations, ready to sweep."""
 
-    def __init__(self, a, torch, dev, local, parts, me, world, trows, tcols, solo, raw_forcing):
+    def __init__(self, a, torch, dev, local, parts, me, world, trows, tcols, solo, raw_forcing, adjoint=None):
         import smash_amd
         from smash_amd import synth, tiles
         from smash_amd.solver import Solver
@@ -311,8 +313,9 @@ class Case:
         if len(loc):
             sol.set_qobs(self.out.qsim)
         sol.upload(self.par, self.sta)
-        if not a.forward_only:
+        if (not a.forward_only) if adjoint is None else adjoint:
             sol.chunking()                               # allocates the tapes of the reverse sweep now (set-up), not in the first sweep
+        self.hbm = sol.hbm()
         self.setup_s = time.perf_counter() - t_setup
 
     def close(self):
@@ -366,7 +369,7 @@ def roofline(tm, adjoint, structure, grid):
     per_cs = 8.0 if dom.startswith("vert") else 4.0               # routing reads qt once: it is not a streaming kernel of the forcing
     alg_bytes = per_cs * cs_launch
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    src, prof = pmc_profile(grid, tm["n_chunks"])
+    src, prof = pmc_profile(grid, tm["n_chunks"], not adjoint)
     pk = prof.get("sx_k_" + dom) if structure == "gr-b" else None
     traffic = pk["hbm_bytes_per_cellstep_corrected"] * cs_launch if pk and "hbm_bytes_per_cellstep_corrected" in pk else None
     r = {"bound": "hbm", "kernel": "sx_k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -400,12 +403,13 @@ def roofline(tm, adjoint, structure, grid):
 def attached_case(a, torch, dev, local, barrier, adjoint, grid_rc, parts, me, solo, steps, warmup, what):
     """One more workload measured in this process after the headline case has been closed: returns the object attached to the line."""
     try:
-        c = Case(a, torch, dev, local, parts, me, 1, grid_rc[0], grid_rc[1], solo, False)
+        c = Case(a, torch, dev, local, parts, me, 1, grid_rc[0], grid_rc[1], solo, False, adjoint)
         secs, tm = timed_sweeps(c, steps, warmup, adjoint, barrier)
         o = {"workload": what, "value": float(c.sol.ncells) * a.nt * steps / secs, "unit": "cell-timesteps/s", "steps": steps, "warmup": warmup,
              "ms_per_step": secs * 1e3 / steps, "grid": [c.nrow, c.ncol], "tile": list(grid_rc), "active_cells": int(c.sol.ncells),
              "n_chunks": int(tm["n_chunks"]), "chunk_steps": int(tm["chunk_steps"]), "pipe_steps": int(tm["pipe_steps"]),
-             "routing_rounds": int(tm["n_rounds"]), "hbm_plan_gb": tm["device_bytes"] / 1e9, "forcing": c.forcing,
+             "routing_rounds": int(tm["n_rounds"]), "hbm_plan_gb": tm["device_bytes"] / 1e9,
+             "hbm_free_at_plan_gb": c.hbm["free_at_plan"] / 1e9, "forcing": c.forcing,
              "kernel_ms_per_step": {"sx_k_" + k: round(tm[k + "_ms"], 3) for k in KERNELS},
              "kernel_launches_per_step": {"sx_k_" + k: int(tm[k + "_launches"]) for k in KERNELS},
              "roofline": roofline(tm, adjoint, a.structure, [c.nrow, c.ncol]) if parts == 1 else None, "setup_s": c.setup_s}
@@ -546,6 +550,9 @@ def main():
             "kernel_cellsteps_per_step": {"sx_k_" + k: tm[k + "_cellsteps"] for k in KERNELS},
             "device_sweep_ms": tm["sweep_ms"], "cost": cost, "setup_s": case.setup_s,
             "hbm_plan_gb": tm["device_bytes"] / 1e9,
+            # free HBM when the plan chose its storage-chunk length (the forcing was resident by then): the chunk count -- and with it the
+            # number of forward passes of the checkpointed adjoint -- follows from this figure, not from the card's nominal size
+            "hbm_free_at_plan_gb": case.hbm["free_at_plan"] / 1e9, "hbm_total_gb": case.hbm["total"] / 1e9,
         }
         if a.profile:
             # what tools/pmc_summary.py divides the counters by: every sweep this process ran, and the cell-steps each kernel
@@ -566,7 +573,7 @@ def main():
             line["cpu_baseline"] = cpu
     # N = 1, default workload: two more cases measured on the same GPU and attached to the line
     default_case = world == 1 and not solo and not a.raw_forcing and (trows, tcols) == (2048, 2048) and nt == 8760 and line is not None
-    if default_case and not (a.no_secondary and a.no_tile_solo):
+    if default_case and not (a.no_secondary and a.no_tile_solo and a.no_forward_only):
         case.close()
         del case, sol
         if not a.no_secondary and a.secondary_grid > 0:
@@ -583,6 +590,15 @@ def main():
                 "`--gpus N` line, so value(N) / (N x this value) is the price of the decomposition's pipeline and exchange")
             o["per_gpu_value"] = o.get("value")
             line["tile_solo"] = o
+        if not a.no_forward_only and adjoint:
+            g = a.secondary_grid or 1024
+            o = attached_case(
+                a, torch, dev, local, barrier, False, (g, g), 1, 0, False, min(a.steps, 5), 1,
+                f"{g}x{g} synthetic catchment, hourly x {nt} steps, {a.structure}, ONE FORWARD sweep = discharge at the gauges + cost "
+                "(BASELINE.json configs[1]; the work of the reference's mw_forward::forward, mw_forward.f90:18-39); compact forcing resident, "
+                "no tape; roofline: 8 algorithmic bytes per cell-step (prcp + pet once, SURVEY.md 8d)")
+            o["metric"] = "cell-timesteps/s, forward sweep"
+            line["forward_only"] = o
     # N = 1: the same workload on the exact-libm build (libsmashx_exact.so: bit-identical to the reference on every golden vector),
     # in a child process -- the library is chosen when smash_amd is imported
     if (default_case and not a.no_exact
@@ -592,18 +608,26 @@ def main():
             case.close()
             del case, sol
         torch.cuda.empty_cache()
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--profile", "--grid", "1024",
+        def exact_child(grid, steps):
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "1", "--profile", "--grid", str(grid),
                                 "--structure", a.structure], env=dict(os.environ, SMASHX_EXACT_LIBM="1"), capture_output=True,
                                text=True, timeout=600)
             e = json.loads(r.stdout.strip().splitlines()[-1])
-            line["exact_libm"] = {"what": "the 1024x1024 workload of `secondary` on libsmashx_exact.so (-DSX_EXACT_LIBM=1: glibc 2.35 expf/logf/powf/tanhf restated, IEEE divisions): "
-                                          "bit-identical to the reference Fortran on all 318 golden outputs (profiles/r3_parity_exact.md); the "
-                                          "default build differs from it by libm rounding only (profiles/r3_parity_default.md)",
-                                  "value": e["value"], "ms_per_step": e["ms_per_step"], "steps": 2, "warmup": 1, "cost": e["cost"],
-                                  "kernel_ms_per_step": e["kernel_ms_per_step"]}
+            return {"grid": [grid, grid], "value": e["value"], "ms_per_step": e["ms_per_step"], "steps": steps, "warmup": 1, "cost": e["cost"],
+                    "n_chunks": e["config"]["n_chunks"], "kernel_ms_per_step": e["kernel_ms_per_step"]}
+        try:
+            e = exact_child(1024, 2)
+            line["exact_libm"] = dict(e, what="libsmashx_exact.so (-DSX_EXACT_LIBM=1: glibc 2.35 expf/logf/powf/tanhf restated, IEEE divisions): "
+                                              "bit-identical to the reference Fortran on all 318 golden outputs (profiles/r3_parity_exact.md); the "
+                                              "default build differs from it by libm rounding only (profiles/r3_parity_default.md).  Top level: the "
+                                              "1024x1024 workload of `secondary`; `headline`: the 2048x2048 workload of this line's `value`")
+            h = exact_child(2048, max(3, min(a.steps, 5)))
+            h["slowdown_vs_default"] = h["ms_per_step"] / line["ms_per_step"]
+            line["exact_libm"]["headline"] = h
+            if isinstance(line.get("secondary"), dict) and line["secondary"].get("ms_per_step"):
+                line["exact_libm"]["slowdown_vs_default"] = e["ms_per_step"] / line["secondary"]["ms_per_step"]
         except Exception as ex:  # pragma: no cover
-            line["exact_libm"] = {"value": None, "error": str(ex)}
+            line.setdefault("exact_libm", {"value": None})["error"] = str(ex)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

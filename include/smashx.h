@@ -139,7 +139,11 @@ int smashx_plan_cell_order(const smashx_plan* plan, int* rows, int* cols);
  * Stays resident in HBM across sweeps. */
 int smashx_set_forcing(smashx_plan* plan, const float* prcp, const float* pet, int sparse);
 /* device-resident block: d_prcp/d_pet are DEVICE pointers to (t1-t0, ncells) arrays, cell index in
- * plan order (smashx_plan_cell_order) fastest.  Used by bench.py to build the forcing in HBM. */
+ * plan order (smashx_plan_cell_order) fastest.  Used by bench.py to build the forcing in HBM.
+ * The forcing counts as set once blocks have covered every step of [0, nt).  fp32 rows: blocks may arrive in any order and a
+ * block may be refreshed later (coverage is only forgotten when the layout is reset).  Compact layout: a block with t0 = 0 opens
+ * a NEW upload cycle (the daily PET field and the gap value of the previous data set are dropped, and so is the coverage), the
+ * other blocks of the cycle may follow in any order. */
 int smashx_set_forcing_device_block(smashx_plan* plan, int t0, int t1, const float* d_prcp, const float* d_pet);
 /* Lossless compact residency of the forcing.  The reference's reader forms every value it stores from far fewer bits:
  *   prcp(cell, t) = real(k) * prcp_conversion_factor, k the raster's integer depth (0.1 mm units in its datasets), or -99
@@ -250,6 +254,11 @@ int smashx_tile_probe(const smashx_config* cfg, const smashx_mesh* mesh, int* in
 int smashx_halo_counts(const smashx_plan* plan, int* n_out, int* n_in);
 int smashx_halo_edges(const smashx_plan* plan, int* out_src, int* out_dst, int* in_src, int* in_dst);
 int smashx_plan_chunking(smashx_plan* plan, int* chunk_steps, int* pipe_steps);   /* fixes and returns the chunk lengths */
+/* HBM accounting of a plan: out = {free bytes on the device at the moment the storage-chunk length was chosen (-1 before then),
+ * total bytes of the device, bytes the plan holds now}.  With chunk_steps = 0 the chunk length -- and with it the number of forward
+ * passes of a checkpointed adjoint -- follows from the first number: a card with less free memory (another process, a larger RCCL
+ * buffer pool) plans more, shorter chunks; bench.py prints it beside hbm_plan_gb. */
+int smashx_plan_hbm(const smashx_plan* plan, double out[3]);
 int smashx_set_halo(smashx_plan* plan, float* d_out_buf, float* d_in_buf, smashx_halo_fn fn, void* user);
 
 /* Cost terms that span the tiles of a decomposition (round 3; reference smash/solver/optimize/mwd_cost.f90:139-154, 159-245).

@@ -25,7 +25,7 @@ SYMBOLS = [
     "smashx_comm_unique_id", "smashx_comm_create", "smashx_comm_destroy", "smashx_comm_allreduce_sum", "smashx_set_exchange",
     "smashx_set_median_slots", "smashx_selftest_paths",
     "smashx_lbfgsb_create", "smashx_lbfgsb_step", "smashx_lbfgsb_destroy", "smashx_lbfgsb_iterations", "smashx_lbfgsb_message",
-    "smashx_lbfgsb_evaluations", "smashx_lbfgsb_projected_gradient",
+    "smashx_lbfgsb_evaluations", "smashx_lbfgsb_projected_gradient", "smashx_plan_hbm",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)

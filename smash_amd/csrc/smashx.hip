@@ -348,11 +348,15 @@ struct smashx_plan {
     int chain_from = 1;              // first chained round
     bool split_v = false;            // SMASHX_SPLIT_V=1: vertical kernels in two cell ranges so that routing round 0 overlaps the second.
                                      // Measured slower (185 vs 175 ms at 1024^2 x 8760: both kernels lose more than the overlap hides): off.
-    size_t debug_vlds = 0;           // SMASHX_DEBUG_VLDS: bytes of unused dynamic LDS per vertical workgroup (occupancy experiments)
+    size_t vlds_fwd = 0, vlds_adj = 0;   // bytes of unused dynamic LDS per vertical workgroup: caps the resident vertical workgroups of a compute unit so
+                                     // that a routing group finds registers beside them (SMASHX_VLDS_FWD / _ADJ; SMASHX_DEBUG_VLDS sets both)
+    std::vector<hipEvent_t> buf_free;    // per pipeline sub-chunk: the R stream has finished with this part of the chunk buffers
     int n0 = 0;                      // cells of the round-0 groups = [0, n0) in device order
     std::vector<double> round_ncells;  // cells per routing round
     bool chain_used = false;         // a chained launch ran in the current sweep: check the stall flag afterwards
     bool chain = true;               // all routing rounds in one launch (progress counters), see sx_kernels.h
+    bool chain_stream = false;       // the chained launches of the pipeline sub-chunks on their own stream (stream_c): round 0 of sub-chunk j + 1 does not
+                                     // queue behind the latency-bound chained rounds of sub-chunk j (single domain only)
     // tile boundary exchange
     int n_out = 0, n_in = 0;
     int *d_out_x = nullptr, *d_in_x = nullptr;
@@ -363,8 +367,10 @@ struct smashx_plan {
     std::vector<PeerSeg> out_segs, in_segs;
     int *d_out_xp = nullptr, *d_in_xp = nullptr;     // exchange slots of the out / in edges in peer-grouped order
     float *x_out = nullptr, *x_in = nullptr;         // [edge][Tp/4] float4
+    float* x_keep = nullptr; size_t x_keep_cap = 0;  // received inlet series of the storage chunks the reverse sweep recomputes: [chunk][sub-chunk][edge][Tp/4] float4
     std::vector<void*> allocs; std::vector<size_t> alloc_bytes;
     double bytes = 0;
+    double hbm_free_at_plan = -1.0, hbm_total = -1.0;    // hipMemGetInfo when the storage-chunk length was chosen (smashx_plan_hbm)
     SxDeviceArrays A{};
     // extra device storage
     int* d_cell_flat = nullptr;      // k -> flat (row + col*nrow)
@@ -491,6 +497,11 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
             return fail(SMASHX_E_ARG, "a tile with boundary series needs an explicit chunk_steps (identical on every rank; pipe_steps = 0 then means no sub-chunks)");
         const int nt16 = (p->nt + 15) / 16 * 16;
         int Tc = p->cfg.chunk_steps > 0 ? (p->cfg.chunk_steps + 15) / 16 * 16 : 0;
+        {
+            size_t fr = 0, tot = 0;
+            HIPCHK(hipMemGetInfo(&fr, &tot));
+            p->hbm_free_at_plan = (double)fr; p->hbm_total = (double)tot;
+        }
         if (Tc == 0) {
             size_t fr = 0, tot = 0;
             HIPCHK(hipMemGetInfo(&fr, &tot));
@@ -600,7 +611,7 @@ void launch_vert_fwd(smashx_plan* p, const SxDeviceArrays& B, bool tape, int t0,
     const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
     p->mark_begin(0, p->stream, (double)(B.k1 - B.k0) * T);
     const bool cf = B.prcp16 != nullptr;
-    const size_t vl = p->debug_vlds;     // diagnostics: unused dynamic LDS that caps the resident waves (SMASHX_DEBUG_VLDS)
+    const size_t vl = p->vlds_fwd;       // unused dynamic LDS that caps the resident vertical workgroups per compute unit
     if (tape) { if (cf) hipLaunchKernelGGL((sx_k_vert_fwd<ST, true, true>), grid, block, vl, p->stream, B, t0, T);
                 else    hipLaunchKernelGGL((sx_k_vert_fwd<ST, true, false>), grid, block, vl, p->stream, B, t0, T); }
     else      { if (cf) hipLaunchKernelGGL((sx_k_vert_fwd<ST, false, true>), grid, block, vl, p->stream, B, t0, T);
@@ -635,7 +646,7 @@ void vert_adj(smashx_plan* p, int off, int t0, int T, int k0 = 0, int k1 = -1) {
     const dim3 grid((B.k1 - B.k0 + SX_VBLOCK - 1) / SX_VBLOCK), block(SX_VBLOCK);
     p->mark_begin(3, p->stream, (double)(B.k1 - B.k0) * T);
     const bool cf = B.prcp16 != nullptr;
-    const size_t vl = p->debug_vlds;
+    const size_t vl = p->vlds_adj;
 #define SX_VADJ(ST) do { if (cf) hipLaunchKernelGGL((sx_k_vert_adj<ST, true>), grid, block, vl, p->stream, B, t0, T); \
                          else hipLaunchKernelGGL((sx_k_vert_adj<ST, false>), grid, block, vl, p->stream, B, t0, T); } while (0)
     switch (p->st) {
@@ -887,7 +898,10 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         A.ngroups = p->sch.ngroups;
         const char* e = getenv("SMASHX_CHAIN_ROUNDS");
         p->chain = !(e && e[0] == '0');
-        if (const char* dv = getenv("SMASHX_DEBUG_VLDS")) p->debug_vlds = (size_t)std::max(0, atoi(dv));
+        if (const char* dv = getenv("SMASHX_DEBUG_VLDS")) p->vlds_fwd = p->vlds_adj = (size_t)std::max(0, atoi(dv));
+        if (const char* cs = getenv("SMASHX_CHAIN_STREAM")) p->chain_stream = atoi(cs) != 0;
+        if (const char* dv = getenv("SMASHX_VLDS_FWD")) p->vlds_fwd = (size_t)std::max(0, atoi(dv));
+        if (const char* dv = getenv("SMASHX_VLDS_ADJ")) p->vlds_adj = (size_t)std::max(0, atoi(dv));
         const char* sv = getenv("SMASHX_SPLIT_V");
         p->split_v = sv && sv[0] == '1';
         p->round_ncells.assign(p->sch.nrounds, 0.0);
@@ -1018,6 +1032,7 @@ int smashx_plan_cell_order(const smashx_plan* p, int* rows, int* cols) {
 static int alloc_forcing(smashx_plan* p) {
     if (p->d_prcp || p->d_prcp16) return 0;
     int rc;
+    p->block_seen.clear();           // new rows: nothing is covered yet
     if (p->flay.compact) {
         p->ndays = (p->nt + p->flay.pet_hour0 + 23) / 24;
         if ((rc = p->dmalloc(&p->d_prcp16, (size_t)p->nt * p->npad))) return rc;
@@ -1079,6 +1094,7 @@ int smashx_set_forcing_layout(smashx_plan* p, const smashx_forcing_layout* lay) 
         drop_compact(p);
         p->dfree(p->d_prcp); p->dfree(p->d_pet); p->d_prcp = p->d_pet = nullptr; p->A.prcp = p->A.pet = nullptr;
         p->have_forcing = false;
+        p->block_seen.clear();
     }
     if (lay->compact) {
         if (p->cfg.dt != 3600.f) return fail(SMASHX_E_UNSUPPORTED, "compact forcing: the daily-PET form is defined for dt = 3600 s");
@@ -1152,8 +1168,12 @@ int smashx_set_forcing(smashx_plan* p, const float* prcp, const float* pet, int 
 
 // The forcing only counts as set once device blocks have covered every step of [0, nt): a sweep started earlier would close the
 // daily PET of days it has not seen (k_close_petd pins them to 0) and later blocks for those days would then fail verification.
-static void mark_block(smashx_plan* p, int t0, int t1) {
-    if (t0 == 0 || (int)p->block_seen.size() != p->nt) { if (t0 == 0) p->block_seen.assign(p->nt, 0); else p->block_seen.resize(p->nt, 0); }
+// Coverage is only forgotten where the data it stands for is: when the rows are (re)allocated (alloc_forcing, a new layout) and -- compact
+// layout only -- when a block starting at step 0 opens a new upload cycle (its daily PET field is reset there, see below).  fp32 rows may
+// be sent in any order and refreshed block by block.
+static void mark_block(smashx_plan* p, int t0, int t1, bool new_cycle) {
+    if (new_cycle) p->block_seen.assign(p->nt, 0);
+    p->block_seen.resize(p->nt, 0);
     std::fill(p->block_seen.begin() + t0, p->block_seen.begin() + t1, 1);
     p->have_forcing = std::find(p->block_seen.begin(), p->block_seen.end(), 0) == p->block_seen.end();
 }
@@ -1174,13 +1194,13 @@ int smashx_set_forcing_device_block(smashx_plan* p, int t0, int t1, const float*
             return fail(SMASHX_E_UNSUPPORTED, "forcing block [" + std::to_string(t0) + ", " + std::to_string(t1) + ") is not of the compact form "
                         "(prcp = k * factor with k < 65535 or one gap value; pet = daily * ratio(hour)): reset the layout to fp32 and send the forcing again");
         }
-        mark_block(p, t0, t1);
+        mark_block(p, t0, t1, t0 == 0);
         return 0;
     }
     HIPCHK(hipMemcpy2DAsync(p->d_prcp + (size_t)t0 * p->npad, (size_t)p->npad * 4, d_prcp, (size_t)p->n * 4, (size_t)p->n * 4, t1 - t0, hipMemcpyDeviceToDevice, p->stream));
     HIPCHK(hipMemcpy2DAsync(p->d_pet + (size_t)t0 * p->npad, (size_t)p->npad * 4, d_pet, (size_t)p->n * 4, (size_t)p->n * 4, t1 - t0, hipMemcpyDeviceToDevice, p->stream));
     HIPCHK(hipStreamSynchronize(p->stream));
-    mark_block(p, t0, t1);
+    mark_block(p, t0, t1, false);
     return 0;
 }
 
@@ -1450,6 +1470,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     if ((p->n_out > 0 || p->n_in > 0) && !p->halo_fn && !p->xcomm)
         return fail(SMASHX_E_STATE, "tile has boundary series but no exchange is set (smashx_set_exchange / smashx_set_halo)");
     p->launches.clear(); p->pool_used = 0;
+    p->buf_free.clear();             // (the previous sweep ended with both streams drained)
     hipStream_t sV = p->stream, sR = p->stream_r;
     if ((rc = close_forcing(p))) return rc;
     HIPCHK(hipEventRecord(p->ev0, sV));
@@ -1480,12 +1501,42 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     // run into its poll limit although every input arrived in the end (cause not found); the launch per sub-chunk is what tiles run.
     const char* pers_env = getenv("SMASHX_PERSIST");
     const bool persist_on = pers_env && pers_env[0] == '1' && (!halo || pers_env[1] == 'x');
-    auto forward_chunk = [&](int c, bool tape) -> int {
+    const bool cstream = p->chain_stream && !halo && !persist_on && !split && chain_first(p) < p->sch.nrounds;
+    // Recomputation of a storage chunk (reverse sweep) needs no neighbour: the inlet series a rank received for that chunk in the first
+    // pass are kept (n_in edges x Tc steps x 4 B per chunk) and unpacked again, and nothing is sent -- the ranks downstream kept theirs.
+    // A sweep then changes direction twice between the ranks (forward -> reverse) instead of twice per recomputed chunk more.
+    const int ns_max = nsub_of(p->Tc);
+    const size_t keep_sub = (size_t)std::max(p->n_in, 1) * (size_t)((p->Tp + 3) / 4) * 4;      // floats of one sub-chunk's message
+    const bool keep_in = adjoint && halo && p->n_in > 0 && C > 1;
+    if (keep_in && p->x_keep_cap < keep_sub * ns_max * (size_t)(C - 1)) {
+        if (p->x_keep) p->dfree(p->x_keep);
+        p->x_keep = nullptr; p->x_keep_cap = 0;
+        if ((rc = p->dmalloc(&p->x_keep, keep_sub * ns_max * (size_t)(C - 1)))) return rc;
+        p->x_keep_cap = keep_sub * ns_max * (size_t)(C - 1);
+    }
+    // the series of the in edges for sub-chunk jb of chunk c reach the exchange rows: received (and kept), or taken from the first pass
+    auto inlet_series = [&](int c, int jb, int off, int t0, int T, bool recompute, hipStream_t st) -> int {
+        float* msg = native ? p->x_in : p->halo_in;
+        float* kept = (keep_in && c < C - 1) ? p->x_keep + ((size_t)c * ns_max + jb) * keep_sub : nullptr;
+        const size_t bytes = (size_t)p->n_in * (size_t)((T + 3) / 4) * 4 * sizeof(float);
+        if (recompute && kept) {
+            HIPCHK(hipMemcpyAsync(msg, kept, bytes, hipMemcpyDeviceToDevice, st));
+        } else {
+            if ((rc = hook(0, t0, T, st))) return rc;      // the message buffer now holds the upstream tiles' series
+            if (kept) HIPCHK(hipMemcpyAsync(kept, msg, bytes, hipMemcpyDeviceToDevice, st));
+        }
+        halo_move(false, false, off, T, st);
+        return 0;
+    };
+    auto forward_chunk = [&](int c, bool tape, bool recompute = false) -> int {
         const int t0c = c * p->Tc, Tcur = chunk_len(p, c), ns = nsub_of(Tcur);
         std::vector<hipEvent_t> ev(ns), ev_rest(ns, nullptr);
         // split: the cells of round 0 first; routing round 0 then runs under the vertical kernel of the remaining cells
         auto launch_v = [&](int jb) -> int {
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
+            // this part of the chunk buffers was last used by the R stream in the previous pass over them (the reverse sweep ends on
+            // the V stream): wait for that sub-chunk only, so that the routing of chunk c's tail runs under chunk c + 1's first kernels
+            if (jb < (int)p->buf_free.size() && p->buf_free[jb]) { HIPCHK(hipStreamWaitEvent(sV, p->buf_free[jb], 0)); p->buf_free[jb] = nullptr; }
             if (split) {
                 vert_fwd(p, off, tape, t0c + off, T, 0, p->n0);
                 ev[jb] = p->event(); HIPCHK(hipEventRecord(ev[jb], sV));
@@ -1519,10 +1570,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
             std::vector<hipEvent_t> e_r0(ns);
             for (int jb = 0; jb < ns; ++jb) {
                 const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
-                if (halo && p->n_in > 0) {
-                    if ((rc = hook(0, t0c + off, T, sR))) return rc;
-                    halo_move(false, false, off, T, sR);
-                }
+                if (halo && p->n_in > 0 && (rc = inlet_series(c, jb, off, t0c + off, T, recompute, sR))) return rc;
                 HIPCHK(hipStreamWaitEvent(sR, ev[jb], 0));
                 route_fwd_rounds(p, off, tape, t0c + off, T, sR);
                 hipLaunchKernelGGL(sx_k_gate_bump, dim3(1), dim3(64), 0, sR, SX_PROG_GATE(p->A), std::min((off + T + 3) / 4, nb));
@@ -1533,7 +1581,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
                     route_fwd_chained(p, 0, tape, t0c, Tcur, sC, true);
                 }
             }
-            for (int jb = 0; jb < ns && halo && p->n_out > 0; ++jb) {
+            for (int jb = 0; jb < ns && halo && p->n_out > 0 && !recompute; ++jb) {
                 const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
                 HIPCHK(hipStreamWaitEvent(sX, e_r0[jb], 0));
                 if (p->n_out_prod > 0)
@@ -1549,21 +1597,38 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
         }
         for (int jb = 0; jb < ns; ++jb) {
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
-            if (halo && p->n_in > 0) {
-                if ((rc = hook(0, t0c + off, T, sR))) return rc;      // in_buf now holds the upstream tiles' series
-                halo_move(false, false, off, T, sR);
-            }
+            if (halo && p->n_in > 0 && (rc = inlet_series(c, jb, off, t0c + off, T, recompute, sR))) return rc;
             HIPCHK(hipStreamWaitEvent(sR, ev[jb], 0));
-            route_fwd(p, off, tape, t0c + off, T, ev_rest[jb]);
-            if (halo && p->n_out > 0) {
+            hipStream_t s_done = sR;
+            if (cstream) {
+                // round 0 on the R stream, the chained rounds behind it on their own stream: round 0 of the next sub-chunk does not wait for them
+                route_fwd_rounds(p, off, tape, t0c + off, T, sR, ev_rest[jb]);
+                hipEvent_t e_r0 = p->event();
+                HIPCHK(hipEventRecord(e_r0, sR));
+                HIPCHK(hipStreamWaitEvent(p->stream_c, e_r0, 0));
+                route_fwd_chained(p, off, tape, t0c + off, T, p->stream_c, false, ev_rest[jb]);
+                s_done = p->stream_c;
+            } else
+                route_fwd(p, off, tape, t0c + off, T, ev_rest[jb]);
+            if (halo && p->n_out > 0 && !recompute) {       // (a recomputed chunk sends nothing: every rank kept what it received)
                 halo_move(true, true, off, T, sR);
                 if ((rc = hook(1, t0c + off, T, sR))) return rc;
             }
+            if ((int)p->buf_free.size() <= jb) p->buf_free.resize(jb + 1, nullptr);
+            p->buf_free[jb] = p->event();
+            HIPCHK(hipEventRecord(p->buf_free[jb], s_done));
+        }
+        if (cstream) {   // what follows on the R stream (cost, checkpoint of the routing store, the reverse sweep) sees the chained rounds done
+            hipEvent_t e_c = p->event();
+            HIPCHK(hipEventRecord(e_c, p->stream_c));
+            HIPCHK(hipStreamWaitEvent(sR, e_c, 0));
         }
         return 0;
     };
-    // before a storage chunk's buffers are overwritten, the V stream must see the R stream drained
+    // before a storage chunk's buffers are overwritten, the V stream must see the R stream done with them: sub-chunk by sub-chunk
+    // through buf_free (forward_chunk); only the gated launch per storage chunk, which has no per-sub-chunk end, drains the R stream
     auto v_waits_r = [&]() -> int {
+        if (!persist_on) return 0;
         hipEvent_t e = p->event();
         HIPCHK(hipEventRecord(e, sR));
         HIPCHK(hipStreamWaitEvent(sV, e, 0));
@@ -1642,7 +1707,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
                 for (int i = 0; i < 5; ++i) src[i] = p->ckpt + ((size_t)c * 5 + i) * p->npad;
                 if ((rc = v_waits_r())) return rc;
                 if ((rc = restore_states(p, src))) return rc;
-                if ((rc = forward_chunk(c, true))) return rc;
+                if ((rc = forward_chunk(c, true, true))) return rc;
             }
             const int nsa = (Tcur + p->Tpa - 1) / p->Tpa;
             const bool persa = persist_on && nsa > 1 && !split && chain_first(p) < p->sch.nrounds;
@@ -1701,6 +1766,20 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
                     halo_move(false, true, off, T, sR);
                 }
                 hipEvent_t e_rest = split ? p->event() : nullptr;
+                if (cstream) {
+                    // the chained rounds (roots of the basin first) run ahead on their own stream, sub-chunk after sub-chunk; round 0 of a
+                    // sub-chunk follows its chained rounds, the vertical adjoint follows round 0
+                    if (jb == nsa - 1) {      // the first one of this storage chunk: the forward chunk, the cost seeds and the accumulators are behind this point
+                        hipEvent_t e_r = p->event();
+                        HIPCHK(hipEventRecord(e_r, sR));
+                        HIPCHK(hipStreamWaitEvent(p->stream_c, e_r, 0));
+                    }
+                    route_adj_chained(p, off, t0c + off, T, p->stream_c, false);
+                    hipEvent_t e_ca = p->event();
+                    HIPCHK(hipEventRecord(e_ca, p->stream_c));
+                    HIPCHK(hipStreamWaitEvent(sR, e_ca, 0));
+                    route_adj_rounds(p, off, t0c + off, T, sR, e_rest);
+                } else
                 route_adj(p, off, t0c + off, T, e_rest);
                 hipEvent_t e = p->event();
                 HIPCHK(hipEventRecord(e, sR));
@@ -1865,6 +1944,13 @@ int smashx_plan_chunking(smashx_plan* p, int* chunk_steps, int* pipe_steps) {
     return 0;
 }
 
+// out = {free HBM when the storage-chunk length was chosen (bytes; -1 before that), total HBM of the device, bytes the plan holds now}
+int smashx_plan_hbm(const smashx_plan* p, double out[3]) {
+    if (!p || !out) return fail(SMASHX_E_ARG, "null argument");
+    out[0] = p->hbm_free_at_plan; out[1] = p->hbm_total; out[2] = p->bytes;
+    return 0;
+}
+
 int smashx_set_halo(smashx_plan* p, float* d_out_buf, float* d_in_buf, smashx_halo_fn fn, void* user) {
     if (!p) return fail(SMASHX_E_ARG, "null plan");
     if (fn && ((p->n_out > 0 && !d_out_buf) || (p->n_in > 0 && !d_in_buf))) return fail(SMASHX_E_ARG, "halo buffers missing");
@@ -1923,6 +2009,12 @@ int smashx_comm_create(const unsigned char id[SMASHX_COMM_ID_BYTES], int rank, i
 }
 
 static void smashx_forget_comm(smashx_plan* p, SxComm* c) { if (p->xcomm == c) p->xcomm = nullptr; }
+// a plan leaves the list of the communicator it pointed to whenever that pointer changes (unset, switched, plan destroyed): a
+// communicator's list only ever holds live plans that still use it
+static void smashx_detach_plan(smashx_plan* p) {
+    if (SxComm* c = p->xcomm) c->plans.erase(std::remove(c->plans.begin(), c->plans.end(), p), c->plans.end());
+    p->xcomm = nullptr;
+}
 
 int smashx_comm_destroy(void* comm) {
     SxComm* c = (SxComm*)comm;
@@ -1951,7 +2043,7 @@ int smashx_comm_allreduce_sum(void* comm, double* values, int n) {
 int smashx_set_exchange(smashx_plan* p, void* comm, const int* out_peer, const int* in_peer) {
     if (!p) return fail(SMASHX_E_ARG, "null plan");
     SxComm* c = (SxComm*)comm;
-    if (!c) { p->xcomm = nullptr; return 0; }
+    if (!c) { smashx_detach_plan(p); return 0; }
     // The call is collective (an agreement all-reduce, then one grouped hello exchange): a rank that left early would leave its
     // neighbours waiting inside ncclGroupEnd for ever.  So everything that can fail locally -- argument checks, regrouping, allocations --
     // happens FIRST and only feeds a status word; the ranks then agree on the status together with the chunking, and enter the hello
@@ -2036,6 +2128,7 @@ int smashx_set_exchange(smashx_plan* p, void* comm, const int* out_peer, const i
     if (p->d_in_xp) p->dfree(p->d_in_xp);
     p->d_out_xp = d_oxp; p->d_in_xp = d_ixp;
     p->out_segs.swap(out_segs); p->in_segs.swap(in_segs);
+    if (p->xcomm != c) smashx_detach_plan(p);        // re-targeted: the previous communicator forgets this plan
     p->xcomm = c;
     if (std::find(c->plans.begin(), c->plans.end(), p) == c->plans.end()) c->plans.push_back(p);
     return 0;

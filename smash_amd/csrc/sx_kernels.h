@@ -625,6 +625,12 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
 #ifndef SX_MU
 #define SX_MU 4
 #endif
+#ifndef SX_MU_F
+#define SX_MU_F SX_MU     // forward kernel
+#endif
+#ifndef SX_MU_A
+#define SX_MU_A SX_MU     // reverse kernel
+#endif
 // Timing-only builds for the anatomy of a routing super-step (tools/anatomy.sh -> profiles/r2_routing_anatomy*.json): each switch
 // removes one ingredient; results are void, the schedule and the progress protocol are not touched (no switch can hang a launch).
 //   SX_ABL_NOBAR (no workgroup barrier)  SX_ABL_NOREL (publications without release fence)  SX_ABL_NOLDS (children not read from LDS)
@@ -644,11 +650,19 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
 #ifndef SX_ABL_A_NOHR
 #define SX_ABL_A_NOHR 0
 #endif
+#ifndef SX_MAXGROUP
 #define SX_MAXGROUP 512   // largest routing workgroup (group_size): 8 waves = 2 per SIMD
+#endif
 // Occupancy of the routing kernels: 132 (forward) / 154 (adjoint) registers = ONE resident group per CU.  Measured at
 // 1024^2 x 8760: compiling them for two groups per CU (128 registers) makes round 0 slower (route_fwd 26.0 -> 27.7 ms; the
 // adjoint spills, 28 -> 98 ms) and leaves the chained rounds unchanged (their time is (blocks + longest cell path) x the
 // latency of one super-step, whoever is resident), so one group per CU stays.
+// Issue priority of the routing waves (s_setprio 0..3).  Beside the vertical kernels -- four to six waves per SIMD that always have an
+// instruction ready -- a routing wave at the default priority gets one issue slot in five or seven, and its super-step is a latency
+// chain (LDS read, ~140 instructions, barrier): raised, it issues as if it were alone and costs the vertical waves only the slots it uses.
+#ifndef SX_R_PRIO
+#define SX_R_PRIO 0
+#endif
 #ifndef SX_RLB_F
 #define SX_RLB_F 1        // waves per SIMD the chained forward kernel is compiled for (a resident group = 2 per SIMD)
 #endif
@@ -676,6 +690,7 @@ template <bool TAPE, bool CHAIN, int TMODE>
 __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, const int g, const int g0, const int gend, const int t0, const int T,
                                                    const bool gated) {
     constexpr bool TAN = (TMODE == 2);
+    constexpr int MU = SX_MU_F, PK = SX_PK * 4 / MU;     // super-steps per macro-step; macro-steps between two publications
     constexpr bool DFORM = (TMODE == 1);
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];   // [2][blockDim.x]
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
@@ -734,28 +749,28 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
     if (CHAIN && gated && valid && !wprog) wprog = SX_PROG_GATE(A);
     auto fetch = [&](int tb) -> float4 { return cell >= 0 ? sx_gload4s(src + (size_t)tb * sstride) : sx_gload4(src + (size_t)tb * sstride); };
 
-    float4 nxt[SX_MU], outq[SX_MU], outh[SX_MU], nhr[SX_MU];
-    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - stage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
+    float4 nxt[MU], outq[MU], outh[MU], nhr[MU];
+    if (CHAIN && wprog) sx_wait_prog(wprog, min(MU - stage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
 #pragma unroll
-    for (int u = 0; u < SX_MU; ++u) {
+    for (int u = 0; u < MU; ++u) {
         const int tb = u - stage;
         nxt[u] = (valid && tb >= 0 && tb < nb) ? fetch(tb) : zero4;
         nhr[u] = (TAN && valid && cell >= 0 && tb >= 0 && tb < nb) ? sx_gload4(hr4 + (size_t)(tb + hs) * A.npad + cell) : zero4;
         outq[u] = zero4; outh[u] = zero4;
     }
     const int nsuper = nb + dmax;
-    const int nmacro = (nsuper + SX_MU - 1) / SX_MU;
+    const int nmacro = (nsuper + MU - 1) / MU;
     for (int mw = 0; mw <= nmacro; ++mw) {
-        float4 cur[SX_MU], chr[SX_MU];
+        float4 cur[MU], chr[MU];
 #pragma unroll
-        for (int u = 0; u < SX_MU; ++u) { cur[u] = nxt[u]; sx_pin(cur[u]); if (TAN) { chr[u] = nhr[u]; sx_pin(chr[u]); } }
+        for (int u = 0; u < MU; ++u) { cur[u] = nxt[u]; sx_pin(cur[u]); if (TAN) { chr[u] = nhr[u]; sx_pin(chr[u]); } }
         // chained: the stores of the previous macro-step (four super-steps old) have completed past this point
         if (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // results of the previous macro-step leave now
         if (mw > 0 && cell >= 0 && !SX_ABL_NOST) {
 #pragma unroll
-            for (int u = 0; u < SX_MU; ++u) {
-                const int tb = SX_MU * (mw - 1) + u - stage;
+            for (int u = 0; u < MU; ++u) {
+                const int tb = MU * (mw - 1) + u - stage;
                 if (tb >= 0 && tb < nb) {
                     if (xout >= 0) x4[(size_t)tb * A.nx + xout] = outq[u];
                     if (TAPE) sx_gstore4s(hr4 + (size_t)(tb + hs) * A.npad + cell, outh[u]);
@@ -771,16 +786,16 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
         }
         if (mw == nmacro) break;
         // inputs of the next macro-step are requested now
-        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - stage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
+        if (CHAIN && wprog) sx_wait_prog(wprog, min(MU * (mw + 2) - stage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
 #pragma unroll
-        for (int u = 0; u < SX_MU; ++u) {
-            const int tb = SX_MU * (mw + 1) + u - stage;
+        for (int u = 0; u < MU; ++u) {
+            const int tb = MU * (mw + 1) + u - stage;
             nxt[u] = (valid && tb >= 0 && tb < nb && !SX_ABL_NOLD) ? fetch(tb) : zero4;
             if (TAN) nhr[u] = (valid && cell >= 0 && tb >= 0 && tb < nb) ? sx_gload4(hr4 + (size_t)(tb + hs) * A.npad + cell) : zero4;
         }
 #pragma unroll
-        for (int u = 0; u < SX_MU; ++u) {
-            const int w = SX_MU * mw + u;
+        for (int u = 0; u < MU; ++u) {
+            const int w = MU * mw + u;
             const int tb = w - stage;
             const bool act = valid && tb >= 0 && tb < nb;
             float4* pub = sx_lds + (size_t)(w & 1) * M;
@@ -876,8 +891,8 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
             else for (int sl = 0; sl < nsubw; ++sl) { sub_pass(sl); if (sl + 1 < nsubw) sx_lds_wave_fence(); }
             sx_lds_barrier();
             // every wave has passed this macro-step's vmcnt(0): what the roots (stage dmax) stored one macro-step
-            // ago -- blocks below SX_MU (mw-1) - dmax -- has reached L2 and can be released
-            if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0 && g != A.mute_group) sx_publish(A.prog + g, done); }
+            // ago -- blocks below MU (mw-1) - dmax -- has reached L2 and can be released
+            if (CHAIN && u == 0 && j == 0 && mw % PK == 0) { const int done = min(MU * (mw - 1) - dmax, nb); if (done > 0 && g != A.mute_group) sx_publish(A.prog + g, done); }
         }
     }
     if (valid && cell >= 0) { if (TAN) A.hlr_b[cell] = hlr; else A.hlr[cell] = hlr; }
@@ -891,7 +906,8 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
 
 // gated != 0: the launch spans several pipeline sub-chunks whose external inputs arrive while it runs (see "gate" above)
 template <bool TAPE, bool CHAIN, int TMODE = 0>
-__global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_fwd(SxDeviceArrays A, int g0, int gend, int t0, int T, int gated) {
+__global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_F) void sx_k_route_fwd(SxDeviceArrays A, int g0, int gend, int t0, int T, int gated) {
+    if (SX_R_PRIO) __builtin_amdgcn_s_setprio(SX_R_PRIO);
     if (!CHAIN) { sx_route_fwd_group<TAPE, false, TMODE>(A, g0 + (int)blockIdx.x, g0, gend, t0, T, false); return; }
     for (;;) {
         const int ticket = sx_next_ticket(A);
@@ -909,6 +925,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, CHAIN ? SX_RLB_F : 1) void sx_k_route_
 template <bool CHAIN>
 __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, const int g, const int g0, const int gend, const int t0, const int T,
                                                    const bool gated) {
+    constexpr int MU = SX_MU_A, PK = SX_PK * 4 / MU;
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
     const int j = threadIdx.x, M = blockDim.x;
@@ -978,10 +995,10 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
     // gated launch: a root whose receiver lives on another rank reads an adjoint series that arrives sub-chunk by sub-chunk
     if (CHAIN && gated && root_in && !wprog) wprog = SX_PROG_GATE(A);
     auto fetch_in = [&](int tb) -> float4 { return sx_gload4(x4 + (size_t)tb * A.nx + xout); };
-    float4 nhr[SX_MU], nin[SX_MU], nsd[SX_MU], outq[SX_MU];
-    if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU - rstage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
+    float4 nhr[MU], nin[MU], nsd[MU], outq[MU];
+    if (CHAIN && wprog) sx_wait_prog(wprog, min(MU - rstage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
 #pragma unroll
-    for (int u = 0; u < SX_MU; ++u) {
+    for (int u = 0; u < MU; ++u) {
         const int tbr = u - rstage;
         const int tb = nb - 1 - tbr;
         const bool ok = valid && tbr >= 0 && tbr < nb;
@@ -991,19 +1008,19 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
         outq[u] = zero4;
     }
     const int nsuper = nb + dmax;
-    const int nmacro = (nsuper + SX_MU - 1) / SX_MU;
+    const int nmacro = (nsuper + MU - 1) / MU;
     for (int mw = 0; mw <= nmacro; ++mw) {
-        float4 chr[SX_MU], cin[SX_MU], csd[SX_MU];
+        float4 chr[MU], cin[MU], csd[MU];
 #pragma unroll
-        for (int u = 0; u < SX_MU; ++u) {
+        for (int u = 0; u < MU; ++u) {
             chr[u] = nhr[u]; cin[u] = nin[u]; csd[u] = nsd[u];
             sx_pin(chr[u]); sx_pin(cin[u]); sx_pin(csd[u]);
         }
         if (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (mw > 0 && valid) {
 #pragma unroll
-            for (int u = 0; u < SX_MU; ++u) {
-                const int tbr = SX_MU * (mw - 1) + u - rstage;
+            for (int u = 0; u < MU; ++u) {
+                const int tbr = MU * (mw - 1) + u - rstage;
                 if (tbr >= 0 && tbr < nb) {
                     const int tb = nb - 1 - tbr;
                     // one store instruction for both kinds of slot; the inlets' destination is an exchange row: never nontemporal
@@ -1012,10 +1029,10 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
             }
         }
         if (mw == nmacro) break;
-        if (CHAIN && wprog) sx_wait_prog(wprog, min(SX_MU * (mw + 2) - rstage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
+        if (CHAIN && wprog) sx_wait_prog(wprog, min(MU * (mw + 2) - rstage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
 #pragma unroll
-        for (int u = 0; u < SX_MU; ++u) {
-            const int tbr = SX_MU * (mw + 1) + u - rstage;
+        for (int u = 0; u < MU; ++u) {
+            const int tbr = MU * (mw + 1) + u - rstage;
             const int tb = nb - 1 - tbr;
             const bool ok = valid && tbr >= 0 && tbr < nb;
             nhr[u] = (ok && cell >= 0) ? (SX_ABL_A_NOHR ? zero4 : sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell)) : zero4;
@@ -1023,8 +1040,8 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
             nsd[u] = ok ? load_seed(tb) : zero4;
         }
 #pragma unroll
-        for (int u = 0; u < SX_MU; ++u) {
-            const int w = SX_MU * mw + u;
+        for (int u = 0; u < MU; ++u) {
+            const int w = MU * mw + u;
             const int tbr = w - rstage;
             const bool act = valid && tbr >= 0 && tbr < nb;
             float4* pub = sx_lds + (size_t)(w & 1) * M;
@@ -1077,8 +1094,8 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
             if (nsubw == 1) sub_pass(0);
             else for (int sl = nsubw - 1; sl >= 0; --sl) { sub_pass(sl); if (sl > 0) sx_lds_wave_fence(); }     // the reverse of the forward order: a component's top first
             sx_lds_barrier();
-            // inlet slots sit at reverse stage <= dmax: reverse blocks below SX_MU (mw-1) - dmax are complete
-            if (CHAIN && u == 0 && j == 0 && mw % SX_PK == 0) { const int done = min(SX_MU * (mw - 1) - dmax, nb); if (done > 0 && g != A.mute_group) sx_publish(A.prog + g, done); }
+            // inlet slots sit at reverse stage <= dmax: reverse blocks below MU (mw-1) - dmax are complete
+            if (CHAIN && u == 0 && j == 0 && mw % PK == 0) { const int done = min(MU * (mw - 1) - dmax, nb); if (done > 0 && g != A.mute_group) sx_publish(A.prog + g, done); }
         }
     }
     if (valid && cell >= 0) { A.hlr_b[cell] = hr_b; A.lr_b[cell] = lr_b; }
@@ -1092,6 +1109,7 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
 
 template <bool CHAIN>
 __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDeviceArrays A, int g0, int gend, int t0, int T, int gated) {
+    if (SX_R_PRIO) __builtin_amdgcn_s_setprio(SX_R_PRIO);
     if (!CHAIN) { sx_route_adj_group<false>(A, g0 + (int)blockIdx.x, g0, gend, t0, T, false); return; }
     // chained rounds run roots-of-the-basin first: tickets walk the groups downwards
     for (;;) {

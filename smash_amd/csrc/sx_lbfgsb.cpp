@@ -197,6 +197,7 @@ struct smashx_lbfgsb {
     LineSearch ls;
     int restarts = 0;
     std::string msg;
+    const char* pending = nullptr;              // convergence verdict reached with the last accepted step, delivered after its NEW_X
 
     int col() const { return (int)order.size(); }
     const double* Scol(int k) const { return S[order[k]].get(); }
@@ -601,6 +602,9 @@ int smashx_lbfgsb_step(smashx_lbfgsb* o, double* x, double f, const double* g, i
         return 0;
     }
     if (*task == SMASHX_LBFGSB_NEW_X) {                    // the caller accepted the iterate: next iteration from it
+        // lbfgsb.f hands every accepted iterate to its caller as NEW_X first and tests for convergence on re-entry (mainlb, label 777):
+        // the caller sees the last iterate like every other (its per-iteration print, its own stopping tests, the iteration count)
+        if (o->pending) { o->msg = o->pending; o->pending = nullptr; *task = SMASHX_LBFGSB_CONVERGED; return 0; }
         if (!begin_iteration(o->g0.data())) { *task = SMASHX_LBFGSB_ABNORMAL; return 0; }
         o->state = 2;
         *task = SMASHX_LBFGSB_FG;
@@ -634,9 +638,10 @@ int smashx_lbfgsb_step(smashx_lbfgsb* o, double* x, double f, const double* g, i
     o->sbgnrm = o->proj_grad_norm(x, g);
     o->update(g);
     std::copy(x, x + n, o->x0.begin()); std::copy(g, g + n, o->g0.begin()); o->f0 = f;
-    if (o->sbgnrm <= o->pgtol) { o->msg = "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL"; *task = SMASHX_LBFGSB_CONVERGED; return 0; }
+    o->pending = nullptr;
     const double ddum = std::max({std::fabs(fold), std::fabs(f), 1.0});
-    if (fold - f <= EPS * o->factr * ddum) { o->msg = "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH"; *task = SMASHX_LBFGSB_CONVERGED; return 0; }
+    if (o->sbgnrm <= o->pgtol) o->pending = "CONVERGENCE: NORM_OF_PROJECTED_GRADIENT_<=_PGTOL";
+    else if (fold - f <= EPS * o->factr * ddum) o->pending = "CONVERGENCE: REL_REDUCTION_OF_F_<=_FACTR*EPSMCH";
     o->state = 3;                                          // waits for the caller's NEW_X acknowledgement
     *task = SMASHX_LBFGSB_NEW_X;
     return 0;

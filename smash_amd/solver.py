@@ -200,6 +200,13 @@ class Solver:
         _lib.check(_lib.lib().smashx_plan_chunking(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def hbm(self):
+        """{free_at_plan, total, held} in bytes (smashx_plan_hbm): free HBM when the storage-chunk length was chosen, the device's
+        total, what the plan holds now."""
+        v = (C.c_double * 3)()
+        _lib.check(_lib.lib().smashx_plan_hbm(self._h, v))
+        return {"free_at_plan": v[0], "total": v[1], "held": v[2]}
+
     def set_domain_outputs(self, qsim_domain=None, net_prcp_domain=None, sparse=False):
         """Host arrays the following forward sweeps fill (OutputDT%qsim_domain / net_prcp_domain or sparse_ forms)."""
         for a in (qsim_domain, net_prcp_domain):

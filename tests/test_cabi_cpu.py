@@ -123,6 +123,29 @@ def test_native_lbfgsb_converges_like_the_reference_code(n, m):
         assert abs(va - vb) <= 1e-6 * max(1.0, abs(va)) and np.max(np.abs(xa - xb)) <= 1e-3
 
 
+def test_native_lbfgsb_hands_over_the_last_iterate_before_it_reports_convergence():
+    """lbfgsb.f returns NEW_X for every accepted iterate and tests for convergence on re-entry (mainlb, label 777); the library's
+    optimiser does the same: the callback sees the final iterate, the iteration count and the trajectory length equal those of
+    scipy's build of the reference code on a run to convergence (they were one short)."""
+    from smash_amd.optimize import _lbfgsb_native, _lbfgsb_scipy
+
+    def fg(u):                                            # bounded Rosenbrock, n = 2 and n = 10
+        x = 0.8 * u
+        f = float(np.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1 - x[:-1]) ** 2))
+        g = np.zeros_like(x)
+        g[:-1] = -400.0 * x[:-1] * (x[1:] - x[:-1] ** 2) - 2 * (1 - x[:-1])
+        g[1:] += 200.0 * (x[1:] - x[:-1] ** 2)
+        return f, 0.8 * g
+    for n in (2, 10):
+        ta, tb = [], []
+        xa, va, ia = _lbfgsb_scipy(fg, np.full(n, 0.3), 5, 1e7, 1e-8, 5000, 8000, lambda xk: ta.append(np.copy(xk)))
+        xb, vb, ib = _lbfgsb_native(fg, np.full(n, 0.3), 5, 1e7, 1e-8, 5000, 8000, lambda xk: tb.append(np.copy(xk)))
+        assert ia["task"].startswith("CONVERGENCE") and ib["task"].startswith("CONVERGENCE")
+        assert ia["nit"] == ib["nit"] == len(ta) == len(tb), (ia["nit"], ib["nit"], len(ta), len(tb))
+        assert np.array_equal(tb[-1], xb)                 # the callback saw the final iterate
+        assert np.max(np.abs(ta[-1] - tb[-1])) <= 1e-6
+
+
 def test_native_lbfgsb_argument_and_limit_behaviour():
     """Error behaviour of the C entry points and the driver's own stop tests (iteration and evaluation limits, callback per iterate)."""
     import ctypes as C

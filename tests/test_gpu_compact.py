@@ -156,3 +156,31 @@ def test_partial_gap_day_across_blocks_is_refused():
             codes.append(e.code)
             break
     assert codes[:5] == [0, 0, 0, 0, 0] and codes[-1] == _lib.E_UNSUPPORTED and len(codes) == 6, codes
+
+
+def test_fp32_device_blocks_in_any_order_and_refreshed():
+    """fp32 rows (no compact layout): device blocks may arrive in any order -- [k, nt) before [0, k) -- and a block of an already
+    complete forcing may be refreshed; neither forgets the coverage (include/smashx.h, smashx_set_forcing_device_block)."""
+    import torch
+    import smash_amd
+    from smash_amd.solver import Solver
+    from test_gpu_parity import _run_adjoint, _types
+    g = gu.load("gr_b_16x16x96_nse_gaps")
+    ref = _run_adjoint(g, chunk_steps=0)
+    setup, mesh, inp, par, sta, out = _types(g)
+    sol = Solver(setup, mesh)
+    rows, cols = sol.cell_order()
+
+    def send(t0, t1):
+        bp = torch.from_numpy(np.ascontiguousarray(g.prcp[rows, cols, t0:t1].T)).cuda()
+        be = torch.from_numpy(np.ascontiguousarray(g.pet[rows, cols, t0:t1].T)).cuda()
+        torch.cuda.synchronize()
+        sol.set_forcing_device_block(t0, t1, bp.data_ptr(), be.data_ptr())
+    send(40, g.nt)
+    send(0, 40)                                      # the block that starts at step 0 comes last
+    send(0, 24)                                      # ... and its head is refreshed once more
+    assert not sol.forcing_info()["layout"].startswith("compact")
+    inp._smashx_solver = sol
+    pb, sb = par.copy(), sta.copy()
+    smash_amd.forward_b(setup, mesh, inp, par, pb, par.copy(), par.copy(), sta, sb, sta.copy(), sta.copy(), out, out.copy(), np.float32(0), np.float32(1))
+    _same(ref, (par, sta, out, pb, sb), g)

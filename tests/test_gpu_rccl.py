@@ -73,3 +73,49 @@ def test_bench_self_launch_two_ranks():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["config"]["grid"] == [64, 128]
     assert "ncclSend" in line["config"]["parallelism"] and line["value"] > 0
+
+
+_TEARDOWN = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, sys.argv[1])
+import torch
+torch.zeros(1, device="cuda:0")
+import golden_util as gu
+import smash_amd
+from smash_amd.solver import Comm, Solver
+from test_gpu_parity import _run_adjoint, _types
+g = gu.load("gr_b_16x16x96_nse_gaps")
+ref = _run_adjoint(g)[2].qsim.copy()
+empty = np.zeros(0, np.int32)
+
+def plan():
+    setup, mesh, inp, par, sta, out = _types(g)
+    sol = Solver(setup, mesh, chunk_steps=32, device=0)
+    sol.set_forcing(g.prcp, g.pet); sol.set_qobs(g.qobs); sol.set_options(setup.optimize)
+    def run():
+        sol.upload(par, sta); sol.sweep(True, 1.0); sol.download(True, par, sta, out, par.copy(), sta.copy())
+        return out.qsim.copy()
+    return sol, run
+
+c1, c2 = Comm(Comm.unique_id(), 0, 1, 0), Comm(Comm.unique_id(), 0, 1, 0)
+# unset, destroy the plan, then the communicator (the communicator used to keep the freed plan in its list)
+sol, run = plan()
+sol.set_exchange(c1, empty, empty); sol.set_exchange(None, empty, empty); sol.close(); c1.close()
+# switch communicators: the first one must forget the plan, the plan must keep the second
+c1 = Comm(Comm.unique_id(), 0, 1, 0)
+sol, run = plan()
+sol.set_exchange(c1, empty, empty); sol.set_exchange(c2, empty, empty); c1.close()
+assert np.array_equal(run(), ref)               # sweeps (their stall agreement runs on c2) still work
+sol.close(); c2.close()
+print("TEARDOWN-OK")
+"""
+
+
+def test_communicator_teardown_orders():
+    """smashx_set_exchange(plan, NULL) and a switch to another communicator take the plan off the previous communicator's list:
+    set, unset, destroy plan, destroy communicator -- and set c1, set c2, destroy c1, sweep, destroy -- with one-rank communicators."""
+    r = subprocess.run([sys.executable, "-c", _TEARDOWN, os.path.dirname(HERE)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    sys.stderr.write(r.stderr[-3000:])
+    assert r.returncode == 0 and "TEARDOWN-OK" in r.stdout, r.stderr[-2000:]

@@ -139,15 +139,15 @@ def test_cance_fixture_is_pinned_by_the_values_the_reference_publishes():
 
 
 def test_default_build_bars_are_capped_and_the_unasserted_outputs_are_pinned():
-    """No default-build assertion has a bar above 1e-4 (golden_util.CAP).  The outputs whose reference self-noise puts the bar
-    beyond that are asserted in the exact-libm build only (bit-identity, tests/test_gpu_exact.py); the list is pinned here so that
-    it cannot grow silently."""
+    """No default-build PARITY bar is above 1e-4 (golden_util.CAP).  The outputs whose reference self-noise puts 3 x noise beyond that
+    keep that finite bar as a sanity check (a gross regression of the default build must not pass) and have their parity asserted in the
+    exact-libm build only (bit-identity, tests/test_gpu_exact.py); the list is pinned here so that it cannot grow silently."""
     un = {}
     for name in gu.names():
         g = gu.load(name)
         for v in list(g.noise["qsim"]) + [g.noise["cost"]] + [x for grp in ("fstates", "parameters_b", "states_b") for x in g.noise[grp].values()]:
             b = gu.tol(v)
-            assert b == gu.UNASSERTED or 1e-6 <= b <= gu.CAP
+            assert np.isfinite(b) and b >= 1e-6 and (b <= gu.CAP or gu.sanity_only(v))
         u = gu.unasserted_outputs(g)
         if u:
             un[name] = u
