@@ -81,6 +81,10 @@ def parse(argv=None):
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "torch"],
                     help="boundary series: rccl = grouped ncclSend/ncclRecv posted by libsmashx on its routing stream (default); "
                          "torch = host callback + torch.distributed point-to-point (always used with --backend gloo)")
+    ap.add_argument("--mesh", default="synth", help="catchment: synth = the E/SE/S field of SURVEY 8d on --grid / the default grid (default); d8 = the "
+                    "synthetic all-eight-code relief (synth.make_mesh_d8) on the same grid; france:all / france:K = the reference's 1-km D8 raster "
+                    "of France, whole or its K largest basins (data fixture tests/golden/mesh/france_d8.npz; N > 1: --partition sub or trunk)")
+    ap.add_argument("--no-real-d8", action="store_true", help="N = 1: skip the real river network (france:all) attached to the line")
     ap.add_argument("--nt", type=int, default=8760)
     ap.add_argument("--structure", default="gr-b")
     ap.add_argument("--chunk", type=int, default=0, help="time-chunk length (0 = from HBM size)")
@@ -105,7 +109,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-solo-nt", type=int, default=160)
     a = ap.parse_args(argv)
     if a.profile:
-        a.no_secondary = a.no_tile_solo = a.no_exact = a.no_cpu_baseline = a.no_inclusive = a.no_forward_only = True
+        a.no_secondary = a.no_tile_solo = a.no_exact = a.no_cpu_baseline = a.no_inclusive = a.no_forward_only = a.no_real_d8 = True
         if a.gpus != 1:
             ap.error("--profile is a single-process run")
     return a
@@ -234,7 +238,19 @@ class Case:
         nrow, ncol = pr * trows, pc * tcols            # the whole catchment; every rank owns 1/parts of it
         self.pr, self.pc, self.nrow, self.ncol, self.parts, self.me = pr, pc, nrow, ncol, parts, me
         t_setup = time.perf_counter()
-        m = synth.make_mesh(nrow, ncol, ng=a.ng)
+        mesh_kind = getattr(a, "mesh", "synth")
+        if mesh_kind.startswith("france"):
+            w = mesh_kind.split(":", 1)[1] if ":" in mesh_kind else "all"
+            m = synth.make_mesh_france(w if w == "all" else int(w), ng=a.ng)
+            if parts > 1 and a.partition == "rect":
+                raise SystemExit("bench.py: a real D8 network cannot be cut into rectangles (cyclic rank graph): --partition sub or trunk")
+            nrow, ncol = m.nrow, m.ncol
+            self.nrow, self.ncol = nrow, ncol
+        elif mesh_kind == "d8":
+            m = synth.make_mesh_d8(nrow, ncol, ng=a.ng)
+        else:
+            m = synth.make_mesh(nrow, ncol, ng=a.ng)
+        self.mesh_kind = mesh_kind
         rect, owner, mine = None, None, None
         if parts > 1 and a.partition == "rect":
             rect = tiles.tile_rect(me, nrow, ncol, pr, pc)
@@ -408,7 +424,11 @@ def attached_case(a, torch, dev, local, barrier, adjoint, grid_rc, parts, me, so
         o = {"workload": what, "value": float(c.sol.ncells) * a.nt * steps / secs, "unit": "cell-timesteps/s", "steps": steps, "warmup": warmup,
              "ms_per_step": secs * 1e3 / steps, "grid": [c.nrow, c.ncol], "tile": list(grid_rc), "active_cells": int(c.sol.ncells),
              "n_chunks": int(tm["n_chunks"]), "chunk_steps": int(tm["chunk_steps"]), "pipe_steps": int(tm["pipe_steps"]),
-             "routing_rounds": int(tm["n_rounds"]), "hbm_plan_gb": tm["device_bytes"] / 1e9,
+             "routing_rounds": int(tm["n_rounds"]), "routing_groups": int(tm["n_groups"]), "deepest_group_stages": int(tm["max_stage"]),
+             "chained_groups": int(tm["n_chained_groups"]),
+             "chained_launch_ms_per_step": {"forward": round(tm["route_fwd_chained_ms"], 3), "reverse": round(tm["route_adj_chained_ms"], 3),
+                                            "launches": int(tm["route_fwd_chained_launches"] + tm["route_adj_chained_launches"])},
+             "hbm_plan_gb": tm["device_bytes"] / 1e9,
              "hbm_free_at_plan_gb": c.hbm["free_at_plan"] / 1e9, "forcing": c.forcing,
              "kernel_ms_per_step": {"sx_k_" + k: round(tm[k + "_ms"], 3) for k in KERNELS},
              "kernel_launches_per_step": {"sx_k_" + k: int(tm[k + "_launches"]) for k in KERNELS},
@@ -538,7 +558,8 @@ def main():
                                       "(the per-GPU tile of BASELINE.json configs[4], fewer tiles)"),
                        "grid": [nrow, ncol], "tile": [trows, tcols], "nt": nt, "structure": a.structure, "active_cells": int(cellsteps / nt),
                        "chunk_steps": int(tm["chunk_steps"]), "n_chunks": int(tm["n_chunks"]), "pipe_steps": int(tm["pipe_steps"]),
-                       "routing_rounds": int(tm["n_rounds"]), "routing_groups": int(tm["n_groups"]),
+                       "routing_rounds": int(tm["n_rounds"]), "routing_groups": int(tm["n_groups"]), "deepest_group_stages": int(tm["max_stage"]),
+                       "chained_groups": int(tm["n_chained_groups"]), "mesh": a.mesh,
                        "forcing": case.forcing,
                        "parallelism": (f"rank {me} of {parts} alone ({a.partition}), no-op exchange" if solo else
                                        ((f"tiles {pr}x{pc}" if a.partition == "rect" else f"{parts} {a.partition} parts of the river tree") +
@@ -548,6 +569,8 @@ def main():
             "kernel_ms_per_step": {"sx_k_" + k: round(tm[k + "_ms"], 3) for k in KERNELS},
             "kernel_launches_per_step": {"sx_k_" + k: int(tm[k + "_launches"]) for k in KERNELS},
             "kernel_cellsteps_per_step": {"sx_k_" + k: tm[k + "_cellsteps"] for k in KERNELS},
+            "chained_launch_ms_per_step": {"forward": round(tm["route_fwd_chained_ms"], 3), "reverse": round(tm["route_adj_chained_ms"], 3),
+                                           "launches": int(tm["route_fwd_chained_launches"] + tm["route_adj_chained_launches"])},
             "device_sweep_ms": tm["sweep_ms"], "cost": cost, "setup_s": case.setup_s,
             "hbm_plan_gb": tm["device_bytes"] / 1e9,
             # free HBM when the plan chose its storage-chunk length (the forcing was resident by then): the chunk count -- and with it the
@@ -572,8 +595,9 @@ def main():
         if cpu is not None:
             line["cpu_baseline"] = cpu
     # N = 1, default workload: two more cases measured on the same GPU and attached to the line
-    default_case = world == 1 and not solo and not a.raw_forcing and (trows, tcols) == (2048, 2048) and nt == 8760 and line is not None
-    if default_case and not (a.no_secondary and a.no_tile_solo and a.no_forward_only):
+    default_case = (world == 1 and not solo and not a.raw_forcing and (trows, tcols) == (2048, 2048) and nt == 8760 and line is not None
+                    and a.mesh == "synth")
+    if default_case and not (a.no_secondary and a.no_tile_solo and a.no_forward_only and a.no_real_d8):
         case.close()
         del case, sol
         if not a.no_secondary and a.secondary_grid > 0:
@@ -590,6 +614,21 @@ def main():
                 "`--gpus N` line, so value(N) / (N x this value) is the price of the decomposition's pipeline and exchange")
             o["per_gpu_value"] = o.get("value")
             line["tile_solo"] = o
+        if not a.no_real_d8 and adjoint:
+            # a REAL river network (all eight D8 codes) beside the E/SE/S field: the reference's 1-km raster of France, every cell with a
+            # direction active (957 k cells, a forest of basins), and the synthetic all-eight-code relief on 1024^2
+            ra = argparse.Namespace(**vars(a))
+            ra.mesh = "france:all"
+            o = attached_case(
+                ra, torch, dev, local, barrier, adjoint, (1125, 1200), 1, 0, False, min(a.steps, 5), 1,
+                f"the reference's 1-km D8 flow-direction raster of France (smash/dataset/France_flwdir.tif as data fixture tests/golden/mesh/france_d8.npz; all "
+                f"eight codes, every cell with a direction active, closed loops masked), hourly x {nt} steps, {a.structure}, one forward+adjoint sweep; "
+                "store-all adjoint")
+            ra.mesh = "d8"
+            o["synthetic_d8_1024"] = attached_case(
+                ra, torch, dev, local, barrier, adjoint, (1024, 1024), 1, 0, False, min(a.steps, 3), 1,
+                "synthetic all-eight-code relief (synth.make_mesh_d8: one basin, interior outlet) on 1024x1024 cells, same forcing and parameters")
+            line["real_d8"] = o
         if not a.no_forward_only and adjoint:
             g = a.secondary_grid or 1024
             o = attached_case(
@@ -628,6 +667,21 @@ def main():
                 line["exact_libm"]["slowdown_vs_default"] = e["ms_per_step"] / line["secondary"]["ms_per_step"]
         except Exception as ex:  # pragma: no cover
             line.setdefault("exact_libm", {"value": None})["error"] = str(ex)
+    if world > 1 and rank == 0 and line is not None:
+        if case.comm is not None:
+            # what the communicator itself says: ranks it spans (ncclCommCount) and RCCL's version code (ncclGetVersion)
+            line["rccl"] = case.comm.info()
+        if not a.no_tile_solo and a.partition == "rect":
+            # rank 0's own tile once more, ALONE (no-op exchange, zero inflow), after the timed region: the like-for-like base of this
+            # line measured on this very GPU, so the run reports its own efficiency; the other ranks wait at the final barrier
+            case.sol.close()
+            torch.cuda.empty_cache()
+            o = attached_case(a, torch, dev, local, torch.cuda.synchronize, adjoint, (trows, tcols), world, 0, True, min(a.steps, 5), 1,
+                              f"rank 0's {trows}x{tcols} tile of this decomposition alone on its GPU (no-op exchange, zero inflow, same chunking and "
+                              "sub-chunks), measured after the timed region")
+            line["tile_solo"] = o
+            if o.get("value"):
+                line["efficiency_vs_solo_tile"] = line["value"] / (world * o["value"])
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

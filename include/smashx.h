@@ -113,6 +113,10 @@ typedef struct {
     double device_bytes;     /* HBM held by the plan */
     double cellsteps[4];     /* cell-steps the launches of the last sweep processed: vert_fwd, route_fwd, route_adj, vert_adj
                                 (a checkpointed adjoint runs the forward kernels over most of the period twice) */
+    float route_fwd_chained_ms, route_adj_chained_ms;   /* the part of route_fwd_ms / route_adj_ms spent in the chained launches (rounds >= 1) */
+    int   route_fwd_chained_launches, route_adj_chained_launches;
+    int   max_stage;         /* stages of the deepest routing group (the fill of a routing launch, in super-steps) */
+    int   n_chained_groups;  /* groups of the chained rounds */
 } smashx_timing;
 
 typedef struct smashx_plan smashx_plan;
@@ -122,7 +126,7 @@ int smashx_device_count(void);
 /* ABI guard for bindings that mirror the structs by hand (the Fortran shim, ctypes): sizes in bytes of
  * {smashx_config, smashx_mesh, smashx_options, smashx_parameters, smashx_states, smashx_costs, smashx_timing};
  * returns SMASHX_ABI_VERSION. */
-#define SMASHX_ABI_VERSION 6
+#define SMASHX_ABI_VERSION 7
 int smashx_abi_sizes(int sizes[7]);
 
 /* builds the routing schedule from the mesh and allocates device storage */
@@ -244,7 +248,11 @@ int smashx_tangent_terms(const smashx_plan* plan, float* jobs_d, float* jreg_d);
  *   phase 1  FWD_SEND  out_buf is ready (series of the out edges)                 after  routing forward
  *   phase 2  ADJ_RECV  fill out_buf (adjoint contributions for the out edges)     before routing adjoint
  *   phase 3  ADJ_SEND  in_buf is ready (adjoint series of the in edges)           after  routing adjoint
- * Layout of a buffer: [edge][ceil(nsteps/4)] float4 (4 consecutive steps each).  */
+ * Layout of a buffer: [edge][ceil(nsteps/4)] float4 (4 consecutive steps each).
+ * A checkpointed adjoint sweep (several storage chunks) runs the forward of every chunk but the last twice; the second run -- the
+ * recomputation inside the reverse sweep -- moves NOTHING between ranks (round 4): every plan keeps the series it received for the
+ * chunk in the first pass (n_in x chunk_steps floats per chunk) and sends none.  Phases 0 and 1 are therefore called once per
+ * sub-chunk and sweep, phases 2 and 3 once; the same holds for the native exchange below. */
 typedef int (*smashx_halo_fn)(void* user, int phase, int t0, int nsteps);
 /* host-only (no GPU needed): builds the routing schedule of one tile and reports
  * info = {cells, rounds, groups, slots, exchange series, deepest stage, n_out, n_in}; edge arrays may be NULL or
@@ -295,6 +303,8 @@ int smashx_comm_unique_id(unsigned char id[SMASHX_COMM_ID_BYTES]);
 int smashx_comm_create(const unsigned char id[SMASHX_COMM_ID_BYTES], int rank, int nranks, int device, void** comm);
 int smashx_comm_destroy(void* comm);
 int smashx_comm_allreduce_sum(void* comm, double* values, int n);
+/* diagnostics: the ranks the communicator spans (ncclCommCount) and RCCL's version code (ncclGetVersion); either pointer may be NULL */
+int smashx_comm_info(void* comm, int* nranks, int* version);
 int smashx_set_exchange(smashx_plan* plan, void* comm, const int* out_peer, const int* in_peer);
 
 /* ---- diagnostics ---------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ SYMBOLS = [
     "smashx_comm_unique_id", "smashx_comm_create", "smashx_comm_destroy", "smashx_comm_allreduce_sum", "smashx_set_exchange",
     "smashx_set_median_slots", "smashx_selftest_paths",
     "smashx_lbfgsb_create", "smashx_lbfgsb_step", "smashx_lbfgsb_destroy", "smashx_lbfgsb_iterations", "smashx_lbfgsb_message",
-    "smashx_lbfgsb_evaluations", "smashx_lbfgsb_projected_gradient", "smashx_plan_hbm",
+    "smashx_lbfgsb_evaluations", "smashx_lbfgsb_projected_gradient", "smashx_plan_hbm", "smashx_comm_info",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
@@ -72,7 +72,10 @@ class Timing(C.Structure):
                 ("route_adj_ms", C.c_float), ("vert_adj_ms", C.c_float), ("vert_fwd_launches", C.c_int),
                 ("route_fwd_launches", C.c_int), ("route_adj_launches", C.c_int), ("vert_adj_launches", C.c_int),
                 ("n_chunks", C.c_int), ("chunk_steps", C.c_int), ("pipe_steps", C.c_int), ("n_rounds", C.c_int), ("n_groups", C.c_int),
-                ("device_bytes", C.c_double), ("cellsteps", C.c_double * 4)]
+                ("device_bytes", C.c_double), ("cellsteps", C.c_double * 4),
+                ("route_fwd_chained_ms", C.c_float), ("route_adj_chained_ms", C.c_float),
+                ("route_fwd_chained_launches", C.c_int), ("route_adj_chained_launches", C.c_int), ("max_stage", C.c_int),
+                ("n_chained_groups", C.c_int)]
 
 
 class SmashxError(RuntimeError):
@@ -104,6 +107,14 @@ def lib():
         L.smashx_lbfgsb_step.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
         for s in ("smashx_lbfgsb_destroy", "smashx_lbfgsb_iterations", "smashx_lbfgsb_message", "smashx_lbfgsb_evaluations", "smashx_lbfgsb_projected_gradient"):
             getattr(L, s).argtypes = [C.c_void_p]
+        # the structs above mirror include/smashx.h by hand: refuse a library built from another layout (a stale .so would have
+        # smashx_get_timing write past the end of Timing)
+        sizes = (C.c_int * 7)()
+        L.smashx_abi_sizes(sizes)
+        mine = [C.sizeof(t) for t in (Config, Mesh, Options, Parameters, States, Costs, Timing)]
+        if list(sizes) != mine:
+            raise ImportError(f"{LIB_PATH} was built from another include/smashx.h (struct sizes {list(sizes)}, this module expects {mine}): "
+                              "rebuild it (__graft_entry__.build())")
         _lib = L
     return _lib
 

@@ -284,6 +284,8 @@ struct RcclApi {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;        // optional (diagnostics: smashx_comm_info)
+    decltype(&ncclGetVersion) GetVersion = nullptr;
     bool ok() const { return h != nullptr && err.empty(); }
 };
 RcclApi& rccl() {
@@ -302,6 +304,8 @@ RcclApi& rccl() {
     SX_SYM(GetUniqueId); SX_SYM(CommInitRank); SX_SYM(CommDestroy); SX_SYM(Send); SX_SYM(Recv); SX_SYM(AllReduce);
     SX_SYM(GroupStart); SX_SYM(GroupEnd); SX_SYM(GetErrorString);
 #undef SX_SYM
+    R.CommCount = (decltype(R.CommCount))dlsym(R.h, "ncclCommCount");
+    R.GetVersion = (decltype(R.GetVersion))dlsym(R.h, "ncclGetVersion");
     return R;
 }
 #define NCCLCHK(expr)                                                                                   \
@@ -337,11 +341,7 @@ struct smashx_plan {
     std::vector<float> wgauge;
     hipStream_t stream = nullptr;    // vertical kernels, uploads/downloads ("V stream")
     hipStream_t stream_r = nullptr;  // routing + cost kernels ("R stream"); overlaps the V stream chunk by chunk
-    hipStream_t stream_c = nullptr;  // the chained routing launch of a storage chunk cut into sub-chunks (persistent, gated: sx_kernels.h)
-    hipStream_t stream_x = nullptr;  // pack + send of a sub-chunk's boundary series beside that launch
-    int persist_wgs = 160;           // workgroups of such a launch (SMASHX_PERSIST_WGS): the other compute units stay free for round 0,
-                                     // the vertical kernels and the exchange kernels it waits for
-    int* d_out_prod = nullptr; int n_out_prod = 0;   // chained groups that publish a boundary series of this tile
+    hipStream_t stream_c = nullptr;  // the chained routing launches when they run beside the R stream (chain_stream)
     int Tp = 0;                      // pipeline sub-chunk length inside a storage chunk
     bool hi_tape = true;             // gr-b / gr-c: full tape of the interception level (false: sparse checkpoints, rebuilt in the reverse kernel)
     int Tpa = 0;                     // ... of the reverse sweep (routing adjoint of sub-chunk j-1 under the vertical adjoint of j)
@@ -355,6 +355,9 @@ struct smashx_plan {
     std::vector<double> round_ncells;  // cells per routing round
     bool chain_used = false;         // a chained launch ran in the current sweep: check the stall flag afterwards
     bool chain = true;               // all routing rounds in one launch (progress counters), see sx_kernels.h
+    bool plain_rows = false;         // the running sweep keeps every series in its plain rows (tangent sweeps)
+    bool chain_stage = true;         // staging rows for the chained groups (sx_kernels.h, sx_k_chain_gather); SMASHX_CHAIN_STAGE=0: plain rows (A/B)
+    int chain_rows_extra = 0;        // deepest chained group: rows of the staging array beyond the time blocks
     bool chain_stream = false;       // the chained launches of the pipeline sub-chunks on their own stream (stream_c): round 0 of sub-chunk j + 1 does not
                                      // queue behind the latency-bound chained rounds of sub-chunk j (single domain only)
     // tile boundary exchange
@@ -506,7 +509,8 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
             size_t fr = 0, tot = 0;
             HIPCHK(hipMemGetInfo(&fr, &tot));
             const double avail = (double)fr * 0.85 - 1.0e9;
-            auto fit = [&](double nt_) { return (long)(avail / (4.0 * ((double)p->npad * (2 + nt_) + (double)std::max(p->sch.nxslots, 1)))) / 16 * 16; };
+            // floats per time step: qt, hr_imd and the taped levels of every cell, the exchange series, the staging rows of the chained groups
+            auto fit = [&](double nt_) { return (long)(avail / (4.0 * ((double)p->npad * (2 + nt_) + (double)std::max(p->sch.nxslots, 1) + (double)p->A.ncs))) / 16 * 16; };
             long t = fit(ntape_full);
             if (has_hi && t < nt16) {
                 // Dropping the hi tape costs the reverse kernel ~14 % (levels rebuilt block by block: 78.5 against 69 ms per 9.2e9
@@ -547,6 +551,9 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
         int rc;
         if ((rc = p->dmalloc(&p->A.qtT, (size_t)p->npad * Tc))) return rc;
         if ((rc = p->dmalloc(&p->A.xT, (size_t)std::max(p->sch.nxslots, 1) * Tc))) return rc;
+        if (p->A.ncs > 0) {       // staging rows of the chained groups: [Tc / 4 + deepest chained group + 1][ncs] float4
+            if ((rc = p->dmalloc(&p->A.qsk, (size_t)p->A.ncs * 4 * ((size_t)Tc / 4 + p->chain_rows_extra + 1)))) return rc;
+        }
         HIPCHK(hipMemsetAsync(p->A.qtT, 0, (size_t)p->npad * Tc * 4, p->stream));
         HIPCHK(hipMemsetAsync(p->A.xT, 0, (size_t)std::max(p->sch.nxslots, 1) * Tc * 4, p->stream));
         p->chunk_ready = true;
@@ -586,6 +593,7 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
     return 0;
 }
 
+int chain_first(const smashx_plan* p);
 // view of the chunk buffers shifted to local step `off` (multiple of 4) of the current storage chunk
 SxDeviceArrays view_at(const smashx_plan* p, int off) {
     SxDeviceArrays B = p->A;
@@ -593,6 +601,8 @@ SxDeviceArrays view_at(const smashx_plan* p, int off) {
     const size_t q = (size_t)(off / 4);
     B.qtT = p->A.qtT + q * p->npad * 4;
     if (p->A.hrT) B.hrT = p->A.hrT + q * p->npad * 4;
+    // staging rows of the chained groups: only while chained launches run (the launch-per-round fallback and the tangent sweep use the plain rows)
+    B.qsk = (p->A.qsk && chain_first(p) < p->sch.nrounds && !p->dom_q_active && !p->plain_rows) ? p->A.qsk + q * (size_t)p->A.ncs * 4 : nullptr;
     if (p->A.qdT) B.qdT = p->A.qdT + q * p->npad * 4;
     B.xT = p->A.xT + q * p->A.nx * 4;
     if (p->A.qtdT) B.qtdT = p->A.qtdT + q * p->npad * 4;      // tangent sweep (smashx_forward_d)
@@ -670,10 +680,10 @@ int chain_first(const smashx_plan* p) {       // first chained round (nrounds: n
     const int nr = p->sch.nrounds;
     return (p->chain && nr - p->chain_from >= 2) ? p->chain_from : nr;
 }
-// counters of a chained launch: the groups' progress, the ticket counter and the gate (the stall flag lives for the whole sweep)
+// counters of a chained launch: the groups' progress and the ticket counter (the stall flag lives for the whole sweep)
 void reset_chain_counters(smashx_plan* p, hipStream_t st) {
     (void)hipMemsetAsync(p->A.prog, 0, (size_t)p->sch.ngroups * sizeof(int), st);
-    (void)hipMemsetAsync(p->A.prog + p->sch.ngroups + 1, 0, 2 * sizeof(int), st);
+    (void)hipMemsetAsync(p->A.prog + p->sch.ngroups + 1, 0, sizeof(int), st);
 }
 // the un-chained rounds [0, chain_first) of one forward pass over [t0, t0 + T): one launch per round on stream st
 void route_fwd_rounds(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st, hipEvent_t wait_rest = nullptr) {
@@ -685,14 +695,13 @@ void route_fwd_rounds(smashx_plan* p, int off, bool tape, int t0, int T, hipStre
         if (r == 1 && wait_rest) (void)hipStreamWaitEvent(st, wait_rest, 0);
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
         p->mark_begin(1, st, round_cells(p, r, r + 1) * T);
-        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T, 0);
-        else      hipLaunchKernelGGL((sx_k_route_fwd<false, false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T, 0);
+        if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T);
+        else      hipLaunchKernelGGL((sx_k_route_fwd<false, false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T);
         p->mark_end();
     }
 }
-// the chained rounds in ONE launch (tickets: sx_kernels.h).  gated: the launch spans several sub-chunks whose external inputs arrive
-// while it runs and is confined to persist_wgs workgroups; the caller has reset the counters on a stream this one waits for
-void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st, bool gated, hipEvent_t wait_rest = nullptr) {
+// the chained rounds in ONE launch (tickets: sx_kernels.h)
+void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st, hipEvent_t wait_rest = nullptr) {
     const int nr = p->sch.nrounds, cf = chain_first(p);
     if (cf >= nr) return;
     SxDeviceArrays B = view_at(p, off);
@@ -700,11 +709,11 @@ void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStr
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
     const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
     if (cf <= 1 && wait_rest) (void)hipStreamWaitEvent(st, wait_rest, 0);
-    if (!gated) reset_chain_counters(p, st);
-    const int grid = gated ? std::min(g1 - g0, p->persist_wgs) : g1 - g0;
-    p->mark_begin(1, st, round_cells(p, cf, nr) * T);
-    if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T, gated ? 1 : 0);
-    else      hipLaunchKernelGGL((sx_k_route_fwd<false, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T, gated ? 1 : 0);
+    reset_chain_counters(p, st);
+    const int grid = g1 - g0;
+    p->mark_begin(5, st, round_cells(p, cf, nr) * T);
+    if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
+    else      hipLaunchKernelGGL((sx_k_route_fwd<false, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
     p->mark_end();
     p->chain_used = true;
 }
@@ -714,18 +723,18 @@ void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStr
 // wait_rest: event the launches after round 0 have to wait for (the vertical kernel of the cells outside round 0)
 void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T, hipEvent_t wait_rest = nullptr) {
     route_fwd_rounds(p, off, tape, t0, T, p->stream_r, wait_rest);
-    route_fwd_chained(p, off, tape, t0, T, p->stream_r, false, wait_rest);
+    route_fwd_chained(p, off, tape, t0, T, p->stream_r, wait_rest);
 }
-void route_adj_chained(smashx_plan* p, int off, int t0, int T, hipStream_t st, bool gated) {
+void route_adj_chained(smashx_plan* p, int off, int t0, int T, hipStream_t st) {
     const int nr = p->sch.nrounds, cf = chain_first(p);
     if (cf >= nr) return;
     const SxDeviceArrays B = view_at(p, off);
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
     const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
-    if (!gated) reset_chain_counters(p, st);
-    const int grid = gated ? std::min(g1 - g0, p->persist_wgs) : g1 - g0;
-    p->mark_begin(2, st, round_cells(p, cf, nr) * T);
-    hipLaunchKernelGGL((sx_k_route_adj<true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T, gated ? 1 : 0);
+    reset_chain_counters(p, st);
+    const int grid = g1 - g0;
+    p->mark_begin(6, st, round_cells(p, cf, nr) * T);
+    hipLaunchKernelGGL((sx_k_route_adj<true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
     p->mark_end();
     p->chain_used = true;
 }
@@ -739,12 +748,12 @@ void route_adj_rounds(smashx_plan* p, int off, int t0, int T, hipStream_t st, hi
         if (r == 0 && cf > 1 && after_rest) (void)hipEventRecord(after_rest, st);
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
         p->mark_begin(2, st, round_cells(p, r, r + 1) * T);
-        hipLaunchKernelGGL((sx_k_route_adj<false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T, 0);
+        hipLaunchKernelGGL((sx_k_route_adj<false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T);
         p->mark_end();
     }
 }
 void route_adj(smashx_plan* p, int off, int t0, int T, hipEvent_t after_rest = nullptr) {
-    route_adj_chained(p, off, t0, T, p->stream_r, false);
+    route_adj_chained(p, off, t0, T, p->stream_r);
     route_adj_rounds(p, off, t0, T, p->stream_r, after_rest);
 }
 
@@ -855,14 +864,7 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->stream_r) != hipSuccess) { delete p; return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
     (void)hipEventCreate(&p->ev0); (void)hipEventCreate(&p->ev1);
     if (hipStreamCreate(&p->stream_j) != hipSuccess || hipEventCreate(&p->ev_j) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
-    {   // the exchange kernels beside a persistent chained launch are tiny and on the critical path of the neighbours: high priority
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        // non-blocking: a persistent launch that waits for its gate must never be waited for by work on the legacy default stream
-        if (hipStreamCreateWithFlags(&p->stream_c, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithPriority(&p->stream_x, hipStreamNonBlocking, hi) != hipSuccess) {
-            smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipStreamCreate failed");
-        }
-    }
+    if (hipStreamCreateWithFlags(&p->stream_c, hipStreamNonBlocking) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
     SxDeviceArrays& A = p->A;
     A.n = p->n; A.npad = p->npad; A.nt = p->nt; A.dt = cfg->dt; A.dx = cfg->dx; A.Tc = 0;
     if (getenv("SMASHX_VERBOSE"))
@@ -894,12 +896,12 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         TRY(p->upload_vec(&d10, p->sch.x_cons_group)); A.x_cons = d10;
         TRY(p->dmalloc(&A.prog, (size_t)p->sch.ngroups + SX_PROG_EXTRA));
         if (hipMemset(A.prog, 0, ((size_t)p->sch.ngroups + SX_PROG_EXTRA) * sizeof(int)) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipMemset"); }
-        if (const char* pw = getenv("SMASHX_PERSIST_WGS")) p->persist_wgs = std::max(1, atoi(pw));
         A.ngroups = p->sch.ngroups;
         const char* e = getenv("SMASHX_CHAIN_ROUNDS");
         p->chain = !(e && e[0] == '0');
         if (const char* dv = getenv("SMASHX_DEBUG_VLDS")) p->vlds_fwd = p->vlds_adj = (size_t)std::max(0, atoi(dv));
         if (const char* cs = getenv("SMASHX_CHAIN_STREAM")) p->chain_stream = atoi(cs) != 0;
+        if (const char* cs = getenv("SMASHX_CHAIN_STAGE")) p->chain_stage = atoi(cs) != 0;
         if (const char* dv = getenv("SMASHX_VLDS_FWD")) p->vlds_fwd = (size_t)std::max(0, atoi(dv));
         if (const char* dv = getenv("SMASHX_VLDS_ADJ")) p->vlds_adj = (size_t)std::max(0, atoi(dv));
         const char* sv = getenv("SMASHX_SPLIT_V");
@@ -911,6 +913,36 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         p->n0 = (int)p->round_ncells[0];
         const char* cfm = getenv("SMASHX_CHAIN_FROM");
         p->chain_from = cfm ? std::max(0, atoi(cfm)) : 1;
+        {   // staging rows of the chained groups (sx_kernels.h): where every cell of a chained group keeps its qt / qt_b, and every series that
+            // a round below the chain hands to a chained group, as an offset in float4 = stage x ncs + slot (row = time block + stage)
+            A.qsk = nullptr; A.ncs = 0; A.k_stg = nullptr; A.x_stg = nullptr;
+            const int cf = chain_first(p);
+            if (p->chain_stage && cf < p->sch.nrounds) {
+                const int gc = p->sch.round_group_begin[cf];
+                const int cs0 = p->sch.g_slot_begin[gc];
+                const int ncs = p->sch.nslots - cs0;
+                std::vector<unsigned> ks((size_t)p->npad, 0xffffffffu);
+                std::vector<int> xs((size_t)std::max(p->sch.nxslots, 1), -1);
+                double worst = 0.0;
+                for (int g = gc; g < p->sch.ngroups; ++g) {
+                    p->chain_rows_extra = std::max(p->chain_rows_extra, p->sch.g_dmax[g]);
+                    for (int q = p->sch.g_slot_begin[g]; q < p->sch.g_slot_begin[g + 1]; ++q) {
+                        const int c = p->sch.s_cell[q];
+                        if (c == INT_MIN) continue;
+                        const double o = (double)p->sch.s_stage[q] * ncs + (q - cs0);
+                        worst = std::max(worst, o);
+                        if (c >= 0) ks[c] = (unsigned)o;
+                        else { const int x = -1 - c; const int pg = p->sch.x_prod_group[x]; if (pg >= 0 && pg < gc) xs[x] = (int)o; }
+                    }
+                }
+                if (worst * 16.0 < 4.0e9 && worst < 2.0e9) {      // (the kernels address a row's lanes with 32-bit byte offsets)
+                    A.ncs = ncs;
+                    unsigned* dk; int* dx;
+                    TRY(p->upload_vec(&dk, ks)); A.k_stg = dk;
+                    TRY(p->upload_vec(&dx, xs)); A.x_stg = dx;
+                }
+            }
+        }
         A.spin_limit = SX_SPIN_LIMIT; A.mute_group = -1;
         if (const char* sl = getenv("SMASHX_SPIN_LIMIT")) A.spin_limit = std::max(1, atoi(sl));
         if (const char* mg = getenv("SMASHX_DEBUG_MUTE_GROUP")) A.mute_group = atoi(mg);     // tests of the stall path only
@@ -926,14 +958,6 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     TRY(p->upload_vec(&p->d_active, std::vector<int>(mesh->active_cell, mesh->active_cell + p->n2)));
     TRY(p->dmalloc(&p->d_jsum, (size_t)SX_JREG_MAXCHAIN));
     p->n_out = (int)p->sch.out_x.size(); p->n_in = (int)p->sch.in_x.size();
-    {   // chained groups whose subtree roots publish a boundary series: what the send of a sub-chunk waits for beside a persistent launch
-        std::vector<int> prod;
-        const int gc = p->sch.round_group_begin[std::min(std::max(p->chain_from, 0), p->sch.nrounds)];
-        for (int x : p->sch.out_x) { const int g = p->sch.x_prod_group[x]; if (g >= gc) prod.push_back(g); }
-        std::sort(prod.begin(), prod.end()); prod.erase(std::unique(prod.begin(), prod.end()), prod.end());
-        p->n_out_prod = (int)prod.size();
-        TRY(p->upload_vec(&p->d_out_prod, prod.empty() ? std::vector<int>(1, 0) : prod));
-    }
     TRY(p->upload_vec(&p->d_out_x, p->sch.out_x.empty() ? std::vector<int>(1, 0) : p->sch.out_x));
     TRY(p->upload_vec(&p->d_in_x, p->sch.in_x.empty() ? std::vector<int>(1, 0) : p->sch.in_x));
     // per-cell mesh data
@@ -1015,7 +1039,6 @@ int smashx_plan_destroy(smashx_plan* p) {
     if (p->stream_r) (void)hipStreamDestroy(p->stream_r);
     if (p->stream_j) { (void)hipStreamSynchronize(p->stream_j); (void)hipStreamDestroy(p->stream_j); }
     if (p->stream_c) { (void)hipStreamSynchronize(p->stream_c); (void)hipStreamDestroy(p->stream_c); }
-    if (p->stream_x) { (void)hipStreamSynchronize(p->stream_x); (void)hipStreamDestroy(p->stream_x); }
     if (p->ev_j) (void)hipEventDestroy(p->ev_j);
     delete p;
     return 0;
@@ -1382,9 +1405,9 @@ static int close_forcing(smashx_plan* p) {       // compact PET: days that never
     return 0;
 }
 
-// A chained routing launch draws its groups by ticket (sx_kernels.h), so a group only waits for groups that are resident or done and
-// for external inputs (the gate) that other streams -- or other ranks -- deliver.  Should a wait nevertheless exhaust its poll limit
-// (a neighbour that died, a starved stream), a flag is raised and the sweep's results are void: the plan then drops to one launch per
+// A chained routing launch draws its groups by ticket (sx_kernels.h), so a group only waits for groups that are resident or done: every
+// input from outside the launch (vertical kernel, round 0, series received from other ranks) is complete before the launch starts.
+// Should a wait nevertheless exhaust its poll limit, a flag is raised and the sweep's results are void: the plan then drops to one launch per
 // round for good and the sweep is run again; the ranks of a decomposition take that decision together (one all-reduce per sweep).
 int smashx_sweep(smashx_plan* p, int adjoint, float cost_b) {
     bool stalled = false;
@@ -1491,17 +1514,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     auto halo_move = [&](bool pack, bool out_edges, int off, int T, hipStream_t st) { sx_halo_move(p, native, p->A.xT, pack, out_edges, off, T, st); };
     auto hook = [&](int phase, int t0, int T, hipStream_t st) -> int { return sx_halo_hook(p, native, phase, t0, T, st); };
     const bool split = p->split_v && !halo && p->sch.nrounds > 1 && p->n0 > 0 && p->n0 < p->n;
-    // SMASHX_PERSIST=1: ONE gated chained launch per storage chunk instead of one per pipeline sub-chunk (persistent workgroups, tickets
-    // and the gate of sx_kernels.h).  Built to take the fill of the chained rounds out of every sub-chunk of a tile; measured and left
-    // OFF by default: a time-skewed group consumes inputs up to its depth (~340 blocks of 4 steps at 512 slots) ahead
-    // of what it publishes, so behind such a launch a rank can only send sub-chunk j after it has received j + 1 and j + 2 -- the fill a
-    // per-sub-chunk launch pays in time comes back as look-ahead and the rank pipeline coarsens to whole storage chunks; alone on a
-    // GPU the tile gains 9 ms of 357 (its persistent workgroups hold compute units the vertical kernels then run on at lower occupancy).
-    // Experimental switch: with a host-callback exchange between plans that share one GPU (tests/test_gpu_tiles.py) a wait was seen to
-    // run into its poll limit although every input arrived in the end (cause not found); the launch per sub-chunk is what tiles run.
-    const char* pers_env = getenv("SMASHX_PERSIST");
-    const bool persist_on = pers_env && pers_env[0] == '1' && (!halo || pers_env[1] == 'x');
-    const bool cstream = p->chain_stream && !halo && !persist_on && !split && chain_first(p) < p->sch.nrounds;
+    const bool cstream = p->chain_stream && !halo && !split && chain_first(p) < p->sch.nrounds;
     // Recomputation of a storage chunk (reverse sweep) needs no neighbour: the inlet series a rank received for that chunk in the first
     // pass are kept (n_in edges x Tc steps x 4 B per chunk) and unpacked again, and nothing is sent -- the ranks downstream kept theirs.
     // A sweep then changes direction twice between the ranks (forward -> reverse) instead of twice per recomputed chunk more.
@@ -1552,49 +1565,6 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
         // disjoint parts of the chunk buffers, so the V stream never waits for the host, which blocks in the halo hooks
         // of the routing pipeline below (tiles) -- the vertical work then hides the pipeline fill across tiles
         for (int jb = 0; jb < ns; ++jb) if ((rc = launch_v(jb))) return rc;
-        if (persist_on && ns > 1 && !split && chain_first(p) < p->sch.nrounds) {
-            // ONE chained launch for the whole storage chunk (persistent workgroups, tickets, gate: sx_kernels.h) beside the per-sub-chunk
-            // work: receive + unpack, round 0 and the gate bump on the R stream; gate on the producers' progress, pack and send on
-            // the X stream.  The fill of the chained rounds -- (time blocks + the longest cell path) super-steps -- is paid once per
-            // chunk pass instead of once per sub-chunk, and a sub-chunk's boundary series leave as soon as its blocks are published.
-            const int nb = (Tcur + 3) / 4;
-            hipStream_t sC = p->stream_c, sX = p->stream_x;
-            reset_chain_counters(p, sR);
-            hipEvent_t e_reset = p->event();
-            HIPCHK(hipEventRecord(e_reset, sR));
-            HIPCHK(hipStreamWaitEvent(sC, e_reset, 0));
-            HIPCHK(hipStreamWaitEvent(sX, e_reset, 0));
-            // two passes over the sub-chunks: a time-skewed group works up to its depth in blocks AHEAD of what it publishes, so the
-            // boundary series of sub-chunk j only complete once round 0 of the following sub-chunks has run -- nothing that feeds the
-            // gate may queue (or, with a host callback, block the host) behind a send
-            std::vector<hipEvent_t> e_r0(ns);
-            for (int jb = 0; jb < ns; ++jb) {
-                const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
-                if (halo && p->n_in > 0 && (rc = inlet_series(c, jb, off, t0c + off, T, recompute, sR))) return rc;
-                HIPCHK(hipStreamWaitEvent(sR, ev[jb], 0));
-                route_fwd_rounds(p, off, tape, t0c + off, T, sR);
-                hipLaunchKernelGGL(sx_k_gate_bump, dim3(1), dim3(64), 0, sR, SX_PROG_GATE(p->A), std::min((off + T + 3) / 4, nb));
-                e_r0[jb] = p->event();
-                HIPCHK(hipEventRecord(e_r0[jb], sR));
-                if (jb == 0) {
-                    HIPCHK(hipStreamWaitEvent(sC, e_r0[0], 0));
-                    route_fwd_chained(p, 0, tape, t0c, Tcur, sC, true);
-                }
-            }
-            for (int jb = 0; jb < ns && halo && p->n_out > 0 && !recompute; ++jb) {
-                const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
-                HIPCHK(hipStreamWaitEvent(sX, e_r0[jb], 0));
-                if (p->n_out_prod > 0)
-                    hipLaunchKernelGGL(sx_k_wait_groups, dim3(1), dim3(256), 0, sX, p->A.prog, p->d_out_prod, p->n_out_prod, 0, 0,
-                                       std::min((off + T + 3) / 4, nb), SX_PROG_STALL(p->A), p->A.spin_limit);
-                halo_move(true, true, off, T, sX);
-                if ((rc = hook(1, t0c + off, T, sX))) return rc;
-            }
-            hipEvent_t e_c = p->event(), e_x = p->event();
-            HIPCHK(hipEventRecord(e_c, sC)); HIPCHK(hipEventRecord(e_x, sX));
-            HIPCHK(hipStreamWaitEvent(sR, e_c, 0)); HIPCHK(hipStreamWaitEvent(sR, e_x, 0));
-            return 0;
-        }
         for (int jb = 0; jb < ns; ++jb) {
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
             if (halo && p->n_in > 0 && (rc = inlet_series(c, jb, off, t0c + off, T, recompute, sR))) return rc;
@@ -1606,7 +1576,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
                 hipEvent_t e_r0 = p->event();
                 HIPCHK(hipEventRecord(e_r0, sR));
                 HIPCHK(hipStreamWaitEvent(p->stream_c, e_r0, 0));
-                route_fwd_chained(p, off, tape, t0c + off, T, p->stream_c, false, ev_rest[jb]);
+                route_fwd_chained(p, off, tape, t0c + off, T, p->stream_c, ev_rest[jb]);
                 s_done = p->stream_c;
             } else
                 route_fwd(p, off, tape, t0c + off, T, ev_rest[jb]);
@@ -1625,16 +1595,9 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
         }
         return 0;
     };
-    // before a storage chunk's buffers are overwritten, the V stream must see the R stream done with them: sub-chunk by sub-chunk
-    // through buf_free (forward_chunk); only the gated launch per storage chunk, which has no per-sub-chunk end, drains the R stream
-    auto v_waits_r = [&]() -> int {
-        if (!persist_on) return 0;
-        hipEvent_t e = p->event();
-        HIPCHK(hipEventRecord(e, sR));
-        HIPCHK(hipStreamWaitEvent(sV, e, 0));
-        return 0;
-    };
+    // (before a storage chunk's buffers are overwritten the V stream waits for the R stream sub-chunk by sub-chunk: buf_free in forward_chunk)
     p->dom_q_active = !adjoint && p->h_qsim_domain && p->A.qdT;
+    p->plain_rows = !adjoint && (p->h_qsim_domain || p->h_net_prcp_domain);      // the export below reads every cell's runoff from qtT
     // optional whole-domain stores (md_forward_structure.f90:158-194) of one storage chunk -> the caller's arrays
     auto export_domain = [&](int c) -> int {
         const int t0c = c * p->Tc, Tcur = chunk_len(p, c);
@@ -1661,7 +1624,6 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     if (!adjoint) {
         const bool dom = p->h_qsim_domain || p->h_net_prcp_domain;
         for (int c = 0; c < C; ++c) {
-            if (c > 0 && (rc = v_waits_r())) return rc;
             if ((rc = forward_chunk(c, false))) return rc;
             if (dom && (rc = export_domain(c))) return rc;
         }
@@ -1672,7 +1634,6 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
                 float* cur[5] = {p->A.hi, p->A.hp, p->A.hft, p->A.hst, p->A.hlr};
                 float* dst[5];
                 for (int i = 0; i < 5; ++i) dst[i] = p->ckpt + ((size_t)c * 5 + i) * p->npad;
-                if (c > 0 && (rc = v_waits_r())) return rc;
                 if ((rc = copy_states(p, dst, cur))) return rc;
             }
             // the last storage chunk is the first one the reverse sweep needs: it runs with the tape on straight away and
@@ -1705,62 +1666,12 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
             if (C > 1 && c < C - 1) {   // recompute this storage chunk with the tape on
                 float* src[5];
                 for (int i = 0; i < 5; ++i) src[i] = p->ckpt + ((size_t)c * 5 + i) * p->npad;
-                if ((rc = v_waits_r())) return rc;
                 if ((rc = restore_states(p, src))) return rc;
                 if ((rc = forward_chunk(c, true, true))) return rc;
             }
             const int nsa = (Tcur + p->Tpa - 1) / p->Tpa;
-            const bool persa = persist_on && nsa > 1 && !split && chain_first(p) < p->sch.nrounds;
-            const int nbc = (Tcur + 3) / 4;
-            if (persa) {   // the chained rounds of the whole storage chunk in one gated launch, started first: roots of the basin lead
-                reset_chain_counters(p, sR);
-                hipEvent_t e_reset = p->event();
-                HIPCHK(hipEventRecord(e_reset, sR));
-                HIPCHK(hipStreamWaitEvent(p->stream_c, e_reset, 0));
-                HIPCHK(hipStreamWaitEvent(p->stream_x, e_reset, 0));
-                route_adj_chained(p, 0, t0c, Tcur, p->stream_c, true);
-            }
-            std::vector<hipEvent_t> e_in(persa ? nsa : 0);
-            for (int jb = nsa - 1; persa && jb >= 0; --jb) {
-                // The adjoint boundary series of every sub-chunk arrive on the X stream, which then opens the gate: reverse blocks whose
-                // series are there -- the chained roots fed by other ranks may enter them.  A time-skewed group works up to its depth in
-                // blocks AHEAD of what it publishes, so the launch can only finish a sub-chunk once the following ones' series are in:
-                // receive, unpack and gate bump never queue (or block the host) behind a sub-chunk's round 0 and send.
-                const int off = jb * p->Tpa, T = std::min(p->Tpa, Tcur - off);
-                hipStream_t sX = p->stream_x;
-                if (halo && p->n_out > 0) {
-                    if ((rc = hook(2, t0c + off, T, sX))) return rc;
-                    halo_move(false, true, off, T, sX);
-                }
-                hipLaunchKernelGGL(sx_k_gate_bump, dim3(1), dim3(64), 0, sX, SX_PROG_GATE(p->A), nbc - off / 4);
-                e_in[jb] = p->event();
-                HIPCHK(hipEventRecord(e_in[jb], sX));
-            }
             for (int jb = nsa - 1; jb >= 0; --jb) {
                 const int off = jb * p->Tpa, T = std::min(p->Tpa, Tcur - off);
-                if (persa) {
-                    const int avail = nbc - off / 4;
-                    const int gc0 = p->sch.round_group_begin[chain_first(p)];
-                    HIPCHK(hipStreamWaitEvent(sR, e_in[jb], 0));
-                    // round 0 of this sub-chunk waits until every chained group has left its blocks behind
-                    hipLaunchKernelGGL(sx_k_wait_groups, dim3(1), dim3(256), 0, sR, p->A.prog, (const int*)nullptr, 0, gc0, p->sch.ngroups, avail,
-                                       SX_PROG_STALL(p->A), p->A.spin_limit);
-                    route_adj_rounds(p, off, t0c + off, T, sR);
-                    hipEvent_t e = p->event();
-                    HIPCHK(hipEventRecord(e, sR));
-                    HIPCHK(hipStreamWaitEvent(sV, e, 0));
-                    vert_adj(p, off, t0c + off, T);
-                    if (halo && p->n_in > 0) {
-                        halo_move(true, false, off, T, sR);
-                        if ((rc = hook(3, t0c + off, T, sR))) return rc;
-                    }
-                    if (jb == 0) {
-                        hipEvent_t e_c = p->event();
-                        HIPCHK(hipEventRecord(e_c, p->stream_c));
-                        HIPCHK(hipStreamWaitEvent(sR, e_c, 0));
-                    }
-                    continue;
-                }
                 if (halo && p->n_out > 0) {
                     if ((rc = hook(2, t0c + off, T, sR))) return rc;  // out_buf now holds the downstream tiles' adjoint contributions
                     halo_move(false, true, off, T, sR);
@@ -1774,7 +1685,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
                         HIPCHK(hipEventRecord(e_r, sR));
                         HIPCHK(hipStreamWaitEvent(p->stream_c, e_r, 0));
                     }
-                    route_adj_chained(p, off, t0c + off, T, p->stream_c, false);
+                    route_adj_chained(p, off, t0c + off, T, p->stream_c);
                     hipEvent_t e_ca = p->event();
                     HIPCHK(hipEventRecord(e_ca, p->stream_c));
                     HIPCHK(hipStreamWaitEvent(sR, e_ca, 0));
@@ -1816,9 +1727,8 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
             if (getenv("SMASHX_VERBOSE")) {
                 int d[7] = {0};
                 (void)hipMemcpy(d, p->A.prog + p->sch.ngroups, sizeof(d), hipMemcpyDeviceToHost);
-                fprintf(stderr, "smashx: stall: waiter %d (group id, -1 = a gate kernel) followed counter %d (< 0: group %d's progress; 2 = the gate), "
-                        "needed %d blocks, saw %d; gate now %d, tickets drawn %d, chained groups %d..%d, progress:", d[3] - 2, d[4], p->sch.ngroups + d[4], d[5], d[6], d[2],
-                        d[1], p->sch.round_group_begin[chain_first(p)], p->sch.ngroups - 1);
+                fprintf(stderr, "smashx: stall: group %d followed the progress of group %d, needed %d blocks, saw %d; tickets drawn %d, chained groups %d..%d, progress:",
+                        d[3] - 2, p->sch.ngroups + d[4], d[5], d[6], d[1], p->sch.round_group_begin[chain_first(p)], p->sch.ngroups - 1);
                 std::vector<int> pr(p->sch.ngroups);
                 (void)hipMemcpy(pr.data(), p->A.prog, pr.size() * sizeof(int), hipMemcpyDeviceToHost);
                 for (int g = p->sch.round_group_begin[chain_first(p)]; g < p->sch.ngroups; ++g) fprintf(stderr, " %d", pr[g]);
@@ -1839,11 +1749,17 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
             case 1: tm.route_fwd_ms += ms; tm.route_fwd_launches++; tm.cellsteps[1] += l.cellsteps; break;
             case 2: tm.route_adj_ms += ms; tm.route_adj_launches++; tm.cellsteps[2] += l.cellsteps; break;
             case 3: tm.vert_adj_ms += ms; tm.vert_adj_launches++; tm.cellsteps[3] += l.cellsteps; break;
+            case 5: tm.route_fwd_ms += ms; tm.route_fwd_launches++; tm.cellsteps[1] += l.cellsteps;
+                    tm.route_fwd_chained_ms += ms; tm.route_fwd_chained_launches++; break;
+            case 6: tm.route_adj_ms += ms; tm.route_adj_launches++; tm.cellsteps[2] += l.cellsteps;
+                    tm.route_adj_chained_ms += ms; tm.route_adj_chained_launches++; break;
             default: tm.cost_ms += ms; break;
         }
     }
     tm.n_chunks = p->nchunks; tm.chunk_steps = p->Tc; tm.pipe_steps = p->Tp; tm.n_rounds = p->sch.nrounds; tm.n_groups = p->sch.ngroups;
     tm.device_bytes = p->bytes;
+    tm.max_stage = p->sch.max_stage;
+    tm.n_chained_groups = chain_first(p) < p->sch.nrounds ? p->sch.ngroups - p->sch.round_group_begin[chain_first(p)] : 0;
     p->last_adjoint = adjoint;
     return 0;
 }
@@ -2025,6 +1941,19 @@ int smashx_comm_destroy(void* comm) {
     if (c->d_buf) (void)hipFree(c->d_buf);
     if (c->comm) (void)rccl().CommDestroy(c->comm);
     delete c;
+    return 0;
+}
+
+// what the communicator itself says about the run: ranks it spans (ncclCommCount) and the library's version code (ncclGetVersion)
+int smashx_comm_info(void* comm, int* nranks, int* version) {
+    SxComm* c = (SxComm*)comm;
+    if (!c) return fail(SMASHX_E_ARG, "null communicator");
+    RcclApi& R = rccl();
+    int n = c->nranks, v = 0;
+    if (R.CommCount) NCCLCHK(R.CommCount(c->comm, &n));
+    if (R.GetVersion) NCCLCHK(R.GetVersion(&v));
+    if (nranks) *nranks = n;
+    if (version) *version = v;
     return 0;
 }
 
@@ -2481,7 +2410,8 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
         }
         jreg_d = pj + sj;
     }
-    // sweep
+    // sweep (one launch per routing round on the plain rows of every array: no staging rows, view_at)
+    struct PlainRows { smashx_plan* q; explicit PlainRows(smashx_plan* q_) : q(q_) { q->plain_rows = true; } ~PlainRows() { q->plain_rows = false; } } plain_rows_guard(p);
     p->launches.clear(); p->pool_used = 0;
     if ((rc = close_forcing(p))) return rc;
     HIPCHK(hipEventRecord(p->ev0, sV));
@@ -2523,8 +2453,8 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
                 for (int r = 0; r < p->sch.nrounds; ++r) {
                     const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
                     p->mark_begin(1, sR);
-                    if (pass == 1) hipLaunchKernelGGL((sx_k_route_fwd<true, false, 1>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c + off, T, 0);
-                    else           hipLaunchKernelGGL((sx_k_route_fwd<false, false, 2>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c + off, T, 0);
+                    if (pass == 1) hipLaunchKernelGGL((sx_k_route_fwd<true, false, 1>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c + off, T);
+                    else           hipLaunchKernelGGL((sx_k_route_fwd<false, false, 2>), dim3(ngr), dim3(p->M), lds, sR, Bt, g0, g0 + ngr, t0c + off, T);
                     p->mark_end();
                 }
                 if (halo && p->n_out > 0) {

@@ -34,9 +34,7 @@
 // global data written here is only read by later kernels.
 __device__ __forceinline__ void sx_lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-#ifndef SX_ABL_NOBAR
     __builtin_amdgcn_s_barrier();
-#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
@@ -131,23 +129,17 @@ __device__ __forceinline__ void sx_pinu(unsigned& v) { asm volatile("" : "+v"(v)
 // Forward progress (round 3): a chained launch no longer relies on the order in which the hardware dispatches workgroups.  Every
 // workgroup that becomes resident draws the next TICKET (one atomic add) and routes the group of that ticket -- tickets run through
 // the chained groups in dependency order (forward: ascending group id; reverse: descending), so a group only ever waits for groups
-// whose tickets were drawn earlier, i.e. by workgroups that are resident or done -- and loops until the tickets are exhausted.  The
-// grid may therefore be SMALLER than the number of groups (persistent workgroups): tiled plans launch ONE chained kernel per
-// storage chunk on a bounded number of compute units and leave the rest to the round-0 launches, the vertical kernels and the
-// exchange kernels that run beside it.
-// External inputs of a chained launch that spans several pipeline sub-chunks arrive while it runs; `gate` (prog[ngroups + 2]) counts
-// the chunk-local time blocks whose external inputs are complete: forward = vertical kernel, boundary series received from other
-// ranks and routing round 0 of the sub-chunk (bumped in stream order behind them); reverse = adjoint boundary series received.
+// whose tickets were drawn earlier, i.e. by workgroups that are resident or done -- and loops until the tickets are exhausted (the
+// grid may be smaller than the number of groups).
 typedef __attribute__((address_space(1))) int sx_gint;
 #define SX_PROG_STALL(A) ((A).prog + (A).ngroups)          // stall flag
 #define SX_PROG_TICKET(A) ((A).prog + (A).ngroups + 1)     // next ticket of the running chained launch
-#define SX_PROG_GATE(A) ((A).prog + (A).ngroups + 2)       // blocks whose external inputs are complete (gated launches)
 #define SX_PROG_EXTRA 8
 #ifndef SX_PK
 #define SX_PK 16              // macro-steps between two publications (x SX_MU x SX_BT = 256 time steps); 2..16 measured, fences dominate
 #endif
 #define SX_SPIN_LIMIT (1 << 22)   // polls (~1 us each at least) before a stalled chain is reported instead of hanging (SxDeviceArrays::spin_limit)
-// stalled[0] = flag; stalled[3..6] = diagnostics of the first waiter that gave up: tag (the waiting group, -1: a gate kernel), the
+// stalled[0] = flag; stalled[3..6] = diagnostics of the first waiter that gave up: tag (the waiting group), the
 // counter it followed (address distance to the flag, in ints), the blocks it needed and the blocks it last saw
 __device__ __forceinline__ void sx_wait_prog(const int* prog, int need, int& seen, int* stalled, int limit, int tag = -1) {
     if (seen >= need) return;
@@ -171,28 +163,8 @@ __device__ __forceinline__ void sx_wait_prog(const int* prog, int need, int& see
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 __device__ __forceinline__ void sx_publish(int* prog, int blocks) {
-#ifndef SX_ABL_NOREL
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#endif
     __hip_atomic_store((sx_gint*)prog, blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ---- small kernels beside a gated chained launch (one workgroup each) ------------------------------------------------------
-// "the external inputs of the chunk's first `blocks` time blocks are complete": enqueued behind the kernels that produce them
-__global__ void sx_k_gate_bump(int* gate, int blocks) {
-    if (threadIdx.x == 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            __hip_atomic_store((sx_gint*)gate, blocks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-}
-// waits until every listed group (list == null: every group of [g0, g1)) has published `need` blocks; the kernels enqueued behind it
-// (pack + send of a sub-chunk's boundary series; round 0 of the reverse sweep) then read what those groups stored.  Bounded like
-// every other wait: running out of polls raises the stall flag and returns.
-__global__ void sx_k_wait_groups(const int* prog, const int* list, int nlist, int g0, int g1, int need, int* stalled, int limit) {
-    const int n = list ? nlist : g1 - g0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int g = list ? list[i] : g0 + i;
-        int seen = 0;
-        sx_wait_prog(prog + g, need, seen, stalled, limit);
-    }
 }
 
 struct SxDeviceArrays {
@@ -229,6 +201,11 @@ struct SxDeviceArrays {
     float *tape_hi, *tape_hp, *tape_hft, *tape_hst;
     float* ckpt_hi;               // gr-b / gr-c: hi at every SX_HIK-th step of the chunk, [Tc / SX_HIK][npad] (tape_hi: vic-a only)
     float* xT;                    // exchange series
+    // staging rows of the chained groups: [time block + stage][chained slot] float4 (null = off; see "Staging rows" below).
+    // ncs = slots of the chained groups; k_stg[cell] = stage x ncs + slot of a cell that belongs to a chained group (0xffffffff: a cell of
+    // the rounds below the chain); x_stg[series] = the same for the inlet of a series that a round below the chain hands to a chained
+    // group (-1: any other series)
+    float* qsk; int ncs; const unsigned* k_stg; const int* x_stg;
     // gauges
     float *qg, *qgb;              // [ngc][nt] discharge at gauge cells / adjoint seeds
     int* cell_gauge;              // [npad] gauge-cell id or -1
@@ -236,12 +213,49 @@ struct SxDeviceArrays {
     const int *g_slot_begin, *g_dmax;
     const int *s_cell, *s_stage, *s_sub, *s_wsub, *s_child, *s_ccount, *s_parent, *s_xout;   // sx_plan.h: components, sub-levels
     const int *x_prod, *x_cons;   // per exchange series: publishing group / group holding the inlet (-1: other tile)
-    int* prog;                    // [ngroups + SX_PROG_EXTRA]: blocks published by each group in the running launch, then the stall flag, the ticket
-                                  // counter and the gate (SX_PROG_STALL / _TICKET / _GATE)
+    int* prog;                    // [ngroups + SX_PROG_EXTRA]: blocks published by each group in the running launch, then the stall flag and the
+                                  // ticket counter (SX_PROG_STALL / _TICKET), then the stall diagnostics
     int ngroups;
     int spin_limit;               // polls before a waiting group gives up and raises the stall flag
     int mute_group;               // tests only (SMASHX_DEBUG_MUTE_GROUP): this group never publishes -> its consumers stall; -1 = none
     long long* gtime;             // diagnostics (SMASHX_TRACE_GROUPS=1): [2 passes][ngroups][start, end] wall_clock64 ticks, else null
+};
+
+// ------------------------------------------------------------------------------------------------
+// Staging rows of the chained groups.  The groups of the rounds >= 1 are the river's main stems: a few workgroups whose super-step
+// is a latency chain, and every memory instruction in it whose 64 lanes touch 64 different lines (slots of one wave sit at different
+// stages, hence in different rows of the time-major arrays) costs that chain a full pass through the CU's memory path (DESIGN.md 12,
+// anatomy of a super-step).  Round 2 gave the routing tape the cure -- row = time block + stage, so a group's super-step touches one
+// row.  Round 4 gives it to everything else a chained group reads and writes: the runoff qt (later its adjoint qt_b) of the cells of the
+// chained groups, and the series that the rounds below the chain hand to them (later the adjoint series handed back), LIVE in the
+// staging array qsk [time block + stage][chained slot] instead of qtT / xT.  Whoever sits at the other end addresses them there:
+// the vertical kernels (a per-cell offset k_stg: the 5 % of their wavefronts that hold such cells store / load a few pieces per
+// instruction instead of one -- once per four steps), the subtree roots of the rounds below the chain (x_stg, a per-slot base and
+// stride like every other series).  No copy pass: a first version that gathered the rows before and scattered them after each
+// chained launch spent 6 ms per pass at 1024^2 x 8760 -- more than the chained launches gained.  Series between two chained groups
+// (produced and consumed inside the launch, behind the counters) and series to or from other ranks keep their plain rows.
+// The tangent sweep, the launch-per-round fallback and sweeps that export the runoff of every cell run with qsk = null: plain rows.
+// ------------------------------------------------------------------------------------------------
+template <int AUX = 0>
+__device__ __forceinline__ void sx_row_store4_wide(float* row, unsigned byte_off, float a, float b, float c, float d) {     // byte offsets up to 4 GB
+    typedef int sx_v4i __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0xffffffff, 0x00020000);
+    sx_v4i v = {__builtin_bit_cast(int, a), __builtin_bit_cast(int, b), __builtin_bit_cast(int, c), __builtin_bit_cast(int, d)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, AUX);
+}
+template <int AUX = 0>
+__device__ __forceinline__ float sx_row_load_wide(const float* row, unsigned byte_off) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0xffffffff, 0x00020000);
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, AUX));
+}
+// qt (forward) / qt_b (reverse) of one cell: where the four steps of time block tq of this launch live
+struct SxQtAddr {
+    bool stg; unsigned off;      // staged: byte offset inside a staging row; else inside a plain row
+    __device__ __forceinline__ SxQtAddr(const SxDeviceArrays& A, int k) {
+        const unsigned so = A.qsk ? A.k_stg[k] : 0xffffffffu;
+        stg = so != 0xffffffffu;
+        off = stg ? so * 16u : (unsigned)k * 16u;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -403,6 +417,7 @@ void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
 
     // rows are wave-uniform (sx_row_load / sx_row_store): the vector unit does no address arithmetic in the time loop
     const unsigned kb = (unsigned)k * 4u;
+    const SxQtAddr QA(A, k);
     SxForcing<CF> F(A, kb, t0);
     if (T > 0) F.template request<SX_NT, false>(t0, true);
     for (int tq = 0; tq * 4 < T; ++tq) {
@@ -428,7 +443,8 @@ void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
                 q[i] = sx_vertical_step<ST>(P, prcp, pet, hi, hp, hft, hst, still);
             }
         }
-        sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
+        if (!QA.stg) sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
+        else sx_row_store4_wide<SX_NT>(A.qsk + (size_t)tq * A.ncs * 4, QA.off, q[0], q[1], q[2], q[3]);      // a cell of a chained group
     }
     if (ST == 2 || ST == 3) A.hi[k] = hi;
     A.hp[k] = hp;
@@ -462,6 +478,7 @@ __global__ __launch_bounds__(SX_VBLOCK, TAPE ? SX_VFWD_WAVES_VIC : 1) void sx_k_
     const float cusl2_m4 = sx_pow_m4(P.cusl2);
     float husl1 = A.hi[k], husl2 = A.hp[k], hlsl = A.hft[k];
     const unsigned kb = (unsigned)k * 4u;
+    const SxQtAddr QA(A, k);
     SxForcing<CF> F(A, kb, t0);
     if (T > 0) F.template request<SX_NT, false>(t0, true);
     for (int tq = 0; tq * 4 < T; ++tq) {
@@ -481,7 +498,8 @@ __global__ __launch_bounds__(SX_VBLOCK, TAPE ? SX_VFWD_WAVES_VIC : 1) void sx_k_
                 q[i] = sx_vic_step(P, cusl2_m4, F.prcp(), F.pet(), husl1, husl2, hlsl);
             }
         }
-        sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
+        if (!QA.stg) sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
+        else sx_row_store4_wide<SX_NT>(A.qsk + (size_t)tq * A.ncs * 4, QA.off, q[0], q[1], q[2], q[3]);      // a cell of a chained group
     }
     A.hi[k] = husl1; A.hp[k] = husl2; A.hft[k] = hlsl;
 }
@@ -505,6 +523,7 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES_VIC) void sx_k_vert_adj_vi
     G.ds_b = A.px_b[0][k]; G.dsm_b = A.px_b[1][k]; G.ws_b = A.px_b[2][k];
     G.husl1_b = A.hi_b[k]; G.husl2_b = A.hp_b[k]; G.hlsl_b = A.hft_b[k];
     const unsigned kb = (unsigned)k * 4u;
+    const SxQtAddr QA(A, k);
     SxForcing<CF> F(A, kb, t0 + T - 1);
     float n_h1 = 0.f, n_h2 = 0.f, n_hl = 0.f, n_q = 0.f;
     auto fetch = [&](int tt, bool first) {
@@ -512,7 +531,8 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES_VIC) void sx_k_vert_adj_vi
         F.template request<SX_VADJ_NT, true>(t0 + tt, first);
         n_h1 = sx_row_load<SX_VADJ_NT>(A.tape_hi + o, kb); n_h2 = sx_row_load<SX_VADJ_NT>(A.tape_hp + o, kb);
         n_hl = sx_row_load<SX_VADJ_NT>(A.tape_hft + o, kb);
-        n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
+        if (!QA.stg) n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
+        else n_q = sx_row_load_wide(A.qsk + (size_t)(tt >> 2) * A.ncs * 4 + (tt & 3), QA.off);                  // a cell of a chained group
     };
     if (T > 0) fetch(T - 1, true);
     for (int tt = T - 1; tt >= 0; --tt) {
@@ -631,25 +651,6 @@ __global__ __launch_bounds__(SX_VBLOCK) void sx_k_vert_fwd_d(SxDeviceArrays A, i
 #ifndef SX_MU_A
 #define SX_MU_A SX_MU     // reverse kernel
 #endif
-// Timing-only builds for the anatomy of a routing super-step (tools/anatomy.sh -> profiles/r2_routing_anatomy*.json): each switch
-// removes one ingredient; results are void, the schedule and the progress protocol are not touched (no switch can hang a launch).
-//   SX_ABL_NOBAR (no workgroup barrier)  SX_ABL_NOREL (publications without release fence)  SX_ABL_NOLDS (children not read from LDS)
-//   SX_ABL_NOST / SX_ABL_NOLD (forward: no global stores / loads)   SX_ABL_A_NOQ / _NOX / _NOHR (reverse: no qt_b / series stores, no tape loads)
-#ifndef SX_ABL_NOST
-#define SX_ABL_NOST 0
-#endif
-#ifndef SX_ABL_NOLD
-#define SX_ABL_NOLD 0
-#endif
-#ifndef SX_ABL_A_NOQ
-#define SX_ABL_A_NOQ 0
-#endif
-#ifndef SX_ABL_A_NOX
-#define SX_ABL_A_NOX 0
-#endif
-#ifndef SX_ABL_A_NOHR
-#define SX_ABL_A_NOHR 0
-#endif
 #ifndef SX_MAXGROUP
 #define SX_MAXGROUP 512   // largest routing workgroup (group_size): 8 waves = 2 per SIMD
 #endif
@@ -687,8 +688,7 @@ __device__ __forceinline__ int sx_next_ticket(const SxDeviceArrays& A) {
 }
 
 template <bool TAPE, bool CHAIN, int TMODE>
-__device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, const int g, const int g0, const int gend, const int t0, const int T,
-                                                   const bool gated) {
+__device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, const int g, const int g0, const int gend, const int t0, const int T) {
     constexpr bool TAN = (TMODE == 2);
     constexpr int MU = SX_MU_F, PK = SX_PK * 4 / MU;     // super-steps per macro-step; macro-steps between two publications
     constexpr bool DFORM = (TMODE == 1);
@@ -704,11 +704,7 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
     float a = 0.f, f = 0.f, den = 1.f, hlr = 0.f, ad = 0.f;
     bool hasup = false;
     // sub-levels of this wavefront's components (wave-uniform): the number of passes through a super-step's body
-#if defined(SX_ABL_ONE_SUBLEVEL)      // timing-only build: what the sub-level loop costs when every component is one level (the default schedule)
-    const int nsubw = 1;
-#else
     const int nsubw = __builtin_amdgcn_readfirstlane(m > 0 ? A.s_wsub[sb + min(j, m - 1)] : 1);
-#endif
     if (valid && A.s_cell[sb + j] == INT_MIN) valid = false;      // a hole of a partly filled wavefront
     if (valid) {
         const int c = A.s_cell[sb + j];
@@ -729,24 +725,30 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
     }
     const float dt = A.dt, dx = A.dx;
     const SxDiv dden = sx_mkdiv(den), ddt = sx_mkdiv(dt);
+    // chained rounds: an inlet whose series is published inside this launch follows its producer's counter
+    const int* wprog = nullptr;
+    int seen = 0;
+    if (CHAIN && xin >= 0) { const int pg = A.x_prod[xin]; if (pg >= g0 && pg < gend) wprog = A.prog + pg; }
+    // "Staging rows" above: the runoff of a cell of a chained group and a series handed up to a chained group live in qsk (row = time
+    // block + the chained slot's stage) -- this slot may be that cell / that inlet, or the subtree root below the chain that publishes
+    const bool stg_on = !TAN && A.qsk != nullptr && valid;
+    const unsigned so_in = !stg_on ? 0xffffffffu : cell >= 0 ? A.k_stg[cell] : (xin >= 0 ? (unsigned)A.x_stg[xin] : 0xffffffffu);
+    const bool staged = so_in != 0xffffffffu;
+    const unsigned so_out = (stg_on && xout >= 0) ? (unsigned)A.x_stg[xout] : 0xffffffffu;
     // T4 addressing: element (tb, id) of an array with `stride` float4 per time block
-    const float4* src = (cell >= 0) ? reinterpret_cast<const float4*>(TAN ? A.qtdT : A.qtT) + cell
+    const float4* src = staged ? reinterpret_cast<const float4*>(A.qsk) + so_in
+                      : (cell >= 0) ? reinterpret_cast<const float4*>(TAN ? A.qtdT : A.qtT) + cell
                                     : reinterpret_cast<const float4*>(TAN ? A.xdT : A.xT) + (xin >= 0 ? xin : 0);
-    const size_t sstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
+    const size_t sstride = staged ? (size_t)A.ncs : (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
     float4* x4 = reinterpret_cast<float4*>(TAN ? A.xdT : A.xT);
+    float4* const xdst = so_out != 0xffffffffu ? reinterpret_cast<float4*>(A.qsk) + so_out : x4 + (xout >= 0 ? xout : 0);      // a root's series
+    const size_t xstride = so_out != 0xffffffffu ? (size_t)A.ncs : (size_t)A.nx;
     float4* hr4 = reinterpret_cast<float4*>(A.hrT);
     // hr_imd tape, private to the routing kernels: row = time block + stage, so the slots of a group -- which work on time block
     // w - stage in super-step w -- all write row w, cell next to cell (measured: 64 -> 8 line requests per wave store)
     const int hs = A.hr_skew ? stage : 0;
     float* gauge_out = TAN ? A.qgd : A.qg;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // chained rounds: an inlet whose series is published inside this launch follows its producer's counter
-    const int* wprog = nullptr;
-    int seen = 0;
-    if (CHAIN && xin >= 0) { const int pg = A.x_prod[xin]; if (pg >= g0 && pg < gend) wprog = A.prog + pg; }
-    // gated launch: everything else a slot reads -- its cell's runoff, a series published by round 0 or received from another
-    // rank -- belongs to a pipeline sub-chunk that may not have been produced yet: follow the gate
-    if (CHAIN && gated && valid && !wprog) wprog = SX_PROG_GATE(A);
     auto fetch = [&](int tb) -> float4 { return cell >= 0 ? sx_gload4s(src + (size_t)tb * sstride) : sx_gload4(src + (size_t)tb * sstride); };
 
     float4 nxt[MU], outq[MU], outh[MU], nhr[MU];
@@ -767,12 +769,12 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
         // chained: the stores of the previous macro-step (four super-steps old) have completed past this point
         if (CHAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // results of the previous macro-step leave now
-        if (mw > 0 && cell >= 0 && !SX_ABL_NOST) {
+        if (mw > 0 && cell >= 0) {
 #pragma unroll
             for (int u = 0; u < MU; ++u) {
                 const int tb = MU * (mw - 1) + u - stage;
                 if (tb >= 0 && tb < nb) {
-                    if (xout >= 0) x4[(size_t)tb * A.nx + xout] = outq[u];
+                    if (xout >= 0) xdst[(size_t)tb * xstride] = outq[u];
                     if (TAPE) sx_gstore4s(hr4 + (size_t)(tb + hs) * A.npad + cell, outh[u]);
                     if (A.qdT) reinterpret_cast<float4*>(A.qdT)[(size_t)tb * A.npad + cell] = outq[u];
                     if (gid >= 0) {
@@ -790,7 +792,7 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
 #pragma unroll
         for (int u = 0; u < MU; ++u) {
             const int tb = MU * (mw + 1) + u - stage;
-            nxt[u] = (valid && tb >= 0 && tb < nb && !SX_ABL_NOLD) ? fetch(tb) : zero4;
+            nxt[u] = (valid && tb >= 0 && tb < nb) ? fetch(tb) : zero4;
             if (TAN) nhr[u] = (valid && cell >= 0 && tb >= 0 && tb < nb) ? sx_gload4(hr4 + (size_t)(tb + hs) * A.npad + cell) : zero4;
         }
 #pragma unroll
@@ -813,20 +815,12 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
                     // together so their LDS latencies overlap; "+ 0" for an absent child is exact
                     float s[SX_BT];
                     {
-#ifdef SX_ABL_NOLDS
-                        const float4 v0 = cur[u], v1 = cur[u];
-#else
                         const float4 v0 = child_val(ch01 & 0xffffu), v1 = child_val(ch01 >> 16);
-#endif
                         const bool h0 = ccount > 0, h1 = ccount > 1;
                         s[0] = (h0 ? v0.x : 0.f) + (h1 ? v1.x : 0.f); s[1] = (h0 ? v0.y : 0.f) + (h1 ? v1.y : 0.f);
                         s[2] = (h0 ? v0.z : 0.f) + (h1 ? v1.z : 0.f); s[3] = (h0 ? v0.w : 0.f) + (h1 ? v1.w : 0.f);
                     }
-#ifdef SX_ABL_NOLDS
-                    for (int c = 2; c < 0; ++c) {
-#else
                     for (int c = 2; c < ccount; ++c) {
-#endif
                         const unsigned wd = c < 4 ? ch23 : c < 6 ? ch45 : ch67;
                         const float4 v = child_val((wd >> ((c & 1) * 16)) & 0xffffu);
                         s[0] = s[0] + v.x; s[1] = s[1] + v.y; s[2] = s[2] + v.z; s[3] = s[3] + v.w;
@@ -835,10 +829,13 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
                     float q[SX_BT], hr[SX_BT], qup[SX_BT], qro[SX_BT];
                     // three phases so that only the two-operation store recurrence is serial: the divisions of the
                     // four steps are independent and overlap (a lone wave pays the full latency of every dependent op)
+                    {
+                        float nq[SX_BT], dq[SX_BT];
 #pragma unroll
-                    for (int i = 0; i < SX_BT; ++i) {
-                        const float d = DFORM ? dt * sx_div(s[i], dden) : sx_div(s[i] * dt, dden);
-                        qup[i] = hasup ? d : 0.f;
+                        for (int i = 0; i < SX_BT; ++i) nq[i] = DFORM ? s[i] : s[i] * dt;
+                        sx_div4(dq, nq, dden);
+#pragma unroll
+                        for (int i = 0; i < SX_BT; ++i) qup[i] = hasup ? (DFORM ? dt * dq[i] : dq[i]) : 0.f;
                     }
                     if (!TAN) {
 #pragma unroll
@@ -851,10 +848,13 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
                             hr[i] = live ? hr_imd : 0.f;
                             hlr = live ? hnew : hlr;
                         }
+                        float nq[SX_BT], dq[SX_BT];
+#pragma unroll
+                        for (int i = 0; i < SX_BT; ++i) nq[i] = DFORM ? qt[i] + f * qro[i] : (qt[i] + qro[i] * f) * dx * dx * 0.001f;
+                        sx_div4(dq, nq, ddt);
 #pragma unroll
                         for (int i = 0; i < SX_BT; ++i) {
-                            const float v = DFORM ? (0.001f * (dx * dx)) * sx_div(qt[i] + f * qro[i], ddt)
-                                                  : sx_div((qt[i] + qro[i] * f) * dx * dx * 0.001f, ddt);
+                            const float v = DFORM ? (0.001f * (dx * dx)) * dq[i] : dq[i];
                             q[i] = (tl + i < T) ? v : 0.f;
                         }
                     } else {
@@ -904,15 +904,14 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
     }
 }
 
-// gated != 0: the launch spans several pipeline sub-chunks whose external inputs arrive while it runs (see "gate" above)
 template <bool TAPE, bool CHAIN, int TMODE = 0>
-__global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_F) void sx_k_route_fwd(SxDeviceArrays A, int g0, int gend, int t0, int T, int gated) {
+__global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_F) void sx_k_route_fwd(SxDeviceArrays A, int g0, int gend, int t0, int T) {
     if (SX_R_PRIO) __builtin_amdgcn_s_setprio(SX_R_PRIO);
-    if (!CHAIN) { sx_route_fwd_group<TAPE, false, TMODE>(A, g0 + (int)blockIdx.x, g0, gend, t0, T, false); return; }
+    if (!CHAIN) { sx_route_fwd_group<TAPE, false, TMODE>(A, g0 + (int)blockIdx.x, g0, gend, t0, T); return; }
     for (;;) {
         const int ticket = sx_next_ticket(A);
         if (ticket >= gend - g0) break;
-        sx_route_fwd_group<TAPE, CHAIN, TMODE>(A, g0 + ticket, g0, gend, t0, T, gated != 0);
+        sx_route_fwd_group<TAPE, CHAIN, TMODE>(A, g0 + ticket, g0, gend, t0, T);
     }
 }
 
@@ -923,8 +922,7 @@ __global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_F) void sx_k_route_fwd(SxDevice
 // Same macro-step staging of global memory as the forward kernel.
 // ------------------------------------------------------------------------------------------------
 template <bool CHAIN>
-__device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, const int g, const int g0, const int gend, const int t0, const int T,
-                                                   const bool gated) {
+__device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, const int g, const int g0, const int gend, const int t0, const int T) {
     constexpr int MU = SX_MU_A, PK = SX_PK * 4 / MU;
     extern __shared__ __attribute__((aligned(16))) float4 sx_lds[];
     const int sb = A.g_slot_begin[g], m = A.g_slot_begin[g + 1] - sb, dmax = A.g_dmax[g];
@@ -937,11 +935,7 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
     bool psame = false;                 // the parent sits in the same component (same wavefront, next sub-level up)
     float a = 0.f, f = 0.f, den = 1.f, lr = 1.f, hr_b = 0.f, lr_b = 0.f;
     bool hasup = false;
-#if defined(SX_ABL_ONE_SUBLEVEL)      // timing-only build: what the sub-level loop costs when every component is one level (the default schedule)
-    const int nsubw = 1;
-#else
     const int nsubw = __builtin_amdgcn_readfirstlane(m > 0 ? A.s_wsub[sb + min(j, m - 1)] : 1);
-#endif
     if (valid && A.s_cell[sb + j] == INT_MIN) valid = false;      // a hole of a partly filled wavefront
     if (valid) {
         const int c = A.s_cell[sb + j];
@@ -971,8 +965,17 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
     // where a slot's result goes: qt_b of its cell, or -- inlet -- the adjoint series of the subtree upstream.  ONE store instruction
     // for both kinds (per-lane base and row stride): in the chained rounds, where a third of the slots are inlets, the second store
     // instruction of a super-step cost as much as the first whatever its lane count (anatomy of the reverse launch)
-    float4* const dst = (cell >= 0) ? qt4 + cell : x4 + (xin >= 0 ? xin : 0);
-    const size_t dstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
+    // "Staging rows": qt_b of a cell of a chained group and the adjoint series an inlet of a chained group hands down to a round below the
+    // chain go to qsk (row = time block + the chained slot's stage = one row per reverse super-step of the group); a subtree root below the
+    // chain finds the adjoint of its series there
+    const bool stg_on = A.qsk != nullptr && valid;
+    const unsigned so_out = !stg_on ? 0xffffffffu : cell >= 0 ? A.k_stg[cell] : (xin >= 0 ? (unsigned)A.x_stg[xin] : 0xffffffffu);
+    const bool staged = so_out != 0xffffffffu;
+    const unsigned so_in = (stg_on && cell >= 0 && xout >= 0) ? (unsigned)A.x_stg[xout] : 0xffffffffu;
+    float4* const dst = staged ? reinterpret_cast<float4*>(A.qsk) + so_out : (cell >= 0) ? qt4 + cell : x4 + (xin >= 0 ? xin : 0);
+    const size_t dstride = staged ? (size_t)A.ncs : (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
+    const float4* const xsrc = so_in != 0xffffffffu ? reinterpret_cast<const float4*>(A.qsk) + so_in : x4 + (xout >= 0 ? xout : 0);
+    const size_t xsstride = so_in != 0xffffffffu ? (size_t)A.ncs : (size_t)A.nx;
 
     // gauge cells also fetch their adjoint seeds (qsim_b summed per cell) with the staged loads, so the
     // super-step loop itself contains no global memory operation and no vmcnt wait
@@ -992,9 +995,7 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
     const int* wprog = nullptr;
     int seen = 0;
     if (CHAIN && root_in) { const int cg = A.x_cons[xout]; if (cg >= g0 && cg < gend) wprog = A.prog + cg; }
-    // gated launch: a root whose receiver lives on another rank reads an adjoint series that arrives sub-chunk by sub-chunk
-    if (CHAIN && gated && root_in && !wprog) wprog = SX_PROG_GATE(A);
-    auto fetch_in = [&](int tb) -> float4 { return sx_gload4(x4 + (size_t)tb * A.nx + xout); };
+    auto fetch_in = [&](int tb) -> float4 { return sx_gload4(xsrc + (size_t)tb * xsstride); };
     float4 nhr[MU], nin[MU], nsd[MU], outq[MU];
     if (CHAIN && wprog) sx_wait_prog(wprog, min(MU - rstage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
 #pragma unroll
@@ -1002,7 +1003,7 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
         const int tbr = u - rstage;
         const int tb = nb - 1 - tbr;
         const bool ok = valid && tbr >= 0 && tbr < nb;
-        nhr[u] = (ok && cell >= 0) ? (SX_ABL_A_NOHR ? zero4 : sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell)) : zero4;
+        nhr[u] = (ok && cell >= 0) ? sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell) : zero4;
         nin[u] = (ok && root_in) ? fetch_in(tb) : zero4;
         nsd[u] = ok ? load_seed(tb) : zero4;
         outq[u] = zero4;
@@ -1024,7 +1025,7 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
                 if (tbr >= 0 && tbr < nb) {
                     const int tb = nb - 1 - tbr;
                     // one store instruction for both kinds of slot; the inlets' destination is an exchange row: never nontemporal
-                    if (!(cell >= 0 ? SX_ABL_A_NOQ : SX_ABL_A_NOX)) sx_gstore4(dst + (size_t)tb * dstride, outq[u]);
+                    sx_gstore4(dst + (size_t)tb * dstride, outq[u]);
                 }
             }
         }
@@ -1035,7 +1036,7 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
             const int tbr = MU * (mw + 1) + u - rstage;
             const int tb = nb - 1 - tbr;
             const bool ok = valid && tbr >= 0 && tbr < nb;
-            nhr[u] = (ok && cell >= 0) ? (SX_ABL_A_NOHR ? zero4 : sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell)) : zero4;
+            nhr[u] = (ok && cell >= 0) ? sx_gload4s(hr4p + (size_t)(tb + hs) * A.npad + cell) : zero4;
             nin[u] = (ok && root_in) ? fetch_in(tb) : zero4;
             nsd[u] = ok ? load_seed(tb) : zero4;
         }
@@ -1058,14 +1059,17 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
                     const float sdv[SX_BT] = {csd[u].x, csd[u].y, csd[u].z, csd[u].w};
                     float pb[SX_BT], qtb[SX_BT];
                     float tmpb[SX_BT], qrb[SX_BT], himb[SX_BT], a1b[SX_BT];
+                    float nq[SX_BT];
 #pragma unroll
                     for (int i = SX_BT - 1; i >= 0; --i) {          // independent of the carried adjoint state
                         float q_b = 0.f;
                         if (gid >= 0) q_b = q_b + sdv[i];
                         q_b = q_b + inv[i];
-                        tmpb[i] = sx_div((dx * dx) * 0.001f * q_b, ddt);
-                        qrb[i] = f * tmpb[i];
+                        nq[i] = (dx * dx) * 0.001f * q_b;
                     }
+                    sx_div4(tmpb, nq, ddt);
+#pragma unroll
+                    for (int i = SX_BT - 1; i >= 0; --i) qrb[i] = f * tmpb[i];
 #pragma unroll
                     for (int i = SX_BT - 1; i >= 0; --i) {          // the serial part: hr_b recurrence (3 operations per step)
                         const bool live = tl + i < T;
@@ -1074,13 +1078,17 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
                         a1b[i] = a * hrv[i] * hb1;
                         hr_b = live ? himb[i] : hr_b;
                     }
+                    float na[SX_BT], nh[SX_BT], da[SX_BT], dh[SX_BT];
+#pragma unroll
+                    for (int i = 0; i < SX_BT; ++i) { na[i] = dt * a1b[i]; nh[i] = dt * himb[i]; }
+                    sx_div4(da, na, dlr);
+                    sx_div4(dh, nh, dden);
 #pragma unroll
                     for (int i = SX_BT - 1; i >= 0; --i) {          // lr_b keeps its reverse-time summation order
                         const bool live = tl + i < T;
-                        const float lnew = lr_b + sx_div(dt * a1b[i], dlr);
-                        const float pbi = sx_div(dt * himb[i], dden);
+                        const float lnew = lr_b + da[i];
                         lr_b = live ? lnew : lr_b;
-                        pb[i] = (live && hasup) ? pbi : 0.f;
+                        pb[i] = (live && hasup) ? dh[i] : 0.f;
                         qtb[i] = live ? tmpb[i] : 0.f;
                     }
                     pub[j] = make_float4(pb[0], pb[1], pb[2], pb[3]);
@@ -1108,14 +1116,14 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
 }
 
 template <bool CHAIN>
-__global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDeviceArrays A, int g0, int gend, int t0, int T, int gated) {
+__global__ __launch_bounds__(SX_MAXGROUP, SX_RLB_A) void sx_k_route_adj(SxDeviceArrays A, int g0, int gend, int t0, int T) {
     if (SX_R_PRIO) __builtin_amdgcn_s_setprio(SX_R_PRIO);
-    if (!CHAIN) { sx_route_adj_group<false>(A, g0 + (int)blockIdx.x, g0, gend, t0, T, false); return; }
+    if (!CHAIN) { sx_route_adj_group<false>(A, g0 + (int)blockIdx.x, g0, gend, t0, T); return; }
     // chained rounds run roots-of-the-basin first: tickets walk the groups downwards
     for (;;) {
         const int ticket = sx_next_ticket(A);
         if (ticket >= gend - g0) break;
-        sx_route_adj_group<CHAIN>(A, gend - 1 - ticket, g0, gend, t0, T, gated != 0);
+        sx_route_adj_group<CHAIN>(A, gend - 1 - ticket, g0, gend, t0, T);
     }
 }
 
@@ -1173,6 +1181,7 @@ void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
     // addresses = wave-uniform row (buffer descriptor in scalar registers, advanced by the scalar unit) + the cell's 32-bit
     // byte offset: no vector address arithmetic in the time loop
     const unsigned kb = (unsigned)k * 4u;
+    const SxQtAddr QA(A, k);
     SxForcing<CF> F(A, kb, t0 + T - 1);
     float n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
     const bool hi_taped = (ST == 2 || ST == 3) && A.tape_hi != nullptr;       // wave-uniform
@@ -1188,7 +1197,8 @@ void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
         n_hp = sx_row_load<SX_VADJ_NT>(r_hp, kb); n_hft = sx_row_load<SX_VADJ_NT>(r_hft, kb);
         r_hp -= npad; r_hft -= npad;
         if (ST == 3) { n_hst = sx_row_load<SX_VADJ_NT>(r_hst, kb); r_hst -= npad; }
-        n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
+        if (!QA.stg) n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
+        else n_q = sx_row_load_wide(A.qsk + (size_t)(tt >> 2) * A.ncs * 4 + (tt & 3), QA.off);                  // a cell of a chained group
     };
     // When the interception level is not taped (it depends on the forcing and ci only; the plan drops its tape when that is what
     // lets the whole period fit): each block of SX_HIK steps is marched forward once more from its checkpoint -- the same

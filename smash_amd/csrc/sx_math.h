@@ -95,13 +95,10 @@ SX_HD float sx_div_scaled(float a, const SxDiv& D, bool* ok) {
     return q3;
 }
 SX_HD float sx_div(float a, const SxDiv& D) {
-#if defined(SX_ABL_DIV)
-    return a * D.r;      // timing-only build (tools/anatomy.sh): what the exact divisions cost; results void
-#endif
     const float q = a * D.r;
     const float e = fmaf(-D.d, q, a);
     const float q2 = fmaf(e, D.r, q);
-#if SX_EXACT_LIBM && !defined(SX_ABL_NOGUARD)
+#if SX_EXACT_LIBM
     // The theorem needs the residual to be exact: outside the comfortable exponent range (tiny quotients on their way to the
     // subnormals -- the fringe of a decaying adjoint field is full of them -- and huge ones) the exact build takes the IEEE division.
     // SX_EXACT_DIV: 0 = per-lane branch (round 2), 1 = the test is made for the whole wavefront (scalar branch, the IEEE expansion
@@ -129,6 +126,24 @@ SX_HD float sx_div(float a, const SxDiv& D) {
     return q2;
 }
 
+// Four quotients by one loop-invariant denominator (the routing kernels' time blocks).  Default build: four sx_div.  Exact-libm build:
+// the three operations for all four, then ONE range test for the batch -- sx_div's wave-uniform guard costs a ballot and a scalar branch
+// per quotient, and in a routing super-step (8 quotients forward, 12 reverse) that was a third of the instructions -- and only a
+// wavefront that holds an out-of-range quotient goes through the guarded form.  Same results as four sx_div by construction.
+SX_HD void sx_div4(float* q, const float* a, const SxDiv& D) {
+#if SX_EXACT_LIBM && defined(__HIP_DEVICE_COMPILE__) && SX_EXACT_DIV >= 1
+    bool odd = false;
+    for (int i = 0; i < 4; ++i) {
+        const float q1 = a[i] * D.r;
+        q[i] = fmaf(fmaf(-D.d, q1, a[i]), D.r, q1);
+        const float m = fabsf(q[i]);
+        odd = odd || (!(m > 0x1p-100f && m < 0x1p100f) && a[i] != 0.f);
+    }
+    if (__builtin_amdgcn_ballot_w64(odd) == 0ull) return;
+#endif
+    for (int i = 0; i < 4; ++i) q[i] = sx_div(a[i], D);
+}
+
 // Division by a denominator that changes every step (1 + hp*tanh, the two quotients inside tanh).  hipcc expands
 // a/b into the 11-instruction IEEE sequence (two v_div_scale, v_rcp, four fma, v_div_fmas, v_div_fixup); the
 // operands here are always in the normal range, so the same Markstein correction as sx_div works on a reciprocal
@@ -136,9 +151,6 @@ SX_HD float sx_div(float a, const SxDiv& D) {
 // boundary, and then q is the correctly rounded quotient.  6 instructions; mismatches against a/b are counted on
 // the device by smashx_selftest_math (tests/test_gpu_parity.py: < 1e-6 of calls, 1 ulp).
 SX_HD float sx_fdiv(float a, float b) {
-#if defined(SX_ABL_DIV) && defined(__HIP_DEVICE_COMPILE__)
-    return a * __builtin_amdgcn_rcpf(b);      // timing-only build
-#endif
 #if defined(__HIP_DEVICE_COMPILE__) && !SX_EXACT_LIBM
     float r = __builtin_amdgcn_rcpf(b);
     r = fmaf(fmaf(-b, r, 1.0f), r, r);
@@ -198,14 +210,6 @@ SX_HD double sx_sqrt_d(float h) {
     return fma(e, 0.5 * r, s);
 }
 
-#if defined(SX_ABL_POW) && defined(__HIP_DEVICE_COMPILE__)      // timing-only build: fp32 hardware seeds, no fp64 refinement
-SX_HD float sx_pow_m4(float x) { const float u = __builtin_amdgcn_rcpf(x), u2 = u * u; return u2 * u2; }
-SX_HD void sx_pow_m4_m5(float x, float* m4, float* m5) { const float u = __builtin_amdgcn_rcpf(x), u2 = u * u, u4 = u2 * u2; *m4 = u4; *m5 = u4 * u; }
-SX_HD float sx_pow_m025(float y) { return __builtin_amdgcn_rsqf(__builtin_amdgcn_sqrtf(y)); }
-SX_HD void sx_pow_m025_m125(float y, float* a, float* b) { const float r = __builtin_amdgcn_rsqf(__builtin_amdgcn_sqrtf(y)), r2 = r * r; *a = r; *b = r2 * r2 * r; }
-SX_HD float sx_pow_3p5(float h) { return h * h * h * __builtin_amdgcn_sqrtf(h); }
-SX_HD void sx_pow_3p5_2p5(float h, float* a, float* b) { const float s = __builtin_amdgcn_sqrtf(h), d2 = h * h; *a = d2 * h * s; *b = d2 * s; }
-#else
 // powf(x, -4), powf(x, -5)   [x > 0]   (gr_transfer, md_gr_operator.f90:94-106; GR_TRANSFER_B forward_db.f90:6349-6368)
 SX_HD float sx_pow_m4(float x) { const double u = sx_rcp_d(x); const double u2 = u * u; return (float)(u2 * u2); }
 SX_HD void sx_pow_m4_m5(float x, float* m4, float* m5) {
@@ -229,7 +233,6 @@ SX_HD void sx_pow_3p5_2p5(float h, float* p35, float* p25) {
     *p35 = (float)((d2 * d) * s); *p25 = (float)(d2 * s);
 }
 
-#endif   // SX_ABL_POW
 // expf: fp64 evaluation, one rounding (glibc's float version is correctly rounded in 99.94 %)
 SX_HD float sx_expf(float x) { return (float)exp((double)x); }
 
@@ -411,9 +414,6 @@ SX_HD float sx_expm1f(float x) {
 }
 
 SX_HD float sx_tanhf(float x, const bool fast = true) {      // fast = false: the branchy restatement only (device self-test)
-#if defined(SX_ABL_TANH) && defined(__HIP_DEVICE_COMPILE__)
-    { const float e = __builtin_amdgcn_exp2f(2.885390082f * x); return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f); }   // timing-only build
-#endif
     const uint32_t jx = sx_f2u(x), ix = jx & 0x7fffffffu;
     float t, z;
 #if defined(__HIP_DEVICE_COMPILE__) && SX_TANH_FAST

@@ -16,22 +16,11 @@
 #define SX_DEV __device__ __forceinline__
 
 // Conditions that are nearly always the same on all 64 lanes (rain or no rain, day or night, a data gap) can be tested per WAVEFRONT:
-// a ballot and a scalar branch, the body runs for every lane and a select keeps what the lane's own condition says -- same results by
-// construction.  It pays where a body is a nest of per-lane branches (sx_tanhf's straight-line path, sx_math.h: vert_fwd -7 %, vert_adj
-// -3.5 %; the still steps below) and does NOT pay for the single-level branches of the operators here (measured at 1024^2 x 8760, bit
-// mask SX_WAVE_BRANCH: none 63.0-63.4 ms of vert_adj, production 63.8, production + transfer 63.9, production_b 64.6, all 66.8 -- the
-// selects cost registers, 10 -> 16 spilled): default 0, the per-lane form.  What did pay in the same pass: plain selects instead of
-// the small divergent branches (1e-6 < ht_try in sx_transfer_b, pr, the day branch of sx_production_b): 66.4 -> 64.4 ms.
-#ifndef SX_WAVE_BRANCH
-#define SX_WAVE_BRANCH 0
-#endif
+// a ballot and a scalar branch.  It pays where a body is a nest of per-lane branches (sx_tanhf's straight-line path, sx_math.h; the still
+// steps below) and does NOT pay for the single-level branches of the operators here (measured in round 3, DESIGN.md 12: the selects
+// cost registers), which keep the per-lane form.
 SX_DEV bool sx_wave_all(bool pred) { return __builtin_amdgcn_ballot_w64(!pred) == 0ull; }   // over the active lanes
 SX_DEV bool sx_wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
-#define SX_ANY_IF(bit, c) (((SX_WAVE_BRANCH) >> (bit)) & 1 ? sx_wave_any(c) : (c))
-#define SX_ANY_P(c) SX_ANY_IF(0, c)      // sx_production_full
-#define SX_ANY_T(c) SX_ANY_IF(1, c)      // sx_transfer (gap)
-#define SX_ANY_B(c) SX_ANY_IF(2, c)      // sx_production_b
-#define SX_ANY_G(c) SX_ANY_IF(3, c)      // sx_transfer_b (gap)
 
 struct SxCellParams {   // time-invariant per cell, hoisted out of the time loop
     float ci, cp, inv_cp, cft, cst, exc;
@@ -64,12 +53,12 @@ SX_DEV SxProd sx_production_full(float pn, float en, float cp, float inv_cp, flo
     // is (+-0)/1: skip the division too (dry steps: 90 %; nights: 45 %)
     R.thp = 0.f; R.the = 0.f; R.ps = 0.f; R.es = 0.f;
     const bool wp = pn > 0.f, we = en > 0.f;
-    if (SX_ANY_P(wp)) {
+    if (wp) {
         const float t = sx_tanhf(pn * inv_cp);
         const float q = sx_fdiv(cp * (1.f - hp * hp) * t, 1.f + hp * t);
         R.thp = wp ? t : 0.f; R.ps = wp ? q : 0.f;
     }
-    if (SX_ANY_P(we)) {
+    if (we) {
         const float t = sx_tanhf(en * inv_cp);
         const float q = sx_fdiv((hp * cp) * (2.f - hp) * t, 1.f + (1.f - hp) * t);
         R.the = we ? t : 0.f; R.es = we ? q : 0.f;
@@ -80,7 +69,7 @@ SX_DEV SxProd sx_production_full(float pn, float en, float cp, float inv_cp, flo
     // neither the division nor the power
     R.pwr1 = 1.f; R.pw125 = 1.f;
     const bool big = !(fabsf(R.hp_imd) < 15.f);
-    if (SX_ANY_P(big)) {
+    if (big) {
         if (big) {
             const float r = sx_div(R.hp_imd, dbeta);
             const float r2 = r * r;
@@ -104,7 +93,7 @@ SX_DEV void sx_production(float pn, float en, float cp, float inv_cp, float& hp,
 SX_DEV void sx_transfer(float prcp, float pr, float ct, const SxDiv& dct, float ct_m4, float& ht, float& q) {
     float pr_imd = pr;
     const bool gap = prcp < 0.f;
-    if (SX_ANY_T(gap)) {   // data gap: closed-form inverse (md_gr_operator.f90:94-96)
+    if (gap) {   // data gap: closed-form inverse (md_gr_operator.f90:94-96)
         if (gap) pr_imd = sx_pow_m025(sx_pow_m4(ht * ct) - ct_m4) - (ht * ct);
     }
     const float ht_imd = fmaxf(1.e-6f, ht + sx_div(pr_imd, dct));
@@ -207,7 +196,7 @@ SX_DEV void sx_production_b(const SxProd& R, float pn, float& pn_b, float en, fl
     const bool wp = pn > 0.f;
     hp_b = 0.f;
     pn_b = 0.f;
-    if (SX_ANY_B(wp)) {
+    if (wp) {
         if (wp) {
             pn_b = pr_b;
             hp_imd_b = hp_imd_b - cp * pr_b;
@@ -220,7 +209,7 @@ SX_DEV void sx_production_b(const SxProd& R, float pn, float& pn_b, float en, fl
     float temp0 = hp * cp * (-hp + 2.f);
     float temp_b, temp_b0, temp_b4, temp_b5;
     const bool we = en > 0.f;
-    if (SX_ANY_B(we)) {
+    if (we) {
         // day: the general form on every lane, the lane's own test selects (a lane with en = 0 has the = 0: same values as below up
         // to the sign of a zero, but the select keeps it to the letter)
         const float temp4 = the, temp1 = the;
@@ -245,7 +234,7 @@ SX_DEV void sx_production_b(const SxProd& R, float pn, float& pn_b, float en, fl
     }
     float temp_b2;
     const float temp2 = cp * (-(hp * hp) + 1.f);
-    if (SX_ANY_B(wp)) {
+    if (wp) {
         if (wp) {
             const float temp = thp, temp1 = thp;
             const SxDiv d0 = sx_mkdiv_fast(hp * temp + 1.f);
@@ -277,7 +266,7 @@ SX_DEV void sx_transfer_b(float prcp, float pr, float& pr_b, float ct, const SxD
                           float ct_m5, float& ct_b, float ht, float& ht_b, float q_b) {
     float pr_imd = pr, g_pwx1 = 0.f, g_pwx3 = 0.f;
     const bool gap = prcp < 0.f;
-    const bool any_gap = SX_ANY_G(gap);
+    const bool any_gap = gap;
     if (any_gap) {
         if (gap) {
             g_pwx1 = ht * ct;

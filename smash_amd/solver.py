@@ -73,6 +73,12 @@ class Comm:
         _lib.check(_lib.lib().smashx_comm_allreduce_sum(self.handle, _ptr(v), int(v.size)))
         return v
 
+    def info(self):
+        """{nranks, version}: what the communicator itself reports (ncclCommCount, ncclGetVersion)."""
+        n, v = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().smashx_comm_info(self.handle, C.byref(n), C.byref(v)))
+        return {"nranks": n.value, "version": v.value}
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.lib().smashx_comm_destroy(self.handle)

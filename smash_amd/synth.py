@@ -205,6 +205,61 @@ def make_mesh_d8(nrow: int, ncol: int, ng: int = 3, dx: float = 1000.0, seed: in
     return Mesh(nrow, ncol, dx, flwdir, flwacc, path, active, gauge_pos, area)
 
 
+def make_mesh_france(which="all", ng: int = 8, fixture: str | None = None) -> Mesh:
+    """A REAL river network: the reference's 1-km D8 raster of France (all eight codes, 957 k cells with a direction, hundreds of
+    coastal and border outlets), from the data fixture tests/golden/mesh/france_d8.npz (tests/golden/make_france_d8.py).
+    which = "all": every cell of the raster that has a direction is active (a forest of basins); an integer K: the K largest basins
+    (by cells draining through their outlets), cropped to their bounding box -- K = 1 is the Loire.  Mesh fields by the rules of the
+    reference's generator (smash/mesh/meshing.py:216-297, mw_meshing.f90:204-233: flow accumulation, path = ascending accumulation);
+    gauges: the ng cells with the largest accumulation, kept apart (pick_gauges)."""
+    import os
+    if fixture is None:
+        fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "mesh", "france_d8.npz")
+    z = np.load(fixture)
+    fd = z["flwdir"].astype(np.int32)
+    dx = float(z["dx"])
+    nrow, ncol = fd.shape
+    act = fd > 0
+    n = nrow * ncol
+
+    def outlets(a):
+        ds, _ = downstream_index(np.where(a, fd, -99), a.astype(np.int32))
+        root = np.where(ds >= 0, ds, np.arange(n))
+        for _ in range(24):                              # pointer doubling: every cell learns where its water ends up
+            root = root[root]
+        return ds, root
+    # The raster holds a few closed loops (pairs of cells that point at each other in flat or endorheic spots: mw_meshing.f90:183 stops
+    # the accumulation there).  A catchment delineated from an outlet never contains one; on the whole raster they are taken out of the
+    # mask, so that what drained into them ends in an inactive cell like water that reaches the sea.
+    r = np.arange(nrow, dtype=np.int64)[:, None] + DROW[np.where(act, fd - 1, 0)]
+    c = np.arange(ncol, dtype=np.int64)[None, :] + DCOL[np.where(act, fd - 1, 0)]
+    inside = act & (r >= 0) & (r < nrow) & (c >= 0) & (c < ncol)
+    raw = np.where(inside, np.where(inside, r, 0) * ncol + np.where(inside, c, 0), -1).reshape(-1)
+    raw = np.where((raw >= 0) & act.reshape(-1)[np.maximum(raw, 0)], raw, -1)
+    jump = np.where(raw >= 0, raw, np.arange(n))
+    for _ in range(24):
+        jump = jump[jump]
+    img = np.unique(jump[act.reshape(-1)])
+    loop = img[raw[img] >= 0]                            # images of f^(2^24) that still have a downstream cell: the cells on loops
+    act.reshape(-1)[loop] = False
+    if which != "all":
+        ds, root = outlets(act)
+        flat = act.reshape(-1)
+        sizes = np.bincount(root[flat], minlength=n)
+        keep = np.argsort(-sizes, kind="stable")[: int(which)]
+        act = (np.isin(root, keep) & flat).reshape(nrow, ncol)
+        rr, cc = np.flatnonzero(act.any(axis=1)), np.flatnonzero(act.any(axis=0))
+        fd, act = fd[rr[0]: rr[-1] + 1, cc[0]: cc[-1] + 1], act[rr[0]: rr[-1] + 1, cc[0]: cc[-1] + 1]
+        nrow, ncol = fd.shape
+    active = np.asfortranarray(act.astype(np.int32))
+    flwdir = np.asfortranarray(np.where(act, fd, -99).astype(np.int32))
+    flwacc = flow_accumulation(flwdir, active)
+    path = make_path(np.where(active == 1, flwacc, -99))
+    gauge_pos = pick_gauges(np.where(active == 1, flwacc, -1), ng)
+    area = np.array([float(flwacc[a, b]) * dx * dx for a, b in gauge_pos], dtype=np.float32)
+    return Mesh(nrow, ncol, dx, flwdir, flwacc, path, active, gauge_pos, area)
+
+
 # ----------------------------------------------------------------------------------------------
 # forcing (integer construction; identical under numpy and torch)
 # ----------------------------------------------------------------------------------------------

@@ -44,8 +44,6 @@ class Loopback:
                 t0_, data = self.box[(p, self.rank, kind)].get(timeout=120)
                 assert t0_ == t0 and data.shape == (len(ix), w)
                 view[ixt] = data
-        # this stream only: a device-wide synchronize would also wait for a persistent routing launch (SMASHX_PERSIST=1) whose gate the
-        # host opens after this callback returns
         torch.cuda.current_stream().synchronize()
         return 0
 

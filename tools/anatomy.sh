@@ -2,7 +2,9 @@
 # Timing-only builds of libsmashx (results void, timings valid): what each ingredient of the kernels costs.
 #   here (container):   tools/anatomy.sh build                  -> variants/lib_<name>.so  (git-ignored, travels with gpurun)
 #   on the GPU box:     tools/anatomy.sh run [names...]          -> gpurun_out/anatomy_<name>.json (+ per-round routing traces)
-# Switches: smash_amd/csrc/sx_kernels.h (routing super-step), smash_amd/csrc/sx_math.h (faithful arithmetic).
+# Switches: the timing-only ones (SX_ABL_*: one ingredient of a kernel removed, results void) and SX_WAVE_BRANCH are NOT in the product
+# sources (round 4): `build` compiles from a scratch copy of smash_amd/csrc with tools/anatomy/timing_switches.patch applied (the patch
+# re-adds them to sx_kernels.h, sx_math.h and sx_ops.h; regenerate it with `diff -u` if those files move under it).
 # Numbers quoted in DESIGN.md 12 and profiles/r2_routing_anatomy*.json come from this.  The round-3 switches (still0, tanh0, wb15, onesub,
 # exact_*: valid results, different instruction streams) are compared on one box with tools/ab_variants.sh.
 set -u
@@ -19,9 +21,11 @@ case "${1:-}" in
 build)
   mkdir -p variants
   F="-O3 -ffp-contract=off --offload-arch=gfx950 -fPIC -shared -std=c++17"
+  W=$(mktemp -d); cp -r smash_amd include "$W"/
+  (cd "$W" && patch -p1 -s < "$OLDPWD/tools/anatomy/timing_switches.patch") || { echo "timing_switches.patch does not apply"; exit 1; }
   n=0
   for k in "${!V[@]}"; do
-    /opt/rocm/bin/hipcc $F ${V[$k]} -o variants/lib_$k.so smash_amd/csrc/smashx.hip smash_amd/csrc/sx_plan.cpp smash_amd/csrc/sx_lbfgsb.cpp -pthread -ldl 2>/dev/null &
+    /opt/rocm/bin/hipcc $F ${V[$k]} -o variants/lib_$k.so "$W"/smash_amd/csrc/smashx.hip "$W"/smash_amd/csrc/sx_plan.cpp "$W"/smash_amd/csrc/sx_lbfgsb.cpp -pthread -ldl 2>/dev/null &
     n=$((n+1)); if [ $((n % 4)) -eq 0 ]; then wait; fi
   done
   wait; ls variants/*.so ;;

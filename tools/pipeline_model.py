@@ -80,7 +80,11 @@ def ramp_schedule(T, pipe, ramp):
     return [v for v in out if v > 0]
 
 
-SCHEDULE = {"ramp": 1}
+SCHEDULE = {"ramp": 1, "keep_inlets": True}
+# keep_inlets (round 4): a rank keeps the inlet series it received for a storage chunk in the first pass, so the recomputation of that
+# chunk in the reverse sweep waits for no neighbour and sends nothing (smashx.hip, inlet_series); False = round 3's sweep, which
+# exchanged the series again.  Also round 4: the V stream waits for the R stream sub-chunk by sub-chunk between storage chunks
+# (buf_free), not for the whole stream.
 
 
 def build(N, tile, nt, chunk, pipe, graph, lat, delta):
@@ -121,25 +125,28 @@ def build(N, tile, nt, chunk, pipe, graph, lat, delta):
 
     pid = 0
     for c in range(nch):
-        _forward(pid, c, c == nch - 1, order_f, N, graph, subs, add, book, cells, P, delta, last, r0_scale)
+        _forward(pid, c, c == nch - 1, order_f, N, graph, subs, add, book, cells, P, delta, last, r0_scale, True, c > 0)
         pid += 1
     for c in range(nch - 1, -1, -1):
         if c < nch - 1:
-            _forward(pid, c, True, order_f, N, graph, subs, add, book, cells, P, delta, last, r0_scale)
+            _forward(pid, c, True, order_f, N, graph, subs, add, book, cells, P, delta, last, r0_scale, not SCHEDULE["keep_inlets"], False)
             pid += 1
         _reverse(pid, c, order_b, N, down, subs, add, book, cells, P, delta, r0_scale)
         pid += 1
     return tasks
 
 
-def _forward(pid, c, taped, order, N, graph, subs, add, book, cells, P, delta, last, r0_scale):
+def _forward(pid, c, taped, order, N, graph, subs, add, book, cells, P, delta, last, r0_scale, exchange, after_forward):
+    """exchange: the inlet series come from the upstream ranks (False: kept from the first pass); after_forward: the previous pass over
+    the chunk buffers was a forward pass, whose routing of sub-chunk j must have finished before V(j) overwrites its part."""
     for r in order:
         vs = []
         for j, T in enumerate(subs(c)):
             w = RATES["vf_t" if taped else "vf_u"] * cells * T / CS
-            vs.append(add(f"Vf{pid}.{j}", r, "V", w, 1.0, deps=[last.get((r, "R"))] if j == 0 else ()))
+            prev = book.get(("CHf", r, pid - 1, j)) if after_forward else None
+            vs.append(add(f"Vf{pid}.{j}", r, "V", w, 1.0, deps=[prev] if prev is not None else ()))
         for j, T in enumerate(subs(c)):
-            up = [book[("CHf", s, pid, j)] for s in graph[r]]
+            up = [book[("CHf", s, pid, j)] for s in graph[r]] if exchange else []
             add(f"R0f{pid}.{j}", r, "R", RATES["r0f_t" if taped else "r0f_u"] * cells * T / CS * r0_scale(T), 1.0, deps=[vs[j]], lat_deps=up)
             book[("CHf", r, pid, j)] = add(f"CHf{pid}.{j}", r, "R", (T / 4.0 + P) * RATES["tau_f"], delta)
 
