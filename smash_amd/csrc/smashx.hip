@@ -341,25 +341,15 @@ struct smashx_plan {
     std::vector<float> wgauge;
     hipStream_t stream = nullptr;    // vertical kernels, uploads/downloads ("V stream")
     hipStream_t stream_r = nullptr;  // routing + cost kernels ("R stream"); overlaps the V stream chunk by chunk
-    hipStream_t stream_c = nullptr;  // the chained routing launches when they run beside the R stream (chain_stream)
     int Tp = 0;                      // pipeline sub-chunk length inside a storage chunk
     bool hi_tape = true;             // gr-b / gr-c: full tape of the interception level (false: sparse checkpoints, rebuilt in the reverse kernel)
-    int Tpa = 0;                     // ... of the reverse sweep (routing adjoint of sub-chunk j-1 under the vertical adjoint of j)
     int chain_from = 1;              // first chained round
-    bool split_v = false;            // SMASHX_SPLIT_V=1: vertical kernels in two cell ranges so that routing round 0 overlaps the second.
-                                     // Measured slower (185 vs 175 ms at 1024^2 x 8760: both kernels lose more than the overlap hides): off.
-    size_t vlds_fwd = 0, vlds_adj = 0;   // bytes of unused dynamic LDS per vertical workgroup: caps the resident vertical workgroups of a compute unit so
-                                     // that a routing group finds registers beside them (SMASHX_VLDS_FWD / _ADJ; SMASHX_DEBUG_VLDS sets both)
+    size_t vlds_fwd = 0, vlds_adj = 0;   // experiments only (SMASHX_DEBUG_VLDS = n or nfwd,nadj): bytes of unused dynamic LDS per vertical workgroup, which
+                                     // caps the vertical workgroups resident on a compute unit (occupancy experiments)
     std::vector<hipEvent_t> buf_free;    // per pipeline sub-chunk: the R stream has finished with this part of the chunk buffers
-    int n0 = 0;                      // cells of the round-0 groups = [0, n0) in device order
     std::vector<double> round_ncells;  // cells per routing round
     bool chain_used = false;         // a chained launch ran in the current sweep: check the stall flag afterwards
     bool chain = true;               // all routing rounds in one launch (progress counters), see sx_kernels.h
-    bool plain_rows = false;         // the running sweep keeps every series in its plain rows (tangent sweeps)
-    bool chain_stage = true;         // staging rows for the chained groups (sx_kernels.h, sx_k_chain_gather); SMASHX_CHAIN_STAGE=0: plain rows (A/B)
-    int chain_rows_extra = 0;        // deepest chained group: rows of the staging array beyond the time blocks
-    bool chain_stream = false;       // the chained launches of the pipeline sub-chunks on their own stream (stream_c): round 0 of sub-chunk j + 1 does not
-                                     // queue behind the latency-bound chained rounds of sub-chunk j (single domain only)
     // tile boundary exchange
     int n_out = 0, n_in = 0;
     int *d_out_x = nullptr, *d_in_x = nullptr;
@@ -509,8 +499,7 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
             size_t fr = 0, tot = 0;
             HIPCHK(hipMemGetInfo(&fr, &tot));
             const double avail = (double)fr * 0.85 - 1.0e9;
-            // floats per time step: qt, hr_imd and the taped levels of every cell, the exchange series, the staging rows of the chained groups
-            auto fit = [&](double nt_) { return (long)(avail / (4.0 * ((double)p->npad * (2 + nt_) + (double)std::max(p->sch.nxslots, 1) + (double)p->A.ncs))) / 16 * 16; };
+            auto fit = [&](double nt_) { return (long)(avail / (4.0 * ((double)p->npad * (2 + nt_) + (double)std::max(p->sch.nxslots, 1)))) / 16 * 16; };
             long t = fit(ntape_full);
             if (has_hi && t < nt16) {
                 // Dropping the hi tape costs the reverse kernel ~14 % (levels rebuilt block by block: 78.5 against 69 ms per 9.2e9
@@ -542,18 +531,10 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
             int want = p->cfg.pipe_steps > 0 ? p->cfg.pipe_steps : Tc;
             const int nsub = std::max(1, (Tc + want / 2) / want);
             p->Tp = std::min(Tc, ((Tc + nsub - 1) / nsub + 15) / 16 * 16);
-            p->Tpa = p->Tp;
-            if (const char* e = getenv("SMASHX_PIPE_ADJ")) {
-                const int wa = atoi(e);
-                if (wa > 0 && !p->tiled) { const int na = std::max(1, (Tc + wa / 2) / wa); p->Tpa = std::min(Tc, ((Tc + na - 1) / na + 15) / 16 * 16); }
-            }
         }
         int rc;
         if ((rc = p->dmalloc(&p->A.qtT, (size_t)p->npad * Tc))) return rc;
         if ((rc = p->dmalloc(&p->A.xT, (size_t)std::max(p->sch.nxslots, 1) * Tc))) return rc;
-        if (p->A.ncs > 0) {       // staging rows of the chained groups: [Tc / 4 + deepest chained group + 1][ncs] float4
-            if ((rc = p->dmalloc(&p->A.qsk, (size_t)p->A.ncs * 4 * ((size_t)Tc / 4 + p->chain_rows_extra + 1)))) return rc;
-        }
         HIPCHK(hipMemsetAsync(p->A.qtT, 0, (size_t)p->npad * Tc * 4, p->stream));
         HIPCHK(hipMemsetAsync(p->A.xT, 0, (size_t)std::max(p->sch.nxslots, 1) * Tc * 4, p->stream));
         p->chunk_ready = true;
@@ -593,7 +574,6 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
     return 0;
 }
 
-int chain_first(const smashx_plan* p);
 // view of the chunk buffers shifted to local step `off` (multiple of 4) of the current storage chunk
 SxDeviceArrays view_at(const smashx_plan* p, int off) {
     SxDeviceArrays B = p->A;
@@ -601,8 +581,6 @@ SxDeviceArrays view_at(const smashx_plan* p, int off) {
     const size_t q = (size_t)(off / 4);
     B.qtT = p->A.qtT + q * p->npad * 4;
     if (p->A.hrT) B.hrT = p->A.hrT + q * p->npad * 4;
-    // staging rows of the chained groups: only while chained launches run (the launch-per-round fallback and the tangent sweep use the plain rows)
-    B.qsk = (p->A.qsk && chain_first(p) < p->sch.nrounds && !p->dom_q_active && !p->plain_rows) ? p->A.qsk + q * (size_t)p->A.ncs * 4 : nullptr;
     if (p->A.qdT) B.qdT = p->A.qdT + q * p->npad * 4;
     B.xT = p->A.xT + q * p->A.nx * 4;
     if (p->A.qtdT) B.qtdT = p->A.qtdT + q * p->npad * 4;      // tangent sweep (smashx_forward_d)
@@ -686,13 +664,12 @@ void reset_chain_counters(smashx_plan* p, hipStream_t st) {
     (void)hipMemsetAsync(p->A.prog + p->sch.ngroups + 1, 0, sizeof(int), st);
 }
 // the un-chained rounds [0, chain_first) of one forward pass over [t0, t0 + T): one launch per round on stream st
-void route_fwd_rounds(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st, hipEvent_t wait_rest = nullptr) {
+void route_fwd_rounds(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st) {
     SxDeviceArrays B = view_at(p, off);
     if (!p->dom_q_active) B.qdT = nullptr;
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
     const int cf = chain_first(p);
     for (int r = 0; r < cf; ++r) {
-        if (r == 1 && wait_rest) (void)hipStreamWaitEvent(st, wait_rest, 0);
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
         p->mark_begin(1, st, round_cells(p, r, r + 1) * T);
         if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T);
@@ -701,14 +678,13 @@ void route_fwd_rounds(smashx_plan* p, int off, bool tape, int t0, int T, hipStre
     }
 }
 // the chained rounds in ONE launch (tickets: sx_kernels.h)
-void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st, hipEvent_t wait_rest = nullptr) {
+void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st) {
     const int nr = p->sch.nrounds, cf = chain_first(p);
     if (cf >= nr) return;
     SxDeviceArrays B = view_at(p, off);
     if (!p->dom_q_active) B.qdT = nullptr;
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
     const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
-    if (cf <= 1 && wait_rest) (void)hipStreamWaitEvent(st, wait_rest, 0);
     reset_chain_counters(p, st);
     const int grid = g1 - g0;
     p->mark_begin(5, st, round_cells(p, cf, nr) * T);
@@ -720,10 +696,9 @@ void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStr
 // Routing launches of one pass.  Rounds below chain_first keep one launch per round (they are wide and
 // HBM-bound); the narrow, latency-bound rounds from there on run chained inside a single launch
 // (sx_kernels.h "rounds chained inside one launch"), which turns their sum into roughly the longest of them.
-// wait_rest: event the launches after round 0 have to wait for (the vertical kernel of the cells outside round 0)
-void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T, hipEvent_t wait_rest = nullptr) {
-    route_fwd_rounds(p, off, tape, t0, T, p->stream_r, wait_rest);
-    route_fwd_chained(p, off, tape, t0, T, p->stream_r, wait_rest);
+void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
+    route_fwd_rounds(p, off, tape, t0, T, p->stream_r);
+    route_fwd_chained(p, off, tape, t0, T, p->stream_r);
 }
 void route_adj_chained(smashx_plan* p, int off, int t0, int T, hipStream_t st) {
     const int nr = p->sch.nrounds, cf = chain_first(p);
@@ -738,23 +713,20 @@ void route_adj_chained(smashx_plan* p, int off, int t0, int T, hipStream_t st) {
     p->mark_end();
     p->chain_used = true;
 }
-// after_rest: recorded once every round but round 0 has run (their cells' qt_b is final)
-void route_adj_rounds(smashx_plan* p, int off, int t0, int T, hipStream_t st, hipEvent_t after_rest = nullptr) {
+void route_adj_rounds(smashx_plan* p, int off, int t0, int T, hipStream_t st) {
     const SxDeviceArrays B = view_at(p, off);
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
     const int cf = chain_first(p);
-    if (cf <= 1 && after_rest) (void)hipEventRecord(after_rest, st);
     for (int r = cf - 1; r >= 0; --r) {
-        if (r == 0 && cf > 1 && after_rest) (void)hipEventRecord(after_rest, st);
         const int g0 = p->sch.round_group_begin[r], ngr = p->sch.round_group_begin[r + 1] - g0;
         p->mark_begin(2, st, round_cells(p, r, r + 1) * T);
         hipLaunchKernelGGL((sx_k_route_adj<false>), dim3(ngr), dim3(p->M), lds, st, B, g0, g0 + ngr, t0, T);
         p->mark_end();
     }
 }
-void route_adj(smashx_plan* p, int off, int t0, int T, hipEvent_t after_rest = nullptr) {
+void route_adj(smashx_plan* p, int off, int t0, int T) {
     route_adj_chained(p, off, t0, T, p->stream_r);
-    route_adj_rounds(p, off, t0, T, p->stream_r, after_rest);
+    route_adj_rounds(p, off, t0, T, p->stream_r);
 }
 
 SxCostArgs cost_args(smashx_plan* p, float jobs_b) {
@@ -864,7 +836,6 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
     if (hipStreamCreate(&p->stream) != hipSuccess || hipStreamCreate(&p->stream_r) != hipSuccess) { delete p; return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
     (void)hipEventCreate(&p->ev0); (void)hipEventCreate(&p->ev1);
     if (hipStreamCreate(&p->stream_j) != hipSuccess || hipEventCreate(&p->ev_j) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
-    if (hipStreamCreateWithFlags(&p->stream_c, hipStreamNonBlocking) != hipSuccess) { smashx_plan_destroy(p); return fail(SMASHX_E_HIP, "hipStreamCreate failed"); }
     SxDeviceArrays& A = p->A;
     A.n = p->n; A.npad = p->npad; A.nt = p->nt; A.dt = cfg->dt; A.dx = cfg->dx; A.Tc = 0;
     if (getenv("SMASHX_VERBOSE"))
@@ -899,50 +870,16 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         A.ngroups = p->sch.ngroups;
         const char* e = getenv("SMASHX_CHAIN_ROUNDS");
         p->chain = !(e && e[0] == '0');
-        if (const char* dv = getenv("SMASHX_DEBUG_VLDS")) p->vlds_fwd = p->vlds_adj = (size_t)std::max(0, atoi(dv));
-        if (const char* cs = getenv("SMASHX_CHAIN_STREAM")) p->chain_stream = atoi(cs) != 0;
-        if (const char* cs = getenv("SMASHX_CHAIN_STAGE")) p->chain_stage = atoi(cs) != 0;
-        if (const char* dv = getenv("SMASHX_VLDS_FWD")) p->vlds_fwd = (size_t)std::max(0, atoi(dv));
-        if (const char* dv = getenv("SMASHX_VLDS_ADJ")) p->vlds_adj = (size_t)std::max(0, atoi(dv));
-        const char* sv = getenv("SMASHX_SPLIT_V");
-        p->split_v = sv && sv[0] == '1';
+        if (const char* dv = getenv("SMASHX_DEBUG_VLDS")) {       // "n" or "nfwd,nadj"
+            p->vlds_fwd = p->vlds_adj = (size_t)std::max(0, atoi(dv));
+            if (const char* c2 = strchr(dv, ',')) p->vlds_adj = (size_t)std::max(0, atoi(c2 + 1));
+        }
         p->round_ncells.assign(p->sch.nrounds, 0.0);
         for (int r = 0; r < p->sch.nrounds; ++r)
             for (int g = p->sch.round_group_begin[r]; g < p->sch.round_group_begin[r + 1]; ++g)
                 for (int q = p->sch.g_slot_begin[g]; q < p->sch.g_slot_begin[g + 1]; ++q) p->round_ncells[r] += p->sch.s_cell[q] >= 0;
-        p->n0 = (int)p->round_ncells[0];
         const char* cfm = getenv("SMASHX_CHAIN_FROM");
         p->chain_from = cfm ? std::max(0, atoi(cfm)) : 1;
-        {   // staging rows of the chained groups (sx_kernels.h): where every cell of a chained group keeps its qt / qt_b, and every series that
-            // a round below the chain hands to a chained group, as an offset in float4 = stage x ncs + slot (row = time block + stage)
-            A.qsk = nullptr; A.ncs = 0; A.k_stg = nullptr; A.x_stg = nullptr;
-            const int cf = chain_first(p);
-            if (p->chain_stage && cf < p->sch.nrounds) {
-                const int gc = p->sch.round_group_begin[cf];
-                const int cs0 = p->sch.g_slot_begin[gc];
-                const int ncs = p->sch.nslots - cs0;
-                std::vector<unsigned> ks((size_t)p->npad, 0xffffffffu);
-                std::vector<int> xs((size_t)std::max(p->sch.nxslots, 1), -1);
-                double worst = 0.0;
-                for (int g = gc; g < p->sch.ngroups; ++g) {
-                    p->chain_rows_extra = std::max(p->chain_rows_extra, p->sch.g_dmax[g]);
-                    for (int q = p->sch.g_slot_begin[g]; q < p->sch.g_slot_begin[g + 1]; ++q) {
-                        const int c = p->sch.s_cell[q];
-                        if (c == INT_MIN) continue;
-                        const double o = (double)p->sch.s_stage[q] * ncs + (q - cs0);
-                        worst = std::max(worst, o);
-                        if (c >= 0) ks[c] = (unsigned)o;
-                        else { const int x = -1 - c; const int pg = p->sch.x_prod_group[x]; if (pg >= 0 && pg < gc) xs[x] = (int)o; }
-                    }
-                }
-                if (worst * 16.0 < 4.0e9 && worst < 2.0e9) {      // (the kernels address a row's lanes with 32-bit byte offsets)
-                    A.ncs = ncs;
-                    unsigned* dk; int* dx;
-                    TRY(p->upload_vec(&dk, ks)); A.k_stg = dk;
-                    TRY(p->upload_vec(&dx, xs)); A.x_stg = dx;
-                }
-            }
-        }
         A.spin_limit = SX_SPIN_LIMIT; A.mute_group = -1;
         if (const char* sl = getenv("SMASHX_SPIN_LIMIT")) A.spin_limit = std::max(1, atoi(sl));
         if (const char* mg = getenv("SMASHX_DEBUG_MUTE_GROUP")) A.mute_group = atoi(mg);     // tests of the stall path only
@@ -1038,7 +975,6 @@ int smashx_plan_destroy(smashx_plan* p) {
     if (p->stream) (void)hipStreamDestroy(p->stream);
     if (p->stream_r) (void)hipStreamDestroy(p->stream_r);
     if (p->stream_j) { (void)hipStreamSynchronize(p->stream_j); (void)hipStreamDestroy(p->stream_j); }
-    if (p->stream_c) { (void)hipStreamSynchronize(p->stream_c); (void)hipStreamDestroy(p->stream_c); }
     if (p->ev_j) (void)hipEventDestroy(p->ev_j);
     delete p;
     return 0;
@@ -1513,8 +1449,6 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     const bool halo = (p->halo_fn || native) && (p->n_out > 0 || p->n_in > 0);
     auto halo_move = [&](bool pack, bool out_edges, int off, int T, hipStream_t st) { sx_halo_move(p, native, p->A.xT, pack, out_edges, off, T, st); };
     auto hook = [&](int phase, int t0, int T, hipStream_t st) -> int { return sx_halo_hook(p, native, phase, t0, T, st); };
-    const bool split = p->split_v && !halo && p->sch.nrounds > 1 && p->n0 > 0 && p->n0 < p->n;
-    const bool cstream = p->chain_stream && !halo && !split && chain_first(p) < p->sch.nrounds;
     // Recomputation of a storage chunk (reverse sweep) needs no neighbour: the inlet series a rank received for that chunk in the first
     // pass are kept (n_in edges x Tc steps x 4 B per chunk) and unpacked again, and nothing is sent -- the ranks downstream kept theirs.
     // A sweep then changes direction twice between the ranks (forward -> reverse) instead of twice per recomputed chunk more.
@@ -1543,22 +1477,14 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     };
     auto forward_chunk = [&](int c, bool tape, bool recompute = false) -> int {
         const int t0c = c * p->Tc, Tcur = chunk_len(p, c), ns = nsub_of(Tcur);
-        std::vector<hipEvent_t> ev(ns), ev_rest(ns, nullptr);
-        // split: the cells of round 0 first; routing round 0 then runs under the vertical kernel of the remaining cells
+        std::vector<hipEvent_t> ev(ns);
         auto launch_v = [&](int jb) -> int {
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
             // this part of the chunk buffers was last used by the R stream in the previous pass over them (the reverse sweep ends on
             // the V stream): wait for that sub-chunk only, so that the routing of chunk c's tail runs under chunk c + 1's first kernels
             if (jb < (int)p->buf_free.size() && p->buf_free[jb]) { HIPCHK(hipStreamWaitEvent(sV, p->buf_free[jb], 0)); p->buf_free[jb] = nullptr; }
-            if (split) {
-                vert_fwd(p, off, tape, t0c + off, T, 0, p->n0);
-                ev[jb] = p->event(); HIPCHK(hipEventRecord(ev[jb], sV));
-                vert_fwd(p, off, tape, t0c + off, T, p->n0, p->n);
-                ev_rest[jb] = p->event(); HIPCHK(hipEventRecord(ev_rest[jb], sV));
-            } else {
-                vert_fwd(p, off, tape, t0c + off, T);
-                ev[jb] = p->event(); HIPCHK(hipEventRecord(ev[jb], sV));
-            }
+            vert_fwd(p, off, tape, t0c + off, T);
+            ev[jb] = p->event(); HIPCHK(hipEventRecord(ev[jb], sV));
             return 0;
         };
         // every vertical sub-chunk is queued at once: they only depend on each other (state carry, stream order) and write
@@ -1569,35 +1495,19 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
             if (halo && p->n_in > 0 && (rc = inlet_series(c, jb, off, t0c + off, T, recompute, sR))) return rc;
             HIPCHK(hipStreamWaitEvent(sR, ev[jb], 0));
-            hipStream_t s_done = sR;
-            if (cstream) {
-                // round 0 on the R stream, the chained rounds behind it on their own stream: round 0 of the next sub-chunk does not wait for them
-                route_fwd_rounds(p, off, tape, t0c + off, T, sR, ev_rest[jb]);
-                hipEvent_t e_r0 = p->event();
-                HIPCHK(hipEventRecord(e_r0, sR));
-                HIPCHK(hipStreamWaitEvent(p->stream_c, e_r0, 0));
-                route_fwd_chained(p, off, tape, t0c + off, T, p->stream_c, ev_rest[jb]);
-                s_done = p->stream_c;
-            } else
-                route_fwd(p, off, tape, t0c + off, T, ev_rest[jb]);
+            route_fwd(p, off, tape, t0c + off, T);
             if (halo && p->n_out > 0 && !recompute) {       // (a recomputed chunk sends nothing: every rank kept what it received)
                 halo_move(true, true, off, T, sR);
                 if ((rc = hook(1, t0c + off, T, sR))) return rc;
             }
             if ((int)p->buf_free.size() <= jb) p->buf_free.resize(jb + 1, nullptr);
             p->buf_free[jb] = p->event();
-            HIPCHK(hipEventRecord(p->buf_free[jb], s_done));
-        }
-        if (cstream) {   // what follows on the R stream (cost, checkpoint of the routing store, the reverse sweep) sees the chained rounds done
-            hipEvent_t e_c = p->event();
-            HIPCHK(hipEventRecord(e_c, p->stream_c));
-            HIPCHK(hipStreamWaitEvent(sR, e_c, 0));
+            HIPCHK(hipEventRecord(p->buf_free[jb], sR));
         }
         return 0;
     };
     // (before a storage chunk's buffers are overwritten the V stream waits for the R stream sub-chunk by sub-chunk: buf_free in forward_chunk)
     p->dom_q_active = !adjoint && p->h_qsim_domain && p->A.qdT;
-    p->plain_rows = !adjoint && (p->h_qsim_domain || p->h_net_prcp_domain);      // the export below reads every cell's runoff from qtT
     // optional whole-domain stores (md_forward_structure.f90:158-194) of one storage chunk -> the caller's arrays
     auto export_domain = [&](int c) -> int {
         const int t0c = c * p->Tc, Tcur = chunk_len(p, c);
@@ -1669,40 +1579,18 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
                 if ((rc = restore_states(p, src))) return rc;
                 if ((rc = forward_chunk(c, true, true))) return rc;
             }
-            const int nsa = (Tcur + p->Tpa - 1) / p->Tpa;
+            const int nsa = (Tcur + p->Tp - 1) / p->Tp;
             for (int jb = nsa - 1; jb >= 0; --jb) {
-                const int off = jb * p->Tpa, T = std::min(p->Tpa, Tcur - off);
+                const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
                 if (halo && p->n_out > 0) {
                     if ((rc = hook(2, t0c + off, T, sR))) return rc;  // out_buf now holds the downstream tiles' adjoint contributions
                     halo_move(false, true, off, T, sR);
                 }
-                hipEvent_t e_rest = split ? p->event() : nullptr;
-                if (cstream) {
-                    // the chained rounds (roots of the basin first) run ahead on their own stream, sub-chunk after sub-chunk; round 0 of a
-                    // sub-chunk follows its chained rounds, the vertical adjoint follows round 0
-                    if (jb == nsa - 1) {      // the first one of this storage chunk: the forward chunk, the cost seeds and the accumulators are behind this point
-                        hipEvent_t e_r = p->event();
-                        HIPCHK(hipEventRecord(e_r, sR));
-                        HIPCHK(hipStreamWaitEvent(p->stream_c, e_r, 0));
-                    }
-                    route_adj_chained(p, off, t0c + off, T, p->stream_c);
-                    hipEvent_t e_ca = p->event();
-                    HIPCHK(hipEventRecord(e_ca, p->stream_c));
-                    HIPCHK(hipStreamWaitEvent(sR, e_ca, 0));
-                    route_adj_rounds(p, off, t0c + off, T, sR, e_rest);
-                } else
-                route_adj(p, off, t0c + off, T, e_rest);
+                route_adj(p, off, t0c + off, T);
                 hipEvent_t e = p->event();
                 HIPCHK(hipEventRecord(e, sR));
-                if (split) {   // the cells outside round 0 start while routing round 0 is still running
-                    HIPCHK(hipStreamWaitEvent(sV, e_rest, 0));
-                    vert_adj(p, off, t0c + off, T, p->n0, p->n);
-                    HIPCHK(hipStreamWaitEvent(sV, e, 0));
-                    vert_adj(p, off, t0c + off, T, 0, p->n0);
-                } else {
-                    HIPCHK(hipStreamWaitEvent(sV, e, 0));
-                    vert_adj(p, off, t0c + off, T);
-                }
+                HIPCHK(hipStreamWaitEvent(sV, e, 0));
+                vert_adj(p, off, t0c + off, T);
                 if (halo && p->n_in > 0) {
                     halo_move(true, false, off, T, sR);
                     if ((rc = hook(3, t0c + off, T, sR))) return rc;
@@ -2410,8 +2298,7 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
         }
         jreg_d = pj + sj;
     }
-    // sweep (one launch per routing round on the plain rows of every array: no staging rows, view_at)
-    struct PlainRows { smashx_plan* q; explicit PlainRows(smashx_plan* q_) : q(q_) { q->plain_rows = true; } ~PlainRows() { q->plain_rows = false; } } plain_rows_guard(p);
+    // sweep
     p->launches.clear(); p->pool_used = 0;
     if ((rc = close_forcing(p))) return rc;
     HIPCHK(hipEventRecord(p->ev0, sV));

@@ -201,11 +201,6 @@ struct SxDeviceArrays {
     float *tape_hi, *tape_hp, *tape_hft, *tape_hst;
     float* ckpt_hi;               // gr-b / gr-c: hi at every SX_HIK-th step of the chunk, [Tc / SX_HIK][npad] (tape_hi: vic-a only)
     float* xT;                    // exchange series
-    // staging rows of the chained groups: [time block + stage][chained slot] float4 (null = off; see "Staging rows" below).
-    // ncs = slots of the chained groups; k_stg[cell] = stage x ncs + slot of a cell that belongs to a chained group (0xffffffff: a cell of
-    // the rounds below the chain); x_stg[series] = the same for the inlet of a series that a round below the chain hands to a chained
-    // group (-1: any other series)
-    float* qsk; int ncs; const unsigned* k_stg; const int* x_stg;
     // gauges
     float *qg, *qgb;              // [ngc][nt] discharge at gauge cells / adjoint seeds
     int* cell_gauge;              // [npad] gauge-cell id or -1
@@ -219,43 +214,6 @@ struct SxDeviceArrays {
     int spin_limit;               // polls before a waiting group gives up and raises the stall flag
     int mute_group;               // tests only (SMASHX_DEBUG_MUTE_GROUP): this group never publishes -> its consumers stall; -1 = none
     long long* gtime;             // diagnostics (SMASHX_TRACE_GROUPS=1): [2 passes][ngroups][start, end] wall_clock64 ticks, else null
-};
-
-// ------------------------------------------------------------------------------------------------
-// Staging rows of the chained groups.  The groups of the rounds >= 1 are the river's main stems: a few workgroups whose super-step
-// is a latency chain, and every memory instruction in it whose 64 lanes touch 64 different lines (slots of one wave sit at different
-// stages, hence in different rows of the time-major arrays) costs that chain a full pass through the CU's memory path (DESIGN.md 12,
-// anatomy of a super-step).  Round 2 gave the routing tape the cure -- row = time block + stage, so a group's super-step touches one
-// row.  Round 4 gives it to everything else a chained group reads and writes: the runoff qt (later its adjoint qt_b) of the cells of the
-// chained groups, and the series that the rounds below the chain hand to them (later the adjoint series handed back), LIVE in the
-// staging array qsk [time block + stage][chained slot] instead of qtT / xT.  Whoever sits at the other end addresses them there:
-// the vertical kernels (a per-cell offset k_stg: the 5 % of their wavefronts that hold such cells store / load a few pieces per
-// instruction instead of one -- once per four steps), the subtree roots of the rounds below the chain (x_stg, a per-slot base and
-// stride like every other series).  No copy pass: a first version that gathered the rows before and scattered them after each
-// chained launch spent 6 ms per pass at 1024^2 x 8760 -- more than the chained launches gained.  Series between two chained groups
-// (produced and consumed inside the launch, behind the counters) and series to or from other ranks keep their plain rows.
-// The tangent sweep, the launch-per-round fallback and sweeps that export the runoff of every cell run with qsk = null: plain rows.
-// ------------------------------------------------------------------------------------------------
-template <int AUX = 0>
-__device__ __forceinline__ void sx_row_store4_wide(float* row, unsigned byte_off, float a, float b, float c, float d) {     // byte offsets up to 4 GB
-    typedef int sx_v4i __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0xffffffff, 0x00020000);
-    sx_v4i v = {__builtin_bit_cast(int, a), __builtin_bit_cast(int, b), __builtin_bit_cast(int, c), __builtin_bit_cast(int, d)};
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, AUX);
-}
-template <int AUX = 0>
-__device__ __forceinline__ float sx_row_load_wide(const float* row, unsigned byte_off) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)row, 0, 0xffffffff, 0x00020000);
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, AUX));
-}
-// qt (forward) / qt_b (reverse) of one cell: where the four steps of time block tq of this launch live
-struct SxQtAddr {
-    bool stg; unsigned off;      // staged: byte offset inside a staging row; else inside a plain row
-    __device__ __forceinline__ SxQtAddr(const SxDeviceArrays& A, int k) {
-        const unsigned so = A.qsk ? A.k_stg[k] : 0xffffffffu;
-        stg = so != 0xffffffffu;
-        off = stg ? so * 16u : (unsigned)k * 16u;
-    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -417,7 +375,6 @@ void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
 
     // rows are wave-uniform (sx_row_load / sx_row_store): the vector unit does no address arithmetic in the time loop
     const unsigned kb = (unsigned)k * 4u;
-    const SxQtAddr QA(A, k);
     SxForcing<CF> F(A, kb, t0);
     if (T > 0) F.template request<SX_NT, false>(t0, true);
     for (int tq = 0; tq * 4 < T; ++tq) {
@@ -443,8 +400,7 @@ void sx_k_vert_fwd(SxDeviceArrays A, int t0, int T) {
                 q[i] = sx_vertical_step<ST>(P, prcp, pet, hi, hp, hft, hst, still);
             }
         }
-        if (!QA.stg) sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
-        else sx_row_store4_wide<SX_NT>(A.qsk + (size_t)tq * A.ncs * 4, QA.off, q[0], q[1], q[2], q[3]);      // a cell of a chained group
+        sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
     }
     if (ST == 2 || ST == 3) A.hi[k] = hi;
     A.hp[k] = hp;
@@ -478,7 +434,6 @@ __global__ __launch_bounds__(SX_VBLOCK, TAPE ? SX_VFWD_WAVES_VIC : 1) void sx_k_
     const float cusl2_m4 = sx_pow_m4(P.cusl2);
     float husl1 = A.hi[k], husl2 = A.hp[k], hlsl = A.hft[k];
     const unsigned kb = (unsigned)k * 4u;
-    const SxQtAddr QA(A, k);
     SxForcing<CF> F(A, kb, t0);
     if (T > 0) F.template request<SX_NT, false>(t0, true);
     for (int tq = 0; tq * 4 < T; ++tq) {
@@ -498,8 +453,7 @@ __global__ __launch_bounds__(SX_VBLOCK, TAPE ? SX_VFWD_WAVES_VIC : 1) void sx_k_
                 q[i] = sx_vic_step(P, cusl2_m4, F.prcp(), F.pet(), husl1, husl2, hlsl);
             }
         }
-        if (!QA.stg) sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
-        else sx_row_store4_wide<SX_NT>(A.qsk + (size_t)tq * A.ncs * 4, QA.off, q[0], q[1], q[2], q[3]);      // a cell of a chained group
+        sx_row_store4<SX_NT>(A.qtT + (size_t)tq * npad * 4, kb * 4u, q[0], q[1], q[2], q[3]);
     }
     A.hi[k] = husl1; A.hp[k] = husl2; A.hft[k] = hlsl;
 }
@@ -523,7 +477,6 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES_VIC) void sx_k_vert_adj_vi
     G.ds_b = A.px_b[0][k]; G.dsm_b = A.px_b[1][k]; G.ws_b = A.px_b[2][k];
     G.husl1_b = A.hi_b[k]; G.husl2_b = A.hp_b[k]; G.hlsl_b = A.hft_b[k];
     const unsigned kb = (unsigned)k * 4u;
-    const SxQtAddr QA(A, k);
     SxForcing<CF> F(A, kb, t0 + T - 1);
     float n_h1 = 0.f, n_h2 = 0.f, n_hl = 0.f, n_q = 0.f;
     auto fetch = [&](int tt, bool first) {
@@ -531,8 +484,7 @@ __global__ __launch_bounds__(SX_VBLOCK, SX_VADJ_WAVES_VIC) void sx_k_vert_adj_vi
         F.template request<SX_VADJ_NT, true>(t0 + tt, first);
         n_h1 = sx_row_load<SX_VADJ_NT>(A.tape_hi + o, kb); n_h2 = sx_row_load<SX_VADJ_NT>(A.tape_hp + o, kb);
         n_hl = sx_row_load<SX_VADJ_NT>(A.tape_hft + o, kb);
-        if (!QA.stg) n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
-        else n_q = sx_row_load_wide(A.qsk + (size_t)(tt >> 2) * A.ncs * 4 + (tt & 3), QA.off);                  // a cell of a chained group
+        n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
     };
     if (T > 0) fetch(T - 1, true);
     for (int tt = T - 1; tt >= 0; --tt) {
@@ -729,20 +681,11 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
     const int* wprog = nullptr;
     int seen = 0;
     if (CHAIN && xin >= 0) { const int pg = A.x_prod[xin]; if (pg >= g0 && pg < gend) wprog = A.prog + pg; }
-    // "Staging rows" above: the runoff of a cell of a chained group and a series handed up to a chained group live in qsk (row = time
-    // block + the chained slot's stage) -- this slot may be that cell / that inlet, or the subtree root below the chain that publishes
-    const bool stg_on = !TAN && A.qsk != nullptr && valid;
-    const unsigned so_in = !stg_on ? 0xffffffffu : cell >= 0 ? A.k_stg[cell] : (xin >= 0 ? (unsigned)A.x_stg[xin] : 0xffffffffu);
-    const bool staged = so_in != 0xffffffffu;
-    const unsigned so_out = (stg_on && xout >= 0) ? (unsigned)A.x_stg[xout] : 0xffffffffu;
     // T4 addressing: element (tb, id) of an array with `stride` float4 per time block
-    const float4* src = staged ? reinterpret_cast<const float4*>(A.qsk) + so_in
-                      : (cell >= 0) ? reinterpret_cast<const float4*>(TAN ? A.qtdT : A.qtT) + cell
+    const float4* src = (cell >= 0) ? reinterpret_cast<const float4*>(TAN ? A.qtdT : A.qtT) + cell
                                     : reinterpret_cast<const float4*>(TAN ? A.xdT : A.xT) + (xin >= 0 ? xin : 0);
-    const size_t sstride = staged ? (size_t)A.ncs : (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
+    const size_t sstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
     float4* x4 = reinterpret_cast<float4*>(TAN ? A.xdT : A.xT);
-    float4* const xdst = so_out != 0xffffffffu ? reinterpret_cast<float4*>(A.qsk) + so_out : x4 + (xout >= 0 ? xout : 0);      // a root's series
-    const size_t xstride = so_out != 0xffffffffu ? (size_t)A.ncs : (size_t)A.nx;
     float4* hr4 = reinterpret_cast<float4*>(A.hrT);
     // hr_imd tape, private to the routing kernels: row = time block + stage, so the slots of a group -- which work on time block
     // w - stage in super-step w -- all write row w, cell next to cell (measured: 64 -> 8 line requests per wave store)
@@ -774,7 +717,7 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
             for (int u = 0; u < MU; ++u) {
                 const int tb = MU * (mw - 1) + u - stage;
                 if (tb >= 0 && tb < nb) {
-                    if (xout >= 0) xdst[(size_t)tb * xstride] = outq[u];
+                    if (xout >= 0) x4[(size_t)tb * A.nx + xout] = outq[u];
                     if (TAPE) sx_gstore4s(hr4 + (size_t)(tb + hs) * A.npad + cell, outh[u]);
                     if (A.qdT) reinterpret_cast<float4*>(A.qdT)[(size_t)tb * A.npad + cell] = outq[u];
                     if (gid >= 0) {
@@ -965,17 +908,8 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
     // where a slot's result goes: qt_b of its cell, or -- inlet -- the adjoint series of the subtree upstream.  ONE store instruction
     // for both kinds (per-lane base and row stride): in the chained rounds, where a third of the slots are inlets, the second store
     // instruction of a super-step cost as much as the first whatever its lane count (anatomy of the reverse launch)
-    // "Staging rows": qt_b of a cell of a chained group and the adjoint series an inlet of a chained group hands down to a round below the
-    // chain go to qsk (row = time block + the chained slot's stage = one row per reverse super-step of the group); a subtree root below the
-    // chain finds the adjoint of its series there
-    const bool stg_on = A.qsk != nullptr && valid;
-    const unsigned so_out = !stg_on ? 0xffffffffu : cell >= 0 ? A.k_stg[cell] : (xin >= 0 ? (unsigned)A.x_stg[xin] : 0xffffffffu);
-    const bool staged = so_out != 0xffffffffu;
-    const unsigned so_in = (stg_on && cell >= 0 && xout >= 0) ? (unsigned)A.x_stg[xout] : 0xffffffffu;
-    float4* const dst = staged ? reinterpret_cast<float4*>(A.qsk) + so_out : (cell >= 0) ? qt4 + cell : x4 + (xin >= 0 ? xin : 0);
-    const size_t dstride = staged ? (size_t)A.ncs : (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
-    const float4* const xsrc = so_in != 0xffffffffu ? reinterpret_cast<const float4*>(A.qsk) + so_in : x4 + (xout >= 0 ? xout : 0);
-    const size_t xsstride = so_in != 0xffffffffu ? (size_t)A.ncs : (size_t)A.nx;
+    float4* const dst = (cell >= 0) ? qt4 + cell : x4 + (xin >= 0 ? xin : 0);
+    const size_t dstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
 
     // gauge cells also fetch their adjoint seeds (qsim_b summed per cell) with the staged loads, so the
     // super-step loop itself contains no global memory operation and no vmcnt wait
@@ -995,7 +929,7 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
     const int* wprog = nullptr;
     int seen = 0;
     if (CHAIN && root_in) { const int cg = A.x_cons[xout]; if (cg >= g0 && cg < gend) wprog = A.prog + cg; }
-    auto fetch_in = [&](int tb) -> float4 { return sx_gload4(xsrc + (size_t)tb * xsstride); };
+    auto fetch_in = [&](int tb) -> float4 { return sx_gload4(x4 + (size_t)tb * A.nx + xout); };
     float4 nhr[MU], nin[MU], nsd[MU], outq[MU];
     if (CHAIN && wprog) sx_wait_prog(wprog, min(MU - rstage, nb), seen, SX_PROG_STALL(A), A.spin_limit, g);
 #pragma unroll
@@ -1181,7 +1115,6 @@ void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
     // addresses = wave-uniform row (buffer descriptor in scalar registers, advanced by the scalar unit) + the cell's 32-bit
     // byte offset: no vector address arithmetic in the time loop
     const unsigned kb = (unsigned)k * 4u;
-    const SxQtAddr QA(A, k);
     SxForcing<CF> F(A, kb, t0 + T - 1);
     float n_hi = 0.f, n_hp = 0.f, n_hft = 0.f, n_hst = 0.f, n_q = 0.f;
     const bool hi_taped = (ST == 2 || ST == 3) && A.tape_hi != nullptr;       // wave-uniform
@@ -1197,8 +1130,7 @@ void sx_k_vert_adj(SxDeviceArrays A, int t0, int T) {
         n_hp = sx_row_load<SX_VADJ_NT>(r_hp, kb); n_hft = sx_row_load<SX_VADJ_NT>(r_hft, kb);
         r_hp -= npad; r_hft -= npad;
         if (ST == 3) { n_hst = sx_row_load<SX_VADJ_NT>(r_hst, kb); r_hst -= npad; }
-        if (!QA.stg) n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
-        else n_q = sx_row_load_wide(A.qsk + (size_t)(tt >> 2) * A.ncs * 4 + (tt & 3), QA.off);                  // a cell of a chained group
+        n_q = sx_row_load(A.qtT + (size_t)(tt >> 2) * npad * 4 + (tt & 3), kb * 4u);
     };
     // When the interception level is not taped (it depends on the forcing and ci only; the plan drops its tape when that is what
     // lets the whole period fit): each block of SX_HIK steps is marched forward once more from its checkpoint -- the same

@@ -30,7 +30,7 @@ CS = 9.185525760e9            # cell-steps of the 1024^2 x 8760 case: the unit t
 # measured kernel times, ms per CS cell-steps (profiles/r3_rocprofv3_kernel_stats_2048.csv: launches of 2192 steps x 4.19 M cells;
 # profiles/r2_rocprofv3_kernel_stats.csv for the store-all 1024^2 case)
 RATES = {
-    "vf_u": 28.6, "vf_t": 35.6, "va": 63.2,                  # vertical: forward untaped / taped, reverse (hi tape on) -- final round-3 build
+    "vf_u": 28.6, "vf_t": 35.6, "va": 60.1,                  # vertical: forward untaped / taped, reverse (hi tape on) -- round 4 (profiles/r4_2048_kernel_stats.csv)
     "r0f_u": 8.68, "r0f_t": 13.94, "r0a": 17.0,              # round 0 at 548 time blocks per launch (2048^2), forward untaped / taped, reverse
     "r0_nb_ref": 548, "r0_depth": 160,                       # ... whose groups are up to 160 stages deep: a launch of nb blocks runs nb + depth super-steps
     "tau_f": 1.366e-3, "tau_a": 1.658e-3,                    # ms per super-step of a chained launch (2048^2: 8.3 / 10.1 ms for 548 blocks + 5530 stages)
@@ -266,21 +266,25 @@ def sweep_ms(N, pr, pc, tile, nt, chunk, pipe, shared, p):
 
 # measurements the model is held to: (label, N, pr, pc, tile, chunk, pipe, shared GPU, measured ms, source)
 MEASURED = [
-    ("solo 2048x1024 tile, no sub-chunks", 1, 1, 1, (2048, 1024), 4384, 4384, True, 319.5, "profiles/r3_solo_rank0_pipe4384.json"),
-    ("solo 2048x1024 tile, sub-chunks of 2192", 1, 1, 1, (2048, 1024), 4384, 2192, True, 327.5, "profiles/r3_solo_rank0_pipe2192.json"),
-    ("solo 2048x1024 tile, sub-chunks of 1104", 1, 1, 1, (2048, 1024), 4384, 1104, True, 342.2, "profiles/r3_solo_rank0_pipe1104.json"),
-    ("2048^2 single domain, 4 storage chunks", 1, 1, 1, (2048, 2048), 2192, 2192, True, 726.0, "profiles/r3_bench_2048x2048x8760*.json (716-733)"),
-    ("1024^2 single domain, store-all", 1, 1, 1, (1024, 1024), 8768, 8768, True, 151.6, "profiles/r3_bench_2048x2048x8760.json (secondary 150.5-152.7)"),
-    ("rehearsal: 2 ranks on ONE GPU, 1x2 tiles of 1024x512", 2, 1, 2, (1024, 512), 8768, 2192, True, 157.4, "profiles/r3_rehearsal_2ranks_one_gpu.json"),
-    ("rehearsal: 4 ranks on ONE GPU, 2x2 tiles of 512x512", 4, 2, 2, (512, 512), 8768, 2192, True, 159.8, "profiles/r3_rehearsal_4ranks_one_gpu.json"),
-    ("rehearsal: 6 ranks on ONE GPU, 1x6 tiles of 1024x176", 6, 1, 6, (1024, 176), 8768, 1104, True, 259.5, "profiles/r3_rehearsal_6ranks_one_gpu.json"),
+    ("solo 2048x1024 tile, no sub-chunks", 1, 1, 1, (2048, 1024), 4384, 4384, True, 323.6, "profiles/r4_solo_p4384.json"),
+    ("solo 2048x1024 tile, sub-chunks of 2192", 1, 1, 1, (2048, 1024), 4384, 2192, True, 329.7, "profiles/r4_solo_p2192.json"),
+    ("solo 2048x1024 tile, sub-chunks of 1104", 1, 1, 1, (2048, 1024), 4384, 1104, True, 339.9, "profiles/r4_solo_p1104.json"),
+    ("2048^2 single domain, 4 storage chunks", 1, 1, 1, (2048, 2048), 2192, 2192, True, 710.6, "profiles/r4_bench_2048x2048x8760.json (699-715 across boxes)"),
+    ("1024^2 single domain, store-all", 1, 1, 1, (1024, 1024), 8768, 8768, True, 150.9, "profiles/r4_bench_2048x2048x8760.json (secondary)"),
+    ("rehearsal: 2 ranks on ONE GPU, 1x2 tiles of 1024x512", 2, 1, 2, (1024, 512), 8768, 2192, True, 156.3, "profiles/r4_reh2.json"),
+    ("rehearsal: 4 ranks on ONE GPU, 2x2 tiles of 512x512", 4, 2, 2, (512, 512), 8768, 2192, True, 157.5, "profiles/r4_reh4.json"),
+    ("rehearsal: 6 ranks on ONE GPU, 1x6 tiles of 1024x176", 6, 1, 6, (1024, 176), 8768, 1104, True, 260.6, "profiles/r4_reh6.json"),
+    # round 4: CHUNKED rehearsals (4 storage chunks: three of them recomputed in the reverse sweep -- without exchange since this round)
+    ("rehearsal: 2 ranks on ONE GPU, 1x2 tiles of 1024x512, 4 storage chunks", 2, 1, 2, (1024, 512), 2192, 1104, True, 204.1, "profiles/r4_reh2_chunked.json"),
+    ("rehearsal: 4 ranks on ONE GPU, 2x2 tiles of 512x512, 4 storage chunks", 4, 2, 2, (512, 512), 2192, 1104, True, 189.2, "profiles/r4_reh4_chunked.json"),
 ]
 
 
 def fit():
     best = None
-    for delta, kappa, lat in itertools.product((0.05, 0.1, 0.15, 0.2, 0.3, 0.4), (1.0, 1.05, 1.1, 1.15, 1.2, 1.3), (0.05, 0.2, 0.5, 1.0)):
-        p = {"delta": delta, "kappa": kappa, "lat": lat}
+    for delta, kappa, lat, pps in itertools.product((0.05, 0.1, 0.15, 0.2, 0.3, 0.4, 0.5), (1.0, 1.05, 1.1, 1.15, 1.2, 1.3), (0.05, 0.2, 0.5, 1.0, 2.0), (0.7, 1.0, 1.35)):
+        p = {"delta": delta, "kappa": kappa, "lat": lat, "path_per_side": pps}
+        RATES["path_per_side"] = pps
         err = []
         for (_, N, pr, pc, tile, chunk, pipe, shared, ms, _src) in MEASURED:
             err.append(sweep_ms(N, pr, pc, tile, 8760, chunk, pipe, shared, p) / ms - 1.0)
@@ -295,6 +299,7 @@ def main():
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     score, p, err = fit()
+    RATES["path_per_side"] = p["path_per_side"]
     rep = {"what": __doc__.split("\n\n")[0], "rates_ms_per_9.19e9_cellsteps": {k: (v if not isinstance(v, dict) else {str(a): b for a, b in v.items()}) for k, v in RATES.items()}, "fitted": p, "rms_relative_error": score, "validation": [], "prediction": []}
     for (label, N, pr, pc, tile, chunk, pipe, shared, ms, src), e in zip(MEASURED, err):
         rep["validation"].append({"case": label, "measured_ms": ms, "model_ms": round(ms * (1.0 + e), 1), "error": round(e, 3), "source": src})
@@ -307,6 +312,13 @@ def main():
                                       "cell_timesteps_per_s": round(N * 2048 * 1024 * 8760 / (t * 1e-3), -8),
                                       "efficiency_vs_solo_tile": round(solo / t, 3)})
     rep["solo_tile_model_ms"] = round(solo, 1)
+    # what keeping the received inlet series buys: the same predictions with the recomputation exchanging them again (round 3's sweep)
+    SCHEDULE["keep_inlets"] = False
+    rep["prediction_if_recomputation_exchanged_again"] = []
+    for N, pr, pc in ((2, 1, 2), (4, 2, 2), (8, 2, 4)):
+        t = sweep_ms(N, pr, pc, (2048, 1024), 8760, 4384, 1104, False, p)
+        rep["prediction_if_recomputation_exchanged_again"].append({"n_gpus": N, "pipe_steps": 1104, "sweep_ms": round(t, 1), "efficiency_vs_solo_tile": round(solo / t, 3)})
+    SCHEDULE["keep_inlets"] = True
     txt = json.dumps(rep, indent=1)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)

@@ -66,7 +66,7 @@ families = {   # name -> (selector, cell-steps the family's dispatches processed
     "sx_k_route_adj": (lambda k: k.startswith("sx_k_route_adj<"), total["reverse"]),
 }
 out = {"workload": {"grid": acct["grid"], "n_chunks": acct["n_chunks"], "chunk_steps": acct["chunk_steps"], "cellsteps_per_sweep": acct["cellsteps"],
-                    "adjoint_sweeps_profiled": nadj, "forward_sweeps_profiled": nfwd, "config": bench.get("config", {}).get("workload")}}
+                    "adjoint_sweeps_profiled": nadj, "forward_sweeps_profiled": nfwd, "forward_only": nadj == 0, "config": bench.get("config", {}).get("workload")}}
 for name, (sel, cs) in families.items():
     ks = [k for k in acc if sel(k)]
     if not ks or cs <= 0 or not all("FETCH_SIZE" in acc[k] for k in ks):
