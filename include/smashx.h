@@ -307,6 +307,35 @@ int smashx_comm_allreduce_sum(void* comm, double* values, int n);
 int smashx_comm_info(void* comm, int* nranks, int* version);
 int smashx_set_exchange(smashx_plan* plan, void* comm, const int* out_peer, const int* in_peer);
 
+/* ---- hyper mappings (host side; round 4) -----------------------------------------------------------------------------------
+ * mw_forward::hyper_forward / hyper_forward_b / hyper_forward_d (mw_forward.f90:99-181 -> base_hyper_forward forward.f90:82-157,
+ * BASE_HYPER_FORWARD_B / _D forward_db.f90:11231-11560, 11079-11162) are forward / forward_b / forward_d with one step in front of the
+ * time loop -- every parameter (state) field is a sigmoid of a linear or polynomial form of nd catchment descriptors
+ * (hyper_parameters_to_parameters mwd_parameters_manipulation.f90:304-362, hyper_states_to_states mwd_states_manipulation.f90:270-329)
+ * -- and that step's tangent / adjoint (forward_db.f90:1313-1537, 2179-2369) around the sweep.  The map is host code in the reference
+ * and host code here (sx_hyper.cpp: no GPU, the caller's planes, fp32 in the reference's operation order); a host composes
+ *     smashx_hyper_map_forward (parameters, states)  ->  smashx_forward                      (base_hyper_forward)
+ *     ... -> smashx_forward_b -> smashx_hyper_map_b (parameters_b -> hyper_parameters_b, ...)  (base_hyper_forward_b)
+ *     smashx_hyper_map_d -> smashx_forward_d                                                 (base_hyper_forward_d)
+ * with denormalize_forward off and no regulariser (hyper_compute_cost knows neither), states left at their final values
+ * (forward.f90:150).  smash_amd.hyper_forward / _b / _d do exactly that; under the Fortran shim the reference's own routines do. */
+#define SMASHX_HYPER_LINEAR 1
+#define SMASHX_HYPER_POLYNOMIAL 2
+typedef struct {
+    int mapping;               /* SMASHX_HYPER_LINEAR / _POLYNOMIAL (setup%optimize%mapping) */
+    int nrow, ncol, nd;        /* grid, number of descriptors (setup%nd) */
+    int nfields;               /* 16 parameter fields or 8 state fields, md_constant order */
+    const float* descriptor;   /* input_data%descriptor (nrow, ncol, nd), column-major */
+    const float* lb;           /* setup%optimize%lb_parameters / lb_states (nfields) */
+    const float* ub;
+} smashx_hyper_map;
+/* rows of a hyper matrix: 1 + nd (linear), 1 + 2 nd (polynomial) = setup%optimize%nhyper; hyper matrices are (nhyper, nfields)
+ * column-major: column i = Hyper_ParametersDT field i (nhyper, 1) */
+int smashx_hyper_nhyper(const smashx_hyper_map* map);
+int smashx_hyper_map_forward(const smashx_hyper_map* map, const float* hyper, float* const* planes /* nfields x (nrow,ncol), NULL skipped */);
+int smashx_hyper_map_d(const smashx_hyper_map* map, const float* hyper, const float* hyper_d, float* const* planes, float* const* planes_d);
+int smashx_hyper_map_b(const smashx_hyper_map* map, const float* hyper, float* const* planes_b /* NULL = zero */, float* hyper_b /* overwritten */);
+
 /* ---- diagnostics ---------------------------------------------------------------------------------------
  * Start / end ticks (100 MHz device wall clock) of every routing group in the last forward (pass 0) and adjoint
  * (pass 1) routing launches: out[2][groups][2]; round_of_group[groups] may be NULL.  Only recorded when the plan

@@ -4,8 +4,9 @@ The package is a thin host-side mirror of the reference's ``mw_forward`` boundar
 (HIP kernels behind the C ABI of include/smashx.h).  Importing it does not need a GPU; calling the
 solver does, and fails loudly without one.
 """
-from .solver import Solver, forward, forward_b, forward_d, gradient_test, invalidate_forcing, scalar_product_test  # noqa: F401
-from .types import (Input_DataDT, MeshDT, Optimize_SetupDT, OutputDT, ParametersDT, SetupDT,  # noqa: F401
-                    StatesDT)
+from .solver import (Solver, forward, forward_b, forward_d, gradient_test, hyper_forward, hyper_forward_b, hyper_forward_d,  # noqa: F401
+                     invalidate_forcing, scalar_product_test)
+from .types import (Hyper_ParametersDT, Hyper_StatesDT, Input_DataDT, MeshDT, Optimize_SetupDT, OutputDT,  # noqa: F401
+                    ParametersDT, SetupDT, StatesDT)
 from ._lib import SmashxError  # noqa: F401
 from .optimize import optimize_lbfgsb  # noqa: F401

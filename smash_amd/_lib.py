@@ -26,6 +26,7 @@ SYMBOLS = [
     "smashx_set_median_slots", "smashx_selftest_paths",
     "smashx_lbfgsb_create", "smashx_lbfgsb_step", "smashx_lbfgsb_destroy", "smashx_lbfgsb_iterations", "smashx_lbfgsb_message",
     "smashx_lbfgsb_evaluations", "smashx_lbfgsb_projected_gradient", "smashx_plan_hbm", "smashx_comm_info",
+    "smashx_hyper_nhyper", "smashx_hyper_map_forward", "smashx_hyper_map_d", "smashx_hyper_map_b",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
@@ -53,6 +54,11 @@ class Options(C.Structure):
 
 class ForcingLayout(C.Structure):
     _fields_ = [("compact", C.c_int), ("prcp_factor", C.c_float), ("pet_ratio", C.c_float * 24), ("pet_hour0", C.c_int)]
+
+
+class HyperMap(C.Structure):
+    _fields_ = [("mapping", C.c_int), ("nrow", C.c_int), ("ncol", C.c_int), ("nd", C.c_int), ("nfields", C.c_int),
+                ("descriptor", C.c_void_p), ("lb", C.c_void_p), ("ub", C.c_void_p)]
 
 
 class Parameters(C.Structure):

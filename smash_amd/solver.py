@@ -486,6 +486,102 @@ def forward_d(setup, mesh, input_data, parameters, parameters_d, parameters_bgd,
     return _tangent_call(s, parameters, parameters_d, parameters_bgd, states, states_d, states_bgd, output, output_d)
 
 
+# ---- hyper mappings: mw_forward::hyper_forward / hyper_forward_b / hyper_forward_d (mw_forward.f90:99-181) -------------------------
+_HYPER = {"hyper-linear": 1, "hyper-polynomial": 2}
+
+
+def _hyper_map(setup, mesh, input_data, nfields, lb, ub):
+    if setup.optimize.mapping not in _HYPER:
+        raise _lib.SmashxError(_lib.E_ARG, f"setup.optimize.mapping = {setup.optimize.mapping!r}: hyper-linear or hyper-polynomial expected")
+    desc = np.asfortranarray(input_data.descriptor, dtype=np.float32)
+    m = _lib.HyperMap(_HYPER[setup.optimize.mapping], mesh.nrow, mesh.ncol, int(desc.shape[2]) if desc.ndim == 3 else 0, nfields,
+                      _ptr(desc), None, None)
+    keep = (desc, np.ascontiguousarray(lb, np.float32), np.ascontiguousarray(ub, np.float32))
+    m.lb, m.ub = _ptr(keep[1]), _ptr(keep[2])
+    return m, keep
+
+
+def _plane_ptrs(fields, names):
+    arr = (C.c_void_p * len(names))()
+    for i, k in enumerate(names):
+        a = getattr(fields, k)
+        if not (a.dtype == np.float32 and a.flags.f_contiguous):
+            a = np.asfortranarray(a, dtype=np.float32)
+            setattr(fields, k, a)
+        arr[i] = a.ctypes.data
+    return arr
+
+
+def _hyper_to_fields(setup, mesh, input_data, parameters, hyper_parameters, states, hyper_states, direction=None):
+    """hyper_parameters_to_parameters + hyper_states_to_states (mwd_parameters_manipulation.f90:304-362, mwd_states_manipulation.f90:
+    270-329) -- or, with direction = (hyper_parameters_d, parameters_d, hyper_states_d, states_d), their tangents (_D)."""
+    L, o = _lib.lib(), setup.optimize
+    for names, fields, hyp, lb, ub, k in ((PARAM_NAMES, parameters, hyper_parameters, o.lb_parameters, o.ub_parameters, 0),
+                                          (STATE_NAMES, states, hyper_states, o.lb_states, o.ub_states, 2)):
+        m, keep = _hyper_map(setup, mesh, input_data, len(names), lb, ub)
+        h = hyp.matrix()
+        if direction is None:
+            _lib.check(L.smashx_hyper_map_forward(C.byref(m), _ptr(h), _plane_ptrs(fields, names)))
+        else:
+            hd = direction[k].matrix()
+            _lib.check(L.smashx_hyper_map_d(C.byref(m), _ptr(h), _ptr(hd), _plane_ptrs(fields, names), _plane_ptrs(direction[k + 1], names)))
+
+
+def _plain(setup):
+    """base_hyper_forward knows neither denormalize_forward nor the regularisers (hyper_compute_cost: cost = jobs)."""
+    s = setup.copy()
+    s.optimize.denormalize_forward = False
+    s.optimize.jreg_fun, s.optimize.wjreg_fun, s.optimize.wjreg = [], [], 0.0
+    return s
+
+
+def hyper_forward(setup, mesh, input_data, parameters, hyper_parameters, hyper_parameters_bgd, states, hyper_states, hyper_states_bgd,
+                  output, cost=None):
+    """Drop-in for mw_forward::hyper_forward (mw_forward.f90:99-123 -> base_hyper_forward, forward.f90:82-157): the descriptor ->
+    field maps on the host (include/smashx.h "hyper mappings"), the time loop and the cost on the GPU.  parameters / states come back
+    as the mapped fields / the FINAL states (forward.f90:150: no restore).  Returns output.cost."""
+    _hyper_to_fields(setup, mesh, input_data, parameters, hyper_parameters, states, hyper_states)
+    s = _solver_for(_plain(setup), mesh, input_data)
+    s.upload(parameters, states, parameters, states)
+    s.sweep(False)
+    cost = s.download(False, None, None, output)
+    for k in STATE_NAMES:
+        getattr(states, k)[...] = getattr(output.fstates, k)
+    return cost
+
+
+def hyper_forward_b(setup, mesh, input_data, parameters, parameters_b, hyper_parameters, hyper_parameters_b, hyper_parameters_bgd,
+                    states, states_b, hyper_states, hyper_states_b, hyper_states_bgd, output, output_b, cost=None, cost_b=1.0):
+    """Drop-in for mw_forward::hyper_forward_b (mw_forward.f90:125-152 -> BASE_HYPER_FORWARD_B, forward_db.f90:11231-11560):
+    hyper_parameters_b / hyper_states_b are overwritten with the gradient of the cost w.r.t. the coefficients (times cost_b);
+    parameters_b / states_b hold the gradient w.r.t. the mapped fields."""
+    L, o = _lib.lib(), setup.optimize
+    _hyper_to_fields(setup, mesh, input_data, parameters, hyper_parameters, states, hyper_states)
+    s = _solver_for(_plain(setup), mesh, input_data)
+    s.upload(parameters, states, parameters, states)
+    s.sweep(True, float(cost_b))
+    cost = s.download(True, None, None, output, parameters_b, states_b)
+    # (the gradient planes of fields the structure does not read come back as zeros: they add nothing to any sum)
+    for names, grads, hyp, hyp_b, lb, ub in ((STATE_NAMES, states_b, hyper_states, hyper_states_b, o.lb_states, o.ub_states),
+                                             (PARAM_NAMES, parameters_b, hyper_parameters, hyper_parameters_b, o.lb_parameters, o.ub_parameters)):
+        m, keep = _hyper_map(setup, mesh, input_data, len(names), lb, ub)
+        ptrs = _plane_ptrs(grads, names)
+        hb = np.zeros((o.nhyper, len(names)), np.float32, order="F")
+        _lib.check(L.smashx_hyper_map_b(C.byref(m), _ptr(hyp.matrix()), ptrs, _ptr(hb)))
+        hyp_b.set_matrix(hb)
+    return cost
+
+
+def hyper_forward_d(setup, mesh, input_data, parameters, parameters_d, hyper_parameters, hyper_parameters_d, hyper_parameters_bgd,
+                    states, states_d, hyper_states, hyper_states_d, hyper_states_bgd, output, output_d, cost=None, cost_d=None):
+    """Drop-in for mw_forward::hyper_forward_d (mw_forward.f90:154-181 -> BASE_HYPER_FORWARD_D, forward_db.f90:11079-11162).
+    Returns (cost, cost_d)."""
+    _hyper_to_fields(setup, mesh, input_data, parameters, hyper_parameters, states, hyper_states,
+                     direction=(hyper_parameters_d, parameters_d, hyper_states_d, states_d))
+    s = _solver_for(_plain(setup), mesh, input_data)
+    return _tangent_call(s, parameters, parameters_d, parameters, states, states_d, states, output, output_d)
+
+
 def scalar_product_test(setup, mesh, input_data, parameters, states, output):
     """mw_adjoint_test::scalar_product_test (mw_adjoint_test.f90:26-105): <dY*, dY> = cost_b * cost_d against
     <dk*, dk> = sum(parameters_b * parameters_d) for dk = 1 on every parameter field and 0 on the states.

@@ -44,6 +44,8 @@ class Optimize_SetupDT:
         self.lb_states = GLB_STATES.copy()
         self.ub_states = GUB_STATES.copy()
         self.wgauge = np.full(max(ng, 1), 1.0 / max(ng, 1), np.float32)[:ng]
+        self.mapping = "uniform"      # "hyper-linear" / "hyper-polynomial": smash_amd.hyper_forward(_b, _d)
+        self.nhyper = 0               # 1 + nd (hyper-linear) or 1 + 2 nd (hyper-polynomial), mwd_setup.f90 / _optimize.py
 
     @property
     def njf(self):
@@ -58,6 +60,7 @@ class SetupDT:
     def __init__(self, nd: int = 0, ng: int = 0, *, structure: str = "gr-a", dt: float = 3600.0, ntime_step: int = 0,
                  sparse_storage: bool = False, save_qsim_domain: bool = False, save_net_prcp_domain: bool = False):
         self.structure = structure
+        self.nd = int(nd)                                       # catchment descriptors (input_data.descriptor (nrow, ncol, nd))
         self.dt = float(dt)
         self.ntime_step = int(ntime_step)
         self.sparse_storage = bool(sparse_storage)
@@ -104,6 +107,7 @@ class Input_DataDT:
         else:
             self.prcp = np.full((mesh.nrow, mesh.ncol, nt), -99.0, np.float32, order="F")
             self.pet = np.full((mesh.nrow, mesh.ncol, nt), -99.0, np.float32, order="F")
+        self.descriptor = np.full((mesh.nrow, mesh.ncol, getattr(setup, "nd", 0)), -99.0, np.float32, order="F")
 
 
 class _Fields:
@@ -140,6 +144,47 @@ class ParametersDT(_Fields):
 class StatesDT(_Fields):
     _names = STATE_NAMES
     _defaults = STATE_DEFAULTS
+
+
+class _HyperFields:
+    """Hyper_ParametersDT / Hyper_StatesDT (mwd_parameters.f90:88-116, mwd_states.f90:71-91): one (nhyper, 1) column of coefficients
+    per field; row 0 the intercept, then (a_j) for hyper-linear or (a_j, b_j) pairs for hyper-polynomial, j over the descriptors."""
+    _names = ()
+
+    def __init__(self, setup):
+        nh = setup.optimize.nhyper
+        for k in self._names:
+            setattr(self, k, np.zeros((nh, 1), np.float32, order="F"))
+
+    def copy(self):
+        o = object.__new__(type(self))
+        for k in self._names:
+            setattr(o, k, np.asfortranarray(getattr(self, k).copy(order="F")))
+        return o
+
+    def matrix(self):
+        """(nhyper, nfields) column-major, md_constant field order: what include/smashx.h calls a hyper matrix."""
+        return np.asfortranarray(np.stack([np.asarray(getattr(self, k), np.float32).reshape(-1) for k in self._names], axis=1))
+
+    def set_matrix(self, a):
+        for i, k in enumerate(self._names):
+            setattr(self, k, np.asfortranarray(np.asarray(a, np.float32)[:, i].reshape(-1, 1)))
+
+    @classmethod
+    def from_dict(cls, setup, d):
+        o = cls(setup)
+        for k in cls._names:
+            if k in d:
+                setattr(o, k, np.asfortranarray(np.asarray(d[k], np.float32).reshape(-1, 1)))
+        return o
+
+
+class Hyper_ParametersDT(_HyperFields):
+    _names = PARAM_NAMES
+
+
+class Hyper_StatesDT(_HyperFields):
+    _names = STATE_NAMES
 
 
 class OutputDT:

@@ -25,7 +25,7 @@ build)
   (cd "$W" && patch -p1 -s < "$OLDPWD/tools/anatomy/timing_switches.patch") || { echo "timing_switches.patch does not apply"; exit 1; }
   n=0
   for k in "${!V[@]}"; do
-    /opt/rocm/bin/hipcc $F ${V[$k]} -o variants/lib_$k.so "$W"/smash_amd/csrc/smashx.hip "$W"/smash_amd/csrc/sx_plan.cpp "$W"/smash_amd/csrc/sx_lbfgsb.cpp -pthread -ldl 2>/dev/null &
+    /opt/rocm/bin/hipcc $F ${V[$k]} -o variants/lib_$k.so "$W"/smash_amd/csrc/smashx.hip "$W"/smash_amd/csrc/sx_plan.cpp "$W"/smash_amd/csrc/sx_lbfgsb.cpp "$W"/smash_amd/csrc/sx_hyper.cpp -pthread -ldl 2>/dev/null &
     n=$((n+1)); if [ $((n % 4)) -eq 0 ]; then wait; fi
   done
   wait; ls variants/*.so ;;
