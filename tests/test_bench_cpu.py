@@ -56,9 +56,28 @@ def test_pmc_profile_is_matched_to_the_workload():
 def test_default_single_gpu_workload_is_the_largest_configuration():
     import bench
     a = bench.parse([])
-    assert a.gpus == 1 and a.grid == 0 and a.secondary_grid == 1024
+    assert a.gpus == 1 and a.grid == 0 and a.secondary_grid == 1024 and a.mesh == "synth"
+    assert not (a.no_forward_only or a.no_real_d8 or a.no_exact)          # the line carries configs[1], the real river network, the exact build
     p = bench.parse(["--profile"])
-    assert p.no_secondary and p.no_tile_solo and p.no_exact and p.no_cpu_baseline and p.no_inclusive
+    assert p.no_secondary and p.no_tile_solo and p.no_exact and p.no_cpu_baseline and p.no_inclusive and p.no_forward_only and p.no_real_d8
+
+
+def test_forward_only_runs_find_their_own_counter_file():
+    """The forward-only case (BASELINE.json configs[1]) has its own PMC passes: the untaped forward kernel of a forward sweep is not
+    priced with the traffic of the taped one of an adjoint sweep (and the other way round)."""
+    import bench
+    src, prof = bench.pmc_profile([1024, 1024], 1, forward_only=True)
+    assert src is not None and "forward_only" in src and "sx_k_vert_fwd_untaped" in prof and "sx_k_vert_adj" not in prof
+    src2, prof2 = bench.pmc_profile([1024, 1024], 1)
+    assert src2 != src and "sx_k_vert_adj" in prof2
+    cs = 1024.0 * 1024 * 8760
+    tm = {"vert_fwd_ms": 30.0, "route_fwd_ms": 17.0, "route_adj_ms": 0.0, "vert_adj_ms": 0.0, "sweep_ms": 48.0,
+          "vert_fwd_launches": 1, "route_fwd_launches": 2, "route_adj_launches": 0, "vert_adj_launches": 0,
+          "vert_fwd_cellsteps": cs, "route_fwd_cellsteps": cs, "route_adj_cellsteps": 0.0, "vert_adj_cellsteps": 0.0, "n_chunks": 1}
+    r = bench.roofline(tm, False, "gr-b", [1024, 1024])
+    assert r["kernel"] == "sx_k_vert_fwd" and abs(r["algorithmic_bytes_per_launch"] - 8 * cs) < 8       # 8 B per cell-step: prcp + pet once
+    assert r["traffic"] is not None and 5.5 * cs < r["traffic"] < 7.0 * cs                                 # the compact forcing + qt: 6.2 B moved
+    assert abs(r["sweep_frac"] - 8 * cs / 48e-3 / 1e9 / 8000.0) < 1e-9
 
 
 def test_bench_self_launch_reaches_the_rendezvous_without_a_gpu():
