@@ -192,3 +192,26 @@ def test_reference_optimize_lbfgsb_on_the_library_setulb():
         r = refbind.run("gr-b", g.mesh, g.dt, g.prcp, g.pet, z["qobs"], P, S, optimize_maxiter=int(it),
                         optim_parameters=z["optim_parameters"], jobs_fun=("nse",), wjobs_fun=(1.0,), fast="ref_lbfgsb")
         assert np.float32(r["cost"]) == np.float32(ref), (int(it), r["cost"], float(ref))
+
+
+def test_oracle_is_bit_identical_to_the_reference_on_a_real_river_network():
+    """The oracle's pin so far is the 18 golden cases (grids up to 64 x 64).  Here: the largest basin of the reference's own 1-km D8 raster
+    of France (139 742 cells, all eight codes; tests/golden/mesh/france_d8.npz -> synth.make_mesh_france), 48 steps, gr-b -- the compiled
+    reference (oracle/_ref/libsmash_ref.so, built in place by oracle/ref/build_ref.sh) against the C restatement, forward and adjoint,
+    bit for bit.  tests/test_gpu_parity.py::test_real_river_network_vs_oracle then holds the GPU to the oracle on the same network."""
+    from oracle import refbind
+    from smash_amd import synth
+    if not refbind.available():
+        pytest.skip("oracle/_ref/libsmash_ref.so not built (needs /root/reference and flang)")
+    m = synth.make_mesh_france(1, ng=4)
+    nt = 48
+    prcp, pet = synth.dense_forcing(m, nt, gap_per_million=2000)
+    P, S = synth.make_parameters(m.nrow, m.ncol), synth.make_states(m.nrow, m.ncol, warm=True)
+    qobs = np.asfortranarray(np.abs(np.random.default_rng(5).standard_normal((m.ng, nt))).astype(np.float32) + 0.1)
+    ref = refbind.run("gr-b", m, 3600.0, prcp, pet, qobs, P, S, adjoint=True)
+    orc = pyoracle.run("gr-b", m, 3600.0, prcp, pet, qobs, P, S, adjoint=True)
+    assert np.array_equal(ref["qsim"], orc["qsim"]) and np.float32(ref["cost"]) == np.float32(orc["cost"])
+    for k in gu.STRUCT_PARAMS["gr-b"]:
+        assert np.array_equal(ref["parameters_b"][k], orc["parameters_b"][k]), k
+    for k in gu.STRUCT_STATES["gr-b"]:
+        assert np.array_equal(ref["states_b"][k], orc["states_b"][k]), k
