@@ -344,6 +344,9 @@ struct smashx_plan {
     int Tp = 0;                      // pipeline sub-chunk length inside a storage chunk
     bool hi_tape = true;             // gr-b / gr-c: full tape of the interception level (false: sparse checkpoints, rebuilt in the reverse kernel)
     int chain_from = 1;              // first chained round
+    // staging rows of the chained groups (sx_kernels.h "Staging rows"): tables of the transposition kernels, rows beyond the time blocks,
+    // LDS of a wave-block's FIFOs; SMASHX_CHAIN_STAGE=0 keeps the plain rows (A/B)
+    bool chain_stage = true; SxStageTables stg{}; int stg_blocks = 0, stg_rows_extra = 0; size_t stg_lds = 0;
     size_t vlds_fwd = 0, vlds_adj = 0;   // experiments only (SMASHX_DEBUG_VLDS = n or nfwd,nadj): bytes of unused dynamic LDS per vertical workgroup, which
                                      // caps the vertical workgroups resident on a compute unit (occupancy experiments)
     std::vector<hipEvent_t> buf_free;    // per pipeline sub-chunk: the R stream has finished with this part of the chunk buffers
@@ -499,7 +502,8 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
             size_t fr = 0, tot = 0;
             HIPCHK(hipMemGetInfo(&fr, &tot));
             const double avail = (double)fr * 0.85 - 1.0e9;
-            auto fit = [&](double nt_) { return (long)(avail / (4.0 * ((double)p->npad * (2 + nt_) + (double)std::max(p->sch.nxslots, 1)))) / 16 * 16; };
+            // floats per time step: qt, hr_imd and the taped levels of every cell, the exchange series, the staging rows of the chained groups
+            auto fit = [&](double nt_) { return (long)(avail / (4.0 * ((double)p->npad * (2 + nt_) + (double)std::max(p->sch.nxslots, 1) + (double)p->A.ncs))) / 16 * 16; };
             long t = fit(ntape_full);
             if (has_hi && t < nt16) {
                 // Dropping the hi tape costs the reverse kernel ~14 % (levels rebuilt block by block: 78.5 against 69 ms per 9.2e9
@@ -535,6 +539,9 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
         int rc;
         if ((rc = p->dmalloc(&p->A.qtT, (size_t)p->npad * Tc))) return rc;
         if ((rc = p->dmalloc(&p->A.xT, (size_t)std::max(p->sch.nxslots, 1) * Tc))) return rc;
+        if (p->A.ncs > 0) {       // staging rows of the chained groups: [Tc / 4 + deepest chained group + 1][ncs] float4
+            if ((rc = p->dmalloc(&p->A.qsk, (size_t)p->A.ncs * 4 * ((size_t)Tc / 4 + p->stg_rows_extra + 1)))) return rc;
+        }
         HIPCHK(hipMemsetAsync(p->A.qtT, 0, (size_t)p->npad * Tc * 4, p->stream));
         HIPCHK(hipMemsetAsync(p->A.xT, 0, (size_t)std::max(p->sch.nxslots, 1) * Tc * 4, p->stream));
         p->chunk_ready = true;
@@ -582,6 +589,7 @@ SxDeviceArrays view_at(const smashx_plan* p, int off) {
     B.qtT = p->A.qtT + q * p->npad * 4;
     if (p->A.hrT) B.hrT = p->A.hrT + q * p->npad * 4;
     if (p->A.qdT) B.qdT = p->A.qdT + q * p->npad * 4;
+    if (!p->chain) B.qsk = nullptr;      // the launch-per-round fallback reads and writes the plain rows
     B.xT = p->A.xT + q * p->A.nx * 4;
     if (p->A.qtdT) B.qtdT = p->A.qtdT + q * p->npad * 4;      // tangent sweep (smashx_forward_d)
     if (p->A.xdT) B.xdT = p->A.xdT + q * p->A.nx * 4;
@@ -687,6 +695,8 @@ void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStr
     const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
     reset_chain_counters(p, st);
     const int grid = g1 - g0;
+    if (B.qsk)       // the chained groups' inputs -- their cells' runoff, the series handed up to them -- into the staging rows
+        hipLaunchKernelGGL((sx_k_chain_transpose<true>), dim3(p->stg_blocks), dim3(64), p->stg_lds, st, B, p->stg, g0, (T + SX_BT - 1) / SX_BT);
     p->mark_begin(5, st, round_cells(p, cf, nr) * T);
     if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
     else      hipLaunchKernelGGL((sx_k_route_fwd<false, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
@@ -711,6 +721,9 @@ void route_adj_chained(smashx_plan* p, int off, int t0, int T, hipStream_t st) {
     p->mark_begin(6, st, round_cells(p, cf, nr) * T);
     hipLaunchKernelGGL((sx_k_route_adj<true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
     p->mark_end();
+    if (B.qsk)       // qt_b of the chained cells and the adjoint series that leave the chain: from the staging rows to where the vertical kernel,
+                     // round 0 and the exchange expect them
+        hipLaunchKernelGGL((sx_k_chain_transpose<false>), dim3(p->stg_blocks), dim3(64), p->stg_lds, st, B, p->stg, g0, (T + SX_BT - 1) / SX_BT);
     p->chain_used = true;
 }
 void route_adj_rounds(smashx_plan* p, int off, int t0, int T, hipStream_t st) {
@@ -880,6 +893,43 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
                 for (int q = p->sch.g_slot_begin[g]; q < p->sch.g_slot_begin[g + 1]; ++q) p->round_ncells[r] += p->sch.s_cell[q] >= 0;
         const char* cfm = getenv("SMASHX_CHAIN_FROM");
         p->chain_from = cfm ? std::max(0, atoi(cfm)) : 1;
+        {   // staging rows of the chained groups: wave-blocks of 64 consecutive slots of one group, FIFO offsets per slot and direction
+            A.qsk = nullptr; A.cs0 = 0; A.ncs = 0;
+            if (const char* cs = getenv("SMASHX_CHAIN_STAGE")) p->chain_stage = atoi(cs) != 0;
+            const int cf = chain_first(p);
+            if (p->chain_stage && cf < p->sch.nrounds) {
+                const int gc = p->sch.round_group_begin[cf];
+                const int cs0 = p->sch.g_slot_begin[gc], ncs = p->sch.nslots - cs0;
+                std::vector<int> slot0, cnt, smn, spr, fg((size_t)std::max(ncs, 1), 0), fs((size_t)std::max(ncs, 1), 0);
+                size_t lds = 0;
+                int extra = 0;
+                for (int g = gc; g < p->sch.ngroups; ++g) {
+                    extra = std::max(extra, p->sch.g_dmax[g]);
+                    const int sb = p->sch.g_slot_begin[g], m = p->sch.g_slot_begin[g + 1] - sb;
+                    for (int o = 0; o < m; o += 64) {
+                        const int nl = std::min(64, m - o);
+                        int lo = INT_MAX, hi = 0;
+                        for (int q = sb + o; q < sb + o + nl; ++q) { lo = std::min(lo, p->sch.s_stage[q]); hi = std::max(hi, p->sch.s_stage[q]); }
+                        size_t og = 0, os = 0;
+                        for (int q = sb + o; q < sb + o + nl; ++q) {
+                            const int d = p->sch.s_stage[q] - lo;
+                            fg[q - cs0] = (int)og; og += (size_t)d + 1;
+                            fs[q - cs0] = (int)os; os += (size_t)(hi - lo - d) + 1;
+                        }
+                        lds = std::max(lds, std::max(og, os) * sizeof(float4));
+                        slot0.push_back(sb + o); cnt.push_back(nl); smn.push_back(lo); spr.push_back(hi - lo);
+                    }
+                }
+                if (lds <= 64 * 1024 && !slot0.empty()) {      // (a schedule whose wave-blocks span more stages than that keeps the plain rows)
+                    int *d0, *d1, *d2, *d3, *d4, *d5;
+                    TRY(p->upload_vec(&d0, slot0)); TRY(p->upload_vec(&d1, cnt)); TRY(p->upload_vec(&d2, smn)); TRY(p->upload_vec(&d3, spr));
+                    TRY(p->upload_vec(&d4, fg)); TRY(p->upload_vec(&d5, fs));
+                    p->stg = SxStageTables{d0, d1, d2, d3, d4, d5};
+                    p->stg_blocks = (int)slot0.size(); p->stg_rows_extra = extra; p->stg_lds = lds;
+                    A.cs0 = cs0; A.ncs = ncs;
+                }
+            }
+        }
         A.spin_limit = SX_SPIN_LIMIT; A.mute_group = -1;
         if (const char* sl = getenv("SMASHX_SPIN_LIMIT")) A.spin_limit = std::max(1, atoi(sl));
         if (const char* mg = getenv("SMASHX_DEBUG_MUTE_GROUP")) A.mute_group = atoi(mg);     // tests of the stall path only

@@ -201,6 +201,9 @@ struct SxDeviceArrays {
     float *tape_hi, *tape_hp, *tape_hft, *tape_hst;
     float* ckpt_hi;               // gr-b / gr-c: hi at every SX_HIK-th step of the chunk, [Tc / SX_HIK][npad] (tape_hi: vic-a only)
     float* xT;                    // exchange series
+    // staging rows of the chained groups ("Staging rows" below): [time block + stage][chained slot] float4, null = off.  cs0 = first slot
+    // of the first chained group, ncs = slots of the chained groups
+    float* qsk; int cs0, ncs;
     // gauges
     float *qg, *qgb;              // [ngc][nt] discharge at gauge cells / adjoint seeds
     int* cell_gauge;              // [npad] gauge-cell id or -1
@@ -215,6 +218,83 @@ struct SxDeviceArrays {
     int mute_group;               // tests only (SMASHX_DEBUG_MUTE_GROUP): this group never publishes -> its consumers stall; -1 = none
     long long* gtime;             // diagnostics (SMASHX_TRACE_GROUPS=1): [2 passes][ngroups][start, end] wall_clock64 ticks, else null
 };
+
+// ------------------------------------------------------------------------------------------------
+// Staging rows of the chained groups.  The groups of the rounds >= 1 are the river's main stems: a few workgroups whose super-step
+// is a latency chain, and every memory instruction in it whose 64 lanes touch 64 different lines (slots of one wave sit at different
+// stages, hence in different rows of the time-major arrays) costs that chain a full pass through the CU's memory path (DESIGN.md 12,
+// anatomy of a super-step).  Round 2 cured the routing tape of that -- row = time block + stage, so a group's super-step touches one
+// row.  qt / qt_b and the exchange series are shared with the vertical kernels and round 0, which want the plain rows, so the chained
+// launches get a copy in that layout: qsk [time block + stage][chained slot].  The copy is a transposition, and it only pays if BOTH
+// of its sides move whole rows (three earlier variants whose scattered side touched one 16-byte piece per row and lane ran at 0.85
+// TB/s and cost more than the chained launches gained; a vertical kernel whose wavefronts store to 20 rows at once is four times
+// slower: DESIGN.md 12).  Hence: one WAVEFRONT owns 64 consecutive slots of a group for all time blocks; per iteration it loads ONE
+// plain row piece (the cells of consecutive slots are consecutive: up to 1 KiB contiguous), pushes each lane's float4 into that
+// lane's own FIFO in LDS -- as deep as the lane's stage is above the lowest stage of the 64 -- and stores ONE staging row piece from
+// the FIFO heads (1 KiB contiguous).  A lane only ever touches its own FIFO: no barrier, no cross-lane traffic.  The reverse sweep
+// runs the mirror image (sx_k_chain_scatter): qt_b of the chained cells and the adjoint series of their inlets leave the staging rows
+// for qtT / xT.  Series between two chained groups (produced and consumed inside the launch, behind the counters) keep their plain rows.
+// Tables (host, smashx.hip): per wave-block the first slot, the slot count, the lowest stage and the stage spread; per chained slot
+// the offset of its FIFO in the block's LDS for each direction.
+// ------------------------------------------------------------------------------------------------
+struct SxStageTables {
+    const int* wb_slot0; const int* wb_n; const int* wb_smin; const int* wb_spread;   // per wave-block
+    const int* fifo_g; const int* fifo_s;                                               // per chained slot: FIFO offset (float4) for gather / scatter
+};
+#define SX_STG_PF 16         // rows requested ahead of the one being pushed (the loop is a latency chain: its pace is the load latency / this)
+template <bool GATHER>
+__global__ __launch_bounds__(64) void sx_k_chain_transpose(SxDeviceArrays A, SxStageTables S, int g0, int nb) {
+    extern __shared__ __attribute__((aligned(16))) float4 sx_fifo[];
+    const int b = blockIdx.x, L = threadIdx.x;
+    const int nL = S.wb_n[b], smin = S.wb_smin[b], spread = S.wb_spread[b];
+    const bool lane = L < nL;
+    const int sl = S.wb_slot0[b] + (lane ? L : 0), cs = sl - A.cs0;
+    const int c = lane ? A.s_cell[sl] : INT_MIN;
+    // what this slot keeps in the plain arrays: its cell's row of qtT, or the row of a series that crosses the chain's boundary (handed up by
+    // a round below the chain or by another rank; in the reverse sweep: handed back).  Series between chained groups and holes: nothing.
+    float4* plain = nullptr; size_t pstride = 0;
+    if (c >= 0) { plain = reinterpret_cast<float4*>(A.qtT) + c; pstride = (size_t)A.npad; }
+    else if (c != INT_MIN && A.x_prod[-1 - c] < g0) { plain = reinterpret_cast<float4*>(A.xT) + (-1 - c); pstride = (size_t)A.nx; }
+    const int d = lane ? A.s_stage[sl] - smin : 0;              // rows this slot's staging row runs ahead of the block's lowest
+    const int delay = GATHER ? d : spread - d, depth = delay + 1;
+    float4* fifo = sx_fifo + (lane ? (GATHER ? S.fifo_g[cs] : S.fifo_s[cs]) : 0);
+    float4* stag = reinterpret_cast<float4*>(A.qsk) + cs;       // + row * ncs
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int niter = nb + spread;
+    // GATHER: iteration i pushes plain row i and emits staging row i + smin (this lane's part of it is its block i - d);
+    // else:   iteration i pushes staging row i + smin (this lane's block i - d) and emits plain row i - spread
+    auto request = [&](int i) -> float4 {
+        if (!lane) return zero4;
+        if (GATHER) return (plain && i < nb) ? sx_gload4(plain + (size_t)i * pstride) : zero4;
+        return (i - d >= 0 && i - d < nb) ? sx_gload4(stag + (size_t)(i + smin) * A.ncs) : zero4;
+    };
+    float4 pf[SX_STG_PF];
+#pragma unroll
+    for (int u = 0; u < SX_STG_PF; ++u) pf[u] = request(u);
+    int wpos = 0, rpos = delay == 0 ? 0 : 1 % depth;            // the entry pushed `delay` iterations ago sits one past the write position
+    for (int i0 = 0; i0 < niter; i0 += SX_STG_PF) {
+#pragma unroll
+        for (int u = 0; u < SX_STG_PF; ++u) {
+            const int i = i0 + u;
+            float4 v = pf[u];
+            sx_pin(v);
+            pf[u] = request(i + SX_STG_PF);
+            if (i < niter && lane) {
+                fifo[wpos] = v;
+                const float4 o = fifo[rpos];                    // (delay 0: the entry just written)
+                wpos = wpos + 1 == depth ? 0 : wpos + 1;
+                rpos = rpos + 1 == depth ? 0 : rpos + 1;
+                if (GATHER) {
+                    const int tb = i - d;
+                    sx_gstore4(stag + (size_t)(i + smin) * A.ncs, (tb >= 0 && tb < nb) ? o : zero4);
+                } else {
+                    const int tb = i - spread;
+                    if (plain && tb >= 0) sx_gstore4(plain + (size_t)tb * pstride, o);
+                }
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // per-cell invariants of the routing operators (md_routing_operator.f90:55-56,75; LINEAR_ROUTING_B
@@ -681,10 +761,13 @@ __device__ __forceinline__ void sx_route_fwd_group(const SxDeviceArrays& A, cons
     const int* wprog = nullptr;
     int seen = 0;
     if (CHAIN && xin >= 0) { const int pg = A.x_prod[xin]; if (pg >= g0 && pg < gend) wprog = A.prog + pg; }
+    // chained rounds: everything else a slot reads waits in the staging rows ("Staging rows" above), row = time block + stage
+    const bool staged = CHAIN && !TAN && A.qsk != nullptr && valid && !wprog;
     // T4 addressing: element (tb, id) of an array with `stride` float4 per time block
-    const float4* src = (cell >= 0) ? reinterpret_cast<const float4*>(TAN ? A.qtdT : A.qtT) + cell
+    const float4* src = staged ? reinterpret_cast<const float4*>(A.qsk) + (size_t)stage * A.ncs + (sb + j - A.cs0)
+                      : (cell >= 0) ? reinterpret_cast<const float4*>(TAN ? A.qtdT : A.qtT) + cell
                                     : reinterpret_cast<const float4*>(TAN ? A.xdT : A.xT) + (xin >= 0 ? xin : 0);
-    const size_t sstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
+    const size_t sstride = staged ? (size_t)A.ncs : (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
     float4* x4 = reinterpret_cast<float4*>(TAN ? A.xdT : A.xT);
     float4* hr4 = reinterpret_cast<float4*>(A.hrT);
     // hr_imd tape, private to the routing kernels: row = time block + stage, so the slots of a group -- which work on time block
@@ -908,8 +991,13 @@ __device__ __forceinline__ void sx_route_adj_group(const SxDeviceArrays& A, cons
     // where a slot's result goes: qt_b of its cell, or -- inlet -- the adjoint series of the subtree upstream.  ONE store instruction
     // for both kinds (per-lane base and row stride): in the chained rounds, where a third of the slots are inlets, the second store
     // instruction of a super-step cost as much as the first whatever its lane count (anatomy of the reverse launch)
-    float4* const dst = (cell >= 0) ? qt4 + cell : x4 + (xin >= 0 ? xin : 0);
-    const size_t dstride = (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
+    // chained rounds: qt_b of the cells and the adjoint series that leave the chain go to the staging rows (row = time block + stage: one
+    // row per reverse super-step of the group; sx_k_chain_transpose<false> puts them in place) -- not the adjoint series of an inlet whose
+    // subtree upstream is routed inside this launch
+    const bool staged = CHAIN && A.qsk != nullptr && valid && (cell >= 0 || (xin >= 0 && !(A.x_prod[xin] >= g0 && A.x_prod[xin] < gend)));
+    float4* const dst = staged ? reinterpret_cast<float4*>(A.qsk) + (size_t)(dmax - rstage) * A.ncs + (sb + j - A.cs0)
+                               : (cell >= 0) ? qt4 + cell : x4 + (xin >= 0 ? xin : 0);
+    const size_t dstride = staged ? (size_t)A.ncs : (cell >= 0) ? (size_t)A.npad : (size_t)A.nx;
 
     // gauge cells also fetch their adjoint seeds (qsim_b summed per cell) with the staged loads, so the
     // super-step loop itself contains no global memory operation and no vmcnt wait

@@ -128,6 +128,24 @@ def test_chunking_and_grouping_do_not_change_results(name, chunk, pipe, group):
         assert np.array_equal(getattr(ref[4], k), getattr(alt[4], k)), k
 
 
+@pytest.mark.parametrize("name,chunk,pipe,group", [("gr_c_32x32x240_d8_ragged", 96, 16, 64), ("gr_b_64x64x720_nse", 240, 48, 128), ("vic_a_24x24x240_d8_kge", 64, 32, 64),
+                                                   ("gr_b_20x20x96_d8", 0, 0, 64), ("gr_b_64x64x720_nse", 0, 0, 512)])
+def test_staging_rows_of_the_chained_groups_equal_the_plain_rows(name, chunk, pipe, group, monkeypatch):
+    """The chained routing launches read their inputs from -- and, in the reverse sweep, write their results to -- staging rows indexed
+    by time block + stage, filled and emptied by the LDS-FIFO transposition passes (sx_k_chain_transpose, sx_kernels.h "Staging rows"):
+    a change of addresses only.  Every output bit-identical with SMASHX_CHAIN_STAGE=0, across storage chunks, sub-chunks and group sizes."""
+    g = gu.load(name)
+    monkeypatch.setenv("SMASHX_CHAIN_STAGE", "0")
+    ref = _run_adjoint(g, chunk_steps=chunk, pipe_steps=pipe, group_size=group)
+    monkeypatch.setenv("SMASHX_CHAIN_STAGE", "1")
+    alt = _run_adjoint(g, chunk_steps=chunk, pipe_steps=pipe, group_size=group)
+    assert np.array_equal(ref[2].qsim, alt[2].qsim) and ref[2].cost == alt[2].cost
+    for k in gu.STRUCT_PARAMS[g.structure]:
+        assert np.array_equal(getattr(ref[3], k), getattr(alt[3], k)), k
+    for k in gu.STRUCT_STATES[g.structure]:
+        assert np.array_equal(getattr(ref[4], k), getattr(alt[4], k)), k
+
+
 @pytest.mark.parametrize("name,chunk,pipe", [("gr_b_20x20x96_d8", 0, 0), ("gr_c_32x32x240_d8_ragged", 48, 16), ("vic_a_24x24x240_d8_kge", 64, 32)])
 def test_routing_tape_indexed_by_super_step_equals_rows_of_time_blocks(name, chunk, pipe, monkeypatch):
     """The hr_imd tape of the routing kernels is indexed by time block + the slot's stage (one row per super-step and group,
