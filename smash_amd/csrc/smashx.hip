@@ -346,7 +346,7 @@ struct smashx_plan {
     int chain_from = 1;              // first chained round
     // staging rows of the chained groups (sx_kernels.h "Staging rows"): tables of the transposition kernels, rows beyond the time blocks,
     // LDS of a wave-block's FIFOs; SMASHX_CHAIN_STAGE=0 keeps the plain rows (A/B)
-    bool chain_stage = true; SxStageTables stg{}; int stg_blocks = 0, stg_rows_extra = 0; size_t stg_lds = 0;
+    bool chain_stage = false; SxStageTables stg{}; int stg_blocks = 0, stg_rows_extra = 0; size_t stg_lds = 0;
     size_t vlds_fwd = 0, vlds_adj = 0;   // experiments only (SMASHX_DEBUG_VLDS = n or nfwd,nadj): bytes of unused dynamic LDS per vertical workgroup, which
                                      // caps the vertical workgroups resident on a compute unit (occupancy experiments)
     std::vector<hipEvent_t> buf_free;    // per pipeline sub-chunk: the R stream has finished with this part of the chunk buffers
@@ -895,8 +895,17 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
         p->chain_from = cfm ? std::max(0, atoi(cfm)) : 1;
         {   // staging rows of the chained groups: wave-blocks of 64 consecutive slots of one group, FIFO offsets per slot and direction
             A.qsk = nullptr; A.cs0 = 0; A.ncs = 0;
-            if (const char* cs = getenv("SMASHX_CHAIN_STAGE")) p->chain_stage = atoi(cs) != 0;
             const int cf = chain_first(p);
+            {   // The copy pays where the chained launch is bound by its memory instructions: several waves of groups per compute unit
+                // (2048^2: 1293 groups, sweep -12 ms).  A launch the device holds at once is bound by the latency of its chain of stages
+                // instead, gains less than the two passes cost (1024^2: 316 groups, chained launches -5 ms, passes +6.5 ms) and keeps the
+                // plain rows.  SMASHX_CHAIN_STAGE=0/1 overrides.
+                int dev = 0, cus = 256;
+                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                const int nchained = cf < p->sch.nrounds ? p->sch.ngroups - p->sch.round_group_begin[cf] : 0;
+                p->chain_stage = nchained >= 2 * cus;
+                if (const char* cs = getenv("SMASHX_CHAIN_STAGE")) p->chain_stage = atoi(cs) != 0;
+            }
             if (p->chain_stage && cf < p->sch.nrounds) {
                 const int gc = p->sch.round_group_begin[cf];
                 const int cs0 = p->sch.g_slot_begin[gc], ncs = p->sch.nslots - cs0;
@@ -2382,6 +2391,7 @@ int smashx_forward_d(smashx_plan* p, smashx_parameters* params, const smashx_par
             for (int off = 0; off < Tcur; off += Tsub) {
                 const int T = std::min(Tsub, Tcur - off);
                 SxDeviceArrays Bt = view_at(p, off); Bt.qdT = nullptr;
+                Bt.qsk = nullptr;            // one launch per round: every series in its plain row
                 float* xarr = pass == 1 ? p->A.xT : p->A.xdT;
                 if (halo && p->n_in > 0) {
                     if ((rc = sx_halo_hook(p, native, 0, t0c + off, T, sR))) return rc;
