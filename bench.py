@@ -426,7 +426,7 @@ def attached_case(a, torch, dev, local, barrier, adjoint, grid_rc, parts, me, so
              "ms_per_step": secs * 1e3 / steps, "grid": [c.nrow, c.ncol], "tile": list(grid_rc), "active_cells": int(c.sol.ncells),
              "n_chunks": int(tm["n_chunks"]), "chunk_steps": int(tm["chunk_steps"]), "pipe_steps": int(tm["pipe_steps"]),
              "routing_rounds": int(tm["n_rounds"]), "routing_groups": int(tm["n_groups"]), "deepest_group_stages": int(tm["max_stage"]),
-             "chained_groups": int(tm["n_chained_groups"]),
+             "chained_groups": int(tm["n_chained_groups"]), "chained_groups_staged": bool(tm["chain_staged"]),
              "chained_launch_ms_per_step": {"forward": round(tm["route_fwd_chained_ms"], 3), "reverse": round(tm["route_adj_chained_ms"], 3),
                                             "launches": int(tm["route_fwd_chained_launches"] + tm["route_adj_chained_launches"])},
              "hbm_plan_gb": tm["device_bytes"] / 1e9,
@@ -561,7 +561,7 @@ def main():
                        "grid": [nrow, ncol], "tile": [trows, tcols], "nt": nt, "structure": a.structure, "active_cells": int(cellsteps / nt),
                        "chunk_steps": int(tm["chunk_steps"]), "n_chunks": int(tm["n_chunks"]), "pipe_steps": int(tm["pipe_steps"]),
                        "routing_rounds": int(tm["n_rounds"]), "routing_groups": int(tm["n_groups"]), "deepest_group_stages": int(tm["max_stage"]),
-                       "chained_groups": int(tm["n_chained_groups"]), "mesh": a.mesh,
+                       "chained_groups": int(tm["n_chained_groups"]), "chained_groups_staged": bool(tm["chain_staged"]), "mesh": a.mesh,
                        "forcing": case.forcing,
                        "parallelism": (f"rank {me} of {parts} alone ({a.partition}), no-op exchange" if solo else
                                        ((f"tiles {pr}x{pc}" if a.partition == "rect" else f"{parts} {a.partition} parts of the river tree") +

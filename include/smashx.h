@@ -117,6 +117,8 @@ typedef struct {
     int   route_fwd_chained_launches, route_adj_chained_launches;
     int   max_stage;         /* stages of the deepest routing group (the fill of a routing launch, in super-steps) */
     int   n_chained_groups;  /* groups of the chained rounds */
+    int   chain_staged;      /* 1: the chained launches read and write staging rows through the copy passes (their time is part of
+                                route_*_chained_ms), 0: the plain rows */
 } smashx_timing;
 
 typedef struct smashx_plan smashx_plan;
@@ -126,7 +128,7 @@ int smashx_device_count(void);
 /* ABI guard for bindings that mirror the structs by hand (the Fortran shim, ctypes): sizes in bytes of
  * {smashx_config, smashx_mesh, smashx_options, smashx_parameters, smashx_states, smashx_costs, smashx_timing};
  * returns SMASHX_ABI_VERSION. */
-#define SMASHX_ABI_VERSION 7
+#define SMASHX_ABI_VERSION 8
 int smashx_abi_sizes(int sizes[7]);
 
 /* builds the routing schedule from the mesh and allocates device storage */

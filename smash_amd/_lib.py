@@ -81,7 +81,7 @@ class Timing(C.Structure):
                 ("device_bytes", C.c_double), ("cellsteps", C.c_double * 4),
                 ("route_fwd_chained_ms", C.c_float), ("route_adj_chained_ms", C.c_float),
                 ("route_fwd_chained_launches", C.c_int), ("route_adj_chained_launches", C.c_int), ("max_stage", C.c_int),
-                ("n_chained_groups", C.c_int)]
+                ("n_chained_groups", C.c_int), ("chain_staged", C.c_int)]
 
 
 class SmashxError(RuntimeError):

@@ -695,9 +695,9 @@ void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStr
     const int g0 = p->sch.round_group_begin[cf], g1 = p->sch.ngroups;
     reset_chain_counters(p, st);
     const int grid = g1 - g0;
+    p->mark_begin(5, st, round_cells(p, cf, nr) * T);       // (the chained launch's time includes its copy pass)
     if (B.qsk)       // the chained groups' inputs -- their cells' runoff, the series handed up to them -- into the staging rows
         hipLaunchKernelGGL((sx_k_chain_transpose<true>), dim3(p->stg_blocks), dim3(64), p->stg_lds, st, B, p->stg, g0, (T + SX_BT - 1) / SX_BT);
-    p->mark_begin(5, st, round_cells(p, cf, nr) * T);
     if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
     else      hipLaunchKernelGGL((sx_k_route_fwd<false, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
     p->mark_end();
@@ -720,10 +720,10 @@ void route_adj_chained(smashx_plan* p, int off, int t0, int T, hipStream_t st) {
     const int grid = g1 - g0;
     p->mark_begin(6, st, round_cells(p, cf, nr) * T);
     hipLaunchKernelGGL((sx_k_route_adj<true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
-    p->mark_end();
     if (B.qsk)       // qt_b of the chained cells and the adjoint series that leave the chain: from the staging rows to where the vertical kernel,
                      // round 0 and the exchange expect them
         hipLaunchKernelGGL((sx_k_chain_transpose<false>), dim3(p->stg_blocks), dim3(64), p->stg_lds, st, B, p->stg, g0, (T + SX_BT - 1) / SX_BT);
+    p->mark_end();
     p->chain_used = true;
 }
 void route_adj_rounds(smashx_plan* p, int off, int t0, int T, hipStream_t st) {
@@ -1706,6 +1706,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
     tm.n_chunks = p->nchunks; tm.chunk_steps = p->Tc; tm.pipe_steps = p->Tp; tm.n_rounds = p->sch.nrounds; tm.n_groups = p->sch.ngroups;
     tm.device_bytes = p->bytes;
     tm.max_stage = p->sch.max_stage;
+    tm.chain_staged = (p->chain && p->A.qsk != nullptr) ? 1 : 0;
     tm.n_chained_groups = chain_first(p) < p->sch.nrounds ? p->sch.ngroups - p->sch.round_group_begin[chain_first(p)] : 0;
     p->last_adjoint = adjoint;
     return 0;

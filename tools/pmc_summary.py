@@ -64,6 +64,9 @@ families = {   # name -> (selector, cell-steps the family's dispatches processed
     "sx_k_route_fwd": (lambda k: k.startswith("sx_k_route_fwd<true"), total["taped_forward"]),
     "sx_k_route_fwd_untaped": (lambda k: k.startswith("sx_k_route_fwd<false"), total["untaped_forward"]),
     "sx_k_route_adj": (lambda k: k.startswith("sx_k_route_adj<"), total["reverse"]),
+    # the copy passes of the chained launches (staging rows): per cell-step of the WHOLE domain, like the routing families they belong to
+    "sx_k_chain_transpose_gather": (lambda k: k.startswith("sx_k_chain_transpose<true"), total["taped_forward"] + total["untaped_forward"]),
+    "sx_k_chain_transpose_scatter": (lambda k: k.startswith("sx_k_chain_transpose<false"), total["reverse"]),
 }
 out = {"workload": {"grid": acct["grid"], "n_chunks": acct["n_chunks"], "chunk_steps": acct["chunk_steps"], "cellsteps_per_sweep": acct["cellsteps"],
                     "adjoint_sweeps_profiled": nadj, "forward_sweeps_profiled": nfwd, "forward_only": nadj == 0, "config": bench.get("config", {}).get("workload")}}
