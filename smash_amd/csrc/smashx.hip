@@ -502,8 +502,9 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
             size_t fr = 0, tot = 0;
             HIPCHK(hipMemGetInfo(&fr, &tot));
             const double avail = (double)fr * 0.85 - 1.0e9;
-            // floats per time step: qt, hr_imd and the taped levels of every cell, the exchange series, the staging rows of the chained groups
-            auto fit = [&](double nt_) { return (long)(avail / (4.0 * ((double)p->npad * (2 + nt_) + (double)std::max(p->sch.nxslots, 1) + (double)p->A.ncs))) / 16 * 16; };
+            // floats per time step: qt, hr_imd and the taped levels of every cell, the exchange series (the staging rows of the chained
+            // groups are optional and come out of the reserve: below)
+            auto fit = [&](double nt_) { return (long)(avail / (4.0 * ((double)p->npad * (2 + nt_) + (double)std::max(p->sch.nxslots, 1)))) / 16 * 16; };
             long t = fit(ntape_full);
             if (has_hi && t < nt16) {
                 // Dropping the hi tape costs the reverse kernel ~14 % (levels rebuilt block by block: 78.5 against 69 ms per 9.2e9
@@ -539,9 +540,6 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
         int rc;
         if ((rc = p->dmalloc(&p->A.qtT, (size_t)p->npad * Tc))) return rc;
         if ((rc = p->dmalloc(&p->A.xT, (size_t)std::max(p->sch.nxslots, 1) * Tc))) return rc;
-        if (p->A.ncs > 0) {       // staging rows of the chained groups: [Tc / 4 + deepest chained group + 1][ncs] float4
-            if ((rc = p->dmalloc(&p->A.qsk, (size_t)p->A.ncs * 4 * ((size_t)Tc / 4 + p->stg_rows_extra + 1)))) return rc;
-        }
         HIPCHK(hipMemsetAsync(p->A.qtT, 0, (size_t)p->npad * Tc * 4, p->stream));
         HIPCHK(hipMemsetAsync(p->A.xT, 0, (size_t)std::max(p->sch.nxslots, 1) * Tc * 4, p->stream));
         p->chunk_ready = true;
@@ -553,6 +551,7 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
     if (adjoint && !p->adj_ready) {
         int rc;
         const size_t cs = (size_t)p->npad * p->Tc;
+        if (p->A.qsk) { p->dfree(p->A.qsk); p->A.qsk = nullptr; }      // (taken by a forward-only sweep before: the tapes go first)
         {   // the hr_imd tape is written and read by the routing kernels only: its rows are shifted by the cell's stage when the
             // extra rows (the deepest group's stages) fit beside everything else -- decided per plan, never changes results
             const size_t extra = (size_t)p->sch.max_stage * p->npad * 4;
@@ -577,6 +576,15 @@ int ensure_chunk_buffers(smashx_plan* p, bool adjoint) {
         if ((rc = p->dmalloc(&p->A.qgb, (size_t)std::max(p->ngc, 1) * p->nt))) return rc;
         if ((rc = p->dmalloc(&p->d_qsim_b, (size_t)std::max(p->ng, 1) * p->nt))) return rc;
         p->adj_ready = true;
+    }
+    if (p->A.ncs > 0 && !p->A.qsk) {
+        // staging rows of the chained groups, [Tc / 4 + deepest chained group + 1][ncs] float4: a copy that makes the chained launches
+        // faster, nothing depends on it -- it takes what the reserve holds once everything else is in place (2048^2: 7.4 GB of the
+        // 34 GB the chunk length leaves free) and is left out when that is not there (the chained launches keep the plain rows)
+        const size_t need = (size_t)p->A.ncs * 16 * ((size_t)p->Tc / 4 + p->stg_rows_extra + 1);
+        size_t fr = 0, tot = 0;
+        HIPCHK(hipMemGetInfo(&fr, &tot));
+        if ((double)fr > (double)need + 2.0e9) { int rc; if ((rc = p->dmalloc(&p->A.qsk, need / 4))) return rc; }
     }
     return 0;
 }
