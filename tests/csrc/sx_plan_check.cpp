@@ -4,6 +4,7 @@
  * appears in exactly one slot; a child is either in its parent's component (same stage, same wavefront, lower sub-level) or exactly
  * one stage below it; child lists and parent links agree; sub-levels stay below the limit and below the wavefront's count; rounds
  * only receive from earlier rounds; a group never exceeds group_size slots -- then prints a one-line summary. */
+#include <algorithm>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +80,30 @@ int main() {
     for (int x = 0; x < s.nxslots; ++x) {
         const int pg = s.x_prod_group[x], cg = s.x_cons_group[x];
         if (pg >= 0 && cg >= 0) REQUIRE(round_of_group[pg] < round_of_group[cg], "series flows to a later round");
+    }
+    // round 4: the series are numbered in the order of the inlets that read them -- walking the slots in order meets the series 0, 1, 2, ...
+    // (so the inlets of consecutive slots read one contiguous piece of a row of the exchange array); series without an inlet in this
+    // tile (they only leave it) come after all of those.  And the subtrees are packed in that order without giving up the fill.
+    {
+        int next = 0;
+        for (int q = 0; q < s.nslots; ++q) {
+            const int c = s.s_cell[q];
+            if (c >= 0 || c == INT_MIN) continue;
+            REQUIRE(-1 - c == next, "series numbered in the order of their inlets");
+            ++next;
+        }
+        for (int x = next; x < s.nxslots; ++x) REQUIRE(s.x_cons_group[x] < 0, "a series without inlet here is read by another tile only");
+        const int g0 = s.round_group_begin[0], g1 = s.round_group_begin[1];
+        const long slots0 = s.g_slot_begin[g1] - s.g_slot_begin[g0];
+        if (g1 - g0 >= 8) REQUIRE(slots0 >= (long)(0.95 * M) * (g1 - g0 - 1), "groups of round 0 at least 95 % full");
+        // the roots of a group publish within a window of a few times their number
+        long outs = 0, span = 0;
+        for (int g = g0; g < g1; ++g) {
+            int lo = INT_MAX, hi = -1, cnt = 0;
+            for (int q = s.g_slot_begin[g]; q < s.g_slot_begin[g + 1]; ++q) { const int x = s.s_xout[q]; if (x >= 0 && s.x_cons_group[x] >= 0) { lo = std::min(lo, x); hi = std::max(hi, x); ++cnt; } }
+            if (cnt) { outs += cnt; span += hi - lo + 1; }
+        }
+        if (outs >= 1000) REQUIRE(span <= 4 * outs, "the roots of a round-0 group publish next to each other");
     }
     REQUIRE(s.out_x.size() == s.out_src.size() && s.in_x.size() == s.in_src.size(), "edge lists");
     for (size_t i = 1; i < s.out_src.size(); ++i) REQUIRE(s.out_src[i - 1] < s.out_src[i], "out edges sorted by source");
