@@ -113,6 +113,25 @@ def test_tiled_sweep_equals_single_domain(world, chunk, pipe):
     _check_partitioned(_short("gr_b_64x64x720_nse", 96), world, chunk, pipe, None)
 
 
+@pytest.mark.parametrize("name,world,chunk,pipe,cut", [("gr_b_64x64x720_nse", 4, 32, 16, None), ("gr_b_64x64x720_nse", 2, 96, 32, None),
+                                                       ("gr_b_64x64x720_nse", 3, 32, 16, "sub"), ("gr_b_64x64x720_nse", 2, 96, 32, "trunk")])
+def test_tiles_with_staging_rows_equal_single_domain(name, world, chunk, pipe, cut, monkeypatch):
+    """A plan with many chained groups gives the chained launches their inputs in staging rows (sx_k_chain_transpose); small plans do not by
+    themselves.  Forced on (SMASHX_CHAIN_STAGE=1) over decompositions: the series received from other tiles -- inlets of chained groups
+    fed through the exchange rows, kept per storage chunk for the recomputation -- pass through the copy like the local ones, and the
+    adjoint series handed back leave through it.  Bit-identical to the single domain (which runs without them)."""
+    from smash_amd import tiles
+    g = _short(name, 96)
+    owner = None if cut is None else (tiles.partition_subcatchments(g.mesh, world) if cut == "sub" else tiles.partition_trunk(g.mesh, world))
+    ref = None
+    import test_gpu_parity
+    monkeypatch.setenv("SMASHX_CHAIN_STAGE", "0")
+    ref = test_gpu_parity._run_adjoint(g)
+    monkeypatch.setenv("SMASHX_CHAIN_STAGE", "1")
+    tm = _check_partitioned(g, world, chunk, pipe, owner, reference=ref, group_size=64)      # (small groups: several rounds even on a 32 x 32 tile)
+    assert any(t["chain_staged"] for t in tm.values()), "no part of this decomposition has chained rounds: the case tests nothing"
+
+
 @pytest.mark.parametrize("name,world,chunk,pipe,cut", [("gr_c_32x32x240_d8_ragged", 3, 96, 16, "sub"), ("gr_b_20x20x96_d8", 4, 32, 16, "sub"),
                                                        ("vic_a_24x24x240_d8_kge", 5, 96, 32, "sub"),
                                                        ("gr_c_32x32x240_d8_ragged", 4, 96, 16, "trunk"), ("gr_a_cance_28x28x1440", 3, 96, 32, "trunk")])
@@ -125,30 +144,30 @@ def test_subcatchment_partition_equals_single_domain(name, world, chunk, pipe, c
     _check_partitioned(g, world, chunk, pipe, owner)
 
 
-def _check_partitioned(g, world, chunk, pipe, owner, keep_opts=False):
+def _check_partitioned(g, world, chunk, pipe, owner, keep_opts=False, reference=None, group_size=128):
     import torch
     torch.zeros(1, device="cuda")                 # initialise torch's HIP context in the main thread
     import smash_amd
     from smash_amd import tiles
     from smash_amd.solver import Solver
     from test_gpu_parity import _run_adjoint
-    _, _, ref_out, ref_pb, ref_sb = _run_adjoint(g)
+    _, _, ref_out, ref_pb, ref_sb = reference if reference is not None else _run_adjoint(g)
     summer = _SumOverTiles(world)
     pr, pc = tiles.tile_grid(world)
     nrow, ncol = g.mesh.nrow, g.mesh.ncol
     box = {(a, b, k): queue.Queue() for a in range(world) for b in range(world) for k in "fa"}
-    res, errs = {}, []
+    res, errs, timings = {}, [], {}
 
     def run(rank):
         try:
             if owner is None:
                 rect = tiles.tile_rect(rank, nrow, ncol, pr, pc)
                 setup, mesh, loc = _tile_inputs(g, rect, g.mesh.ng)
-                sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=128, tile=rect)
+                sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=group_size, tile=rect)
             else:
                 mine = np.asarray(owner) == rank
                 setup, mesh, loc = _tile_inputs(g, None, g.mesh.ng, mine)
-                sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=128, owner_mask=mine)
+                sol = Solver(setup, mesh, chunk_steps=chunk, pipe_steps=pipe, group_size=group_size, owner_mask=mine)
                 assert sol.ncells == int(mine.sum())
             rows, cols = sol.cell_order()
             sol.set_forcing(g.prcp, g.pet)
@@ -171,6 +190,7 @@ def _check_partitioned(g, world, chunk, pipe, owner, keep_opts=False):
             sol.sweep(True, 1.0)
             sol.download(True, par, sta, out, pb, sb)
             res[rank] = (loc, out, pb, sb, rows, cols, ex.calls)
+            timings[rank] = sol.timing()
         except Exception as e:  # pragma: no cover
             import traceback
             traceback.print_exc()
@@ -203,6 +223,7 @@ def _check_partitioned(g, world, chunk, pipe, owner, keep_opts=False):
         _, _, pb0, sb0, _, _, _ = res[0]
         for k in gu.STRUCT_PARAMS[g.structure]:
             assert np.array_equal(getattr(pb0, k)[~owned], getattr(ref_pb, k)[~owned]), k
+    return timings
 
 
 def test_regularisation_on_tiles_equals_single_domain():
