@@ -30,10 +30,10 @@ CS = 9.185525760e9            # cell-steps of the 1024^2 x 8760 case: the unit t
 # measured kernel times, ms per CS cell-steps (profiles/r3_rocprofv3_kernel_stats_2048.csv: launches of 2192 steps x 4.19 M cells;
 # profiles/r2_rocprofv3_kernel_stats.csv for the store-all 1024^2 case)
 RATES = {
-    "vf_u": 28.6, "vf_t": 35.6, "va": 60.1,                  # vertical: forward untaped / taped, reverse (hi tape on) -- round 4 (profiles/r4_2048_kernel_stats.csv)
-    "r0f_u": 8.68, "r0f_t": 13.94, "r0a": 17.0,              # round 0 at 548 time blocks per launch (2048^2), forward untaped / taped, reverse
+    "vf_u": 27.1, "vf_t": 34.4, "va": 60.4,                  # vertical: forward untaped / taped, reverse (hi tape on) -- round 4, final schedule (profiles/r4_2048_kernel_stats.csv)
+    "r0f_u": 8.91, "r0f_t": 12.68, "r0a": 17.24,             # round 0 at 548 time blocks per launch (2048^2), forward untaped / taped, reverse
     "r0_nb_ref": 548, "r0_depth": 160,                       # ... whose groups are up to 160 stages deep: a launch of nb blocks runs nb + depth super-steps
-    "tau_f": 1.366e-3, "tau_a": 1.658e-3,                    # ms per super-step of a chained launch (2048^2: 8.3 / 10.1 ms for 548 blocks + 5530 stages)
+    "tau_f": 1.30e-3, "tau_a": 1.31e-3,                      # ms per super-step of a chained launch WITH its copy pass (2048^2: 4.88 + 3.05 / 5.16 + 2.82 ms for 548 blocks + 5530 stages)
     "path_per_side": 1.35,                                   # longest cell path of a tile ~ 1.35 x (rows + cols) stages (2900 at 1024^2, 5250 at 2048^2)
     # ... except where the chained launches of the very tile were timed (per-round timelines, --trace-groups): the 2048 x 1024 tile of
     # the 8-rank split has 7 routing rounds and its chained launch of a 1104-step sub-chunk takes 2.7 ms forward / 3.2 ms reverse
@@ -266,17 +266,17 @@ def sweep_ms(N, pr, pc, tile, nt, chunk, pipe, shared, p):
 
 # measurements the model is held to: (label, N, pr, pc, tile, chunk, pipe, shared GPU, measured ms, source)
 MEASURED = [
-    ("solo 2048x1024 tile, no sub-chunks", 1, 1, 1, (2048, 1024), 4384, 4384, True, 323.6, "profiles/r4_solo_p4384.json"),
-    ("solo 2048x1024 tile, sub-chunks of 2192", 1, 1, 1, (2048, 1024), 4384, 2192, True, 329.7, "profiles/r4_solo_p2192.json"),
-    ("solo 2048x1024 tile, sub-chunks of 1104", 1, 1, 1, (2048, 1024), 4384, 1104, True, 339.9, "profiles/r4_solo_p1104.json"),
-    ("2048^2 single domain, 4 storage chunks", 1, 1, 1, (2048, 2048), 2192, 2192, True, 710.6, "profiles/r4_bench_2048x2048x8760.json (699-715 across boxes)"),
-    ("1024^2 single domain, store-all", 1, 1, 1, (1024, 1024), 8768, 8768, True, 150.9, "profiles/r4_bench_2048x2048x8760.json (secondary)"),
-    ("rehearsal: 2 ranks on ONE GPU, 1x2 tiles of 1024x512", 2, 1, 2, (1024, 512), 8768, 2192, True, 156.3, "profiles/r4_reh2.json"),
-    ("rehearsal: 4 ranks on ONE GPU, 2x2 tiles of 512x512", 4, 2, 2, (512, 512), 8768, 2192, True, 157.5, "profiles/r4_reh4.json"),
-    ("rehearsal: 6 ranks on ONE GPU, 1x6 tiles of 1024x176", 6, 1, 6, (1024, 176), 8768, 1104, True, 260.6, "profiles/r4_reh6.json"),
+    ("solo 2048x1024 tile, no sub-chunks", 1, 1, 1, (2048, 1024), 4384, 4384, True, 323.4, "profiles/r4_solo_p4384_final_schedule.json"),
+    ("solo 2048x1024 tile, sub-chunks of 2192", 1, 1, 1, (2048, 1024), 4384, 2192, True, 325.1, "profiles/r4_solo_p2192_final_schedule.json"),
+    ("solo 2048x1024 tile, sub-chunks of 1104", 1, 1, 1, (2048, 1024), 4384, 1104, True, 336.0, "profiles/r4_solo_p1104_final_schedule.json"),
+    ("2048^2 single domain, 4 storage chunks", 1, 1, 1, (2048, 2048), 2192, 2192, True, 694.5, "profiles/r4_bench_2048x2048x8760.json (674-700 across boxes)"),
+    ("1024^2 single domain, store-all", 1, 1, 1, (1024, 1024), 8768, 8768, True, 149.7, "profiles/r4_bench_2048x2048x8760.json (secondary)"),
+    ("rehearsal: 2 ranks on ONE GPU, 1x2 tiles of 1024x512", 2, 1, 2, (1024, 512), 8768, 2192, True, 155.8, "profiles/r4_reh2_final_schedule.json"),
+    ("rehearsal: 4 ranks on ONE GPU, 2x2 tiles of 512x512", 4, 2, 2, (512, 512), 8768, 2192, True, 154.8, "profiles/r4_reh4_final_schedule.json"),
+    ("rehearsal: 6 ranks on ONE GPU, 1x6 tiles of 1024x176", 6, 1, 6, (1024, 176), 8768, 1104, True, 240.5, "profiles/r4_reh6_final_schedule.json"),
     # round 4: CHUNKED rehearsals (4 storage chunks: three of them recomputed in the reverse sweep -- without exchange since this round)
-    ("rehearsal: 2 ranks on ONE GPU, 1x2 tiles of 1024x512, 4 storage chunks", 2, 1, 2, (1024, 512), 2192, 1104, True, 204.1, "profiles/r4_reh2_chunked.json"),
-    ("rehearsal: 4 ranks on ONE GPU, 2x2 tiles of 512x512, 4 storage chunks", 4, 2, 2, (512, 512), 2192, 1104, True, 189.2, "profiles/r4_reh4_chunked.json"),
+    ("rehearsal: 2 ranks on ONE GPU, 1x2 tiles of 1024x512, 4 storage chunks", 2, 1, 2, (1024, 512), 2192, 1104, True, 198.4, "profiles/r4_reh2_chunked_final_schedule.json"),
+    ("rehearsal: 4 ranks on ONE GPU, 2x2 tiles of 512x512, 4 storage chunks", 4, 2, 2, (512, 512), 2192, 1104, True, 184.1, "profiles/r4_reh4_chunked_final_schedule.json"),
 ]
 
 
