@@ -694,9 +694,11 @@ void route_fwd_rounds(smashx_plan* p, int off, bool tape, int t0, int T, hipStre
     }
 }
 // the chained rounds in ONE launch (tickets: sx_kernels.h)
-void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st) {
+// inputs_read (optional): recorded on st as soon as the pass has read the last of qtT -- after the copy into the staging rows when the
+// chained launch runs on those (it then touches no buffer of the vertical kernels), else left alone (the caller records after the pass)
+bool route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStream_t st, hipEvent_t inputs_read = nullptr) {
     const int nr = p->sch.nrounds, cf = chain_first(p);
-    if (cf >= nr) return;
+    if (cf >= nr) return false;
     SxDeviceArrays B = view_at(p, off);
     if (!p->dom_q_active) B.qdT = nullptr;
     const size_t lds = (size_t)2 * p->M * sizeof(float4);
@@ -706,17 +708,20 @@ void route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStr
     p->mark_begin(5, st, round_cells(p, cf, nr) * T);       // (the chained launch's time includes its copy pass)
     if (B.qsk)       // the chained groups' inputs -- their cells' runoff, the series handed up to them -- into the staging rows
         hipLaunchKernelGGL((sx_k_chain_transpose<true>), dim3(p->stg_blocks), dim3(64), p->stg_lds, st, B, p->stg, g0, (T + SX_BT - 1) / SX_BT);
+    const bool early = B.qsk && inputs_read && !B.qdT;
+    if (early) (void)hipEventRecord(inputs_read, st);
     if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
     else      hipLaunchKernelGGL((sx_k_route_fwd<false, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
     p->mark_end();
     p->chain_used = true;
+    return early;
 }
 // Routing launches of one pass.  Rounds below chain_first keep one launch per round (they are wide and
 // HBM-bound); the narrow, latency-bound rounds from there on run chained inside a single launch
 // (sx_kernels.h "rounds chained inside one launch"), which turns their sum into roughly the longest of them.
-void route_fwd(smashx_plan* p, int off, bool tape, int t0, int T) {
+bool route_fwd(smashx_plan* p, int off, bool tape, int t0, int T, hipEvent_t inputs_read = nullptr) {
     route_fwd_rounds(p, off, tape, t0, T, p->stream_r);
-    route_fwd_chained(p, off, tape, t0, T, p->stream_r);
+    return route_fwd_chained(p, off, tape, t0, T, p->stream_r, inputs_read);
 }
 void route_adj_chained(smashx_plan* p, int off, int t0, int T, hipStream_t st) {
     const int nr = p->sch.nrounds, cf = chain_first(p);
@@ -1542,6 +1547,7 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
         halo_move(false, false, off, T, st);
         return 0;
     };
+    static const bool early_release = []() { const char* e = getenv("SMASHX_EARLY_RELEASE"); return !(e && e[0] == '0'); }();
     auto forward_chunk = [&](int c, bool tape, bool recompute = false) -> int {
         const int t0c = c * p->Tc, Tcur = chunk_len(p, c), ns = nsub_of(Tcur);
         std::vector<hipEvent_t> ev(ns);
@@ -1562,14 +1568,18 @@ static int sweep_once(smashx_plan* p, int adjoint, float cost_b, bool* stalled_o
             const int off = jb * p->Tp, T = std::min(p->Tp, Tcur - off);
             if (halo && p->n_in > 0 && (rc = inlet_series(c, jb, off, t0c + off, T, recompute, sR))) return rc;
             HIPCHK(hipStreamWaitEvent(sR, ev[jb], 0));
-            route_fwd(p, off, tape, t0c + off, T);
+            // The next pass over this part of the chunk buffers is a vertical kernel that overwrites qt (and, taped, the level tapes --
+            // which no forward routing launch reads): it may start as soon as the routing has READ qt.  With the chained launch on staging
+            // rows that is after round 0 and the copy pass -- the chained launch, a latency chain on a few CUs, then runs under the next
+            // storage chunk's vertical kernel (first pass of a checkpointed sweep: 3 x 3.6 ms at 2048^2); else after the whole pass.
+            if ((int)p->buf_free.size() <= jb) p->buf_free.resize(jb + 1, nullptr);
+            p->buf_free[jb] = p->event();
+            const bool released = route_fwd(p, off, tape, t0c + off, T, early_release ? p->buf_free[jb] : nullptr);
             if (halo && p->n_out > 0 && !recompute) {       // (a recomputed chunk sends nothing: every rank kept what it received)
                 halo_move(true, true, off, T, sR);
                 if ((rc = hook(1, t0c + off, T, sR))) return rc;
             }
-            if ((int)p->buf_free.size() <= jb) p->buf_free.resize(jb + 1, nullptr);
-            p->buf_free[jb] = p->event();
-            HIPCHK(hipEventRecord(p->buf_free[jb], sR));
+            if (!released) HIPCHK(hipEventRecord(p->buf_free[jb], sR));
         }
         return 0;
     };
