@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 
@@ -90,3 +92,43 @@ def test_bench_self_launch_reaches_the_rendezvous_without_a_gpu():
     assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
     assert r.stderr.count("handshake ok (gloo)") == 2 and "rank 0/2" in r.stderr and "rank 1/2" in r.stderr
     assert "no HIP device" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())     # (gloo prints a banner on stdout)
+
+
+def test_pmc_summary_divides_every_family_by_the_cell_steps_it_swept(tmp_path):
+    """tools/pmc_summary.py on a synthetic counter file: FETCH_SIZE (KiB, x2 on gfx950) + WRITE_SIZE summed over all dispatches of a
+    kernel family and divided by the cell-steps bench.py says that family swept -- taped / untaped forward, reverse, and the copy
+    passes of the chained launches (gather: every forward pass, scatter: the reverse pass)."""
+    import json
+    root = ROOT
+    acct = {"grid": [64, 64], "n_chunks": 2, "chunk_steps": 48, "cellsteps": 64 * 64 * 96, "adjoint_sweeps": 2, "forward_sweeps": 1,
+            "per_adjoint_sweep": {"taped_forward": 1000.0, "untaped_forward": 500.0, "reverse": 1000.0},
+            "per_forward_sweep": {"taped_forward": 0.0, "untaped_forward": 1000.0}}
+    bench = tmp_path / "bench.json"
+    bench.write_text(json.dumps({"profile_accounting": acct, "config": {"workload": "synthetic"}}))
+    rows = [("void sx_k_vert_fwd<2, true, true>(SxDeviceArrays, int, int)", 10.0, 20.0),        # taped forward: 2000 cell-steps
+            ("void sx_k_vert_fwd<2, false, true>(SxDeviceArrays, int, int)", 4.0, 8.0),         # untaped: 2 x 500 + 1000 = 2000
+            ("void sx_k_vert_adj<2, true>(SxDeviceArrays, int, int)", 6.0, 2.0),                # reverse: 2000
+            ("void sx_k_chain_transpose<true>(SxDeviceArrays, SxStageTables, int, int)", 1.0, 2.0),    # gather: 4000
+            ("void sx_k_chain_transpose<false>(SxDeviceArrays, SxStageTables, int, int)", 2.0, 4.0)]   # scatter: 2000
+    for i, counter in enumerate(("FETCH_SIZE", "WRITE_SIZE"), 1):
+        d = tmp_path / f"pmc{i}" / "host"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w") as f:
+            f.write("Kernel_Name,Counter_Name,Counter_Value\n")
+            for name, fetch, write in rows:
+                for _ in range(2):                                 # two dispatches each: summed
+                    f.write(f"\"{name}\",{counter},{fetch if counter == 'FETCH_SIZE' else write}\n")
+    out = tmp_path / "out.json"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pmc_summary.py"), str(tmp_path), "--bench", str(bench), "--json", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(out.read_text())
+
+    def per(fetch, write, cs):
+        return (2.0 * 2 * fetch + 2 * write) * 1024.0 / cs
+    assert d["sx_k_vert_fwd"]["hbm_bytes_per_cellstep_corrected"] == pytest.approx(per(10.0, 20.0, 2000.0))
+    assert d["sx_k_vert_fwd_untaped"]["hbm_bytes_per_cellstep_corrected"] == pytest.approx(per(4.0, 8.0, 2000.0))
+    assert d["sx_k_vert_adj"]["hbm_bytes_per_cellstep_corrected"] == pytest.approx(per(6.0, 2.0, 2000.0))
+    assert d["sx_k_chain_transpose_gather"]["hbm_bytes_per_cellstep_corrected"] == pytest.approx(per(1.0, 2.0, 4000.0))
+    assert d["sx_k_chain_transpose_scatter"]["hbm_bytes_per_cellstep_corrected"] == pytest.approx(per(2.0, 4.0, 2000.0))
+    assert d["sx_k_vert_fwd"]["dispatches"] == 2 and d["workload"]["forward_only"] is False
