@@ -246,7 +246,9 @@ struct SxStageTables {
     const int* wb_slot0; const int* wb_n; const int* wb_smin; const int* wb_spread;   // per wave-block
     const int* fifo_g; const int* fifo_s;                                               // per chained slot: FIFO offset (float4) for gather / scatter
 };
+#ifndef SX_STG_PF
 #define SX_STG_PF 16         // rows requested ahead of the one being pushed (the loop is a latency chain: its pace is the load latency / this)
+#endif
 template <bool GATHER>
 __global__ __launch_bounds__(64) void sx_k_chain_transpose(SxDeviceArrays A, SxStageTables S, int g0, int nb) {
     extern __shared__ __attribute__((aligned(16))) float4 sx_fifo[];
