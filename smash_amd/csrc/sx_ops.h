@@ -106,10 +106,11 @@ SX_DEV void sx_transfer(float prcp, float pr, float ct, const SxDiv& dct, float 
 template <int ST>
 SX_DEV float sx_vertical_step(const SxCellParams& P, float prcp, float pet, float& hi, float& hp, float& hft, float& hst, bool still = false) {
     float ei = 0.f, pn = 0.f, en = 0.f, pr = 0.f, perc = 0.f, l = 0.f;
-    if (still) {       // wave-uniform: every lane in a still step (see sx_is_still below)
-        if (ST == 2 || ST == 3) hi = hi + 0.f;        // hi + (prcp - ei - pn) / ci
-        hp = hp + 0.f;                                // hp_imd = hp + (ps - es) / cp;  perc = (hp_imd cp) (1 - 1) = +-0;  hp = hp_imd - perc / cp
-        if (ST != 4) l = P.exc * sx_pow_3p5(hft);     // pr + perc = +0
+    if (still) {       // wave-uniform: every lane in a still step or in a data gap (see sx_is_still below)
+        const bool gap = !(prcp >= 0.f && pet >= 0.f);          // a gap lane does what the general step does for it: nothing here
+        if (ST == 2 || ST == 3) hi = gap ? hi : hi + 0.f;       // hi + (prcp - ei - pn) / ci
+        hp = gap ? hp : hp + 0.f;                     // hp_imd = hp + (ps - es) / cp;  perc = (hp_imd cp) (1 - 1) = +-0;  hp = hp_imd - perc / cp
+        if (ST != 4) { const float lw = P.exc * sx_pow_3p5(hft); l = gap ? 0.f : lw; }     // pr + perc = +0
     } else if (prcp >= 0.f && pet >= 0.f) {
         if (ST == 1 || ST == 4) {
             ei = fminf(pet, prcp);
@@ -154,11 +155,14 @@ SX_DEV float sx_vertical_step(const SxCellParams& P, float prcp, float pet, floa
 // already infinite adjoint, can differ).
 //   needs, per lane: prcp == 0, pet == 0; 0 <= hi <= 1 (then ei = min(0, hi ci) = 0 and pn = max(0, -ci (1 - hi)) = 0, no branch
 //   of GR_INTERCEPTION_B is taken); |hp| < 15 (the percolation power is exactly 1, sx_production_full).
+// Lanes in a data gap (prcp < 0 or pet < 0, md_forward_structure.f90:106) do not keep a wavefront from the short form: the general
+// step skips interception, production and exchange for them, and so does the short one, lane by lane (a gap every thousand cell-steps,
+// as in the synthetic forcing, otherwise sends 6 % of the wavefront-steps -- and a quarter of them would have been still -- the long way).
 template <int ST>
 SX_DEV bool sx_is_still(float prcp, float pet, float hi, float hp) {
     bool s = (prcp == 0.f) & (pet == 0.f) & (fabsf(hp) < 15.f);
     if (ST == 2 || ST == 3) s = s & (hi >= 0.f) & (hi <= 1.f);
-    return s;
+    return s | !(prcp >= 0.f && pet >= 0.f);
 }
 
 // ---------------------------------------------------------------- adjoint
@@ -335,7 +339,7 @@ struct SxAdjParams {   // extra per-cell invariants of the adjoint
 template <int ST>
 SX_DEV void sx_vertical_step_b(const SxCellParams& P, const SxAdjParams& Q, float prcp, float pet, float hi, float hp,
                                float hft, float hst, float qt_b, SxCellGrads& G, bool still = false) {
-    const bool wet = still || (prcp >= 0.f && pet >= 0.f);
+    const bool wet = prcp >= 0.f && pet >= 0.f;         // (per lane, also inside a still wavefront: its gap lanes take the dry path)
     float ei = 0.f, pn = 0.f, en = 0.f, pr = 0.f, perc = 0.f, l = 0.f, prr, prl = 0.f, prd = 0.f;
     float h35 = 0.f, h25 = 0.f;
     SxProd R;
