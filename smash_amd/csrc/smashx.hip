@@ -707,7 +707,7 @@ bool route_fwd_chained(smashx_plan* p, int off, bool tape, int t0, int T, hipStr
     const int grid = g1 - g0;
     p->mark_begin(5, st, round_cells(p, cf, nr) * T);       // (the chained launch's time includes its copy pass)
     if (B.qsk)       // the chained groups' inputs -- their cells' runoff, the series handed up to them -- into the staging rows
-        hipLaunchKernelGGL((sx_k_chain_transpose<true>), dim3(p->stg_blocks), dim3(64), p->stg_lds, st, B, p->stg, g0, (T + SX_BT - 1) / SX_BT);
+        hipLaunchKernelGGL((sx_k_chain_transpose<true>), dim3((p->stg_blocks + SX_STG_WAVES - 1) / SX_STG_WAVES), dim3(64 * SX_STG_WAVES), p->stg_lds * SX_STG_WAVES, st, B, p->stg, g0, (T + SX_BT - 1) / SX_BT, p->stg_blocks, (int)p->stg_lds);
     const bool early = B.qsk && inputs_read && !B.qdT;
     if (early) (void)hipEventRecord(inputs_read, st);
     if (tape) hipLaunchKernelGGL((sx_k_route_fwd<true, true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
@@ -735,7 +735,7 @@ void route_adj_chained(smashx_plan* p, int off, int t0, int T, hipStream_t st) {
     hipLaunchKernelGGL((sx_k_route_adj<true>), dim3(grid), dim3(p->M), lds, st, B, g0, g1, t0, T);
     if (B.qsk)       // qt_b of the chained cells and the adjoint series that leave the chain: from the staging rows to where the vertical kernel,
                      // round 0 and the exchange expect them
-        hipLaunchKernelGGL((sx_k_chain_transpose<false>), dim3(p->stg_blocks), dim3(64), p->stg_lds, st, B, p->stg, g0, (T + SX_BT - 1) / SX_BT);
+        hipLaunchKernelGGL((sx_k_chain_transpose<false>), dim3((p->stg_blocks + SX_STG_WAVES - 1) / SX_STG_WAVES), dim3(64 * SX_STG_WAVES), p->stg_lds * SX_STG_WAVES, st, B, p->stg, g0, (T + SX_BT - 1) / SX_BT, p->stg_blocks, (int)p->stg_lds);
     p->mark_end();
     p->chain_used = true;
 }
@@ -942,12 +942,16 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
                         slot0.push_back(sb + o); cnt.push_back(nl); smn.push_back(lo); spr.push_back(hi - lo);
                     }
                 }
-                if (lds <= 64 * 1024 && !slot0.empty()) {      // (a schedule whose wave-blocks span more stages than that keeps the plain rows)
+                if (lds * SX_STG_WAVES <= 160 * 1024 && lds <= 64 * 1024 && !slot0.empty()) {      // (a schedule whose wave-blocks span more stages than that keeps the plain rows)
                     int *d0, *d1, *d2, *d3, *d4, *d5;
                     TRY(p->upload_vec(&d0, slot0)); TRY(p->upload_vec(&d1, cnt)); TRY(p->upload_vec(&d2, smn)); TRY(p->upload_vec(&d3, spr));
                     TRY(p->upload_vec(&d4, fg)); TRY(p->upload_vec(&d5, fs));
                     p->stg = SxStageTables{d0, d1, d2, d3, d4, d5};
-                    p->stg_blocks = (int)slot0.size(); p->stg_rows_extra = extra; p->stg_lds = lds;
+                    p->stg_blocks = (int)slot0.size(); p->stg_rows_extra = extra; p->stg_lds = (lds + 15) / 16 * 16;
+                    if (p->stg_lds * SX_STG_WAVES > 48 * 1024) {       // beyond the default limit of dynamic LDS
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sx_k_chain_transpose<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(p->stg_lds * SX_STG_WAVES));
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sx_k_chain_transpose<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(p->stg_lds * SX_STG_WAVES));
+                    }
                     A.cs0 = cs0; A.ncs = ncs;
                 }
             }

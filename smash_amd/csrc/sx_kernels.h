@@ -235,8 +235,8 @@ struct SxDeviceArrays {
 // the FIFO heads (1 KiB contiguous).  A lane only ever touches its own FIFO: no barrier, no cross-lane traffic.  The reverse sweep
 // runs the mirror image (GATHER = false): qt_b of the chained cells and the adjoint series of their inlets leave the staging rows
 // for qtT / xT.  Series between two chained groups (produced and consumed inside the launch, behind the counters) keep their plain rows.
-// Measured at 2048^2 (644 k chained slots x 548 time blocks, 11.3 GB per pass): 3.05 ms gather, 2.8 ms scatter beside a vertical
-// kernel that takes 2.8 TB/s itself -- the pair saturates HBM.  A plan takes the staging rows only when it has at least two chained
+// Measured at 2048^2 (644 k chained slots x 548 time blocks, 11.3 GB per pass): 2.75 ms gather, 2.26 ms scatter (four wave-blocks per
+// workgroup; 3.06 / 2.72 with one).  A plan takes the staging rows only when it has at least two chained
 // groups per compute unit (smashx.hip): below that the chained launch is bound by the latency of its chain and gains less than the
 // copies cost.
 // Tables (host, smashx.hip): per wave-block the first slot, the slot count, the lowest stage and the stage spread; per chained slot
@@ -249,10 +249,18 @@ struct SxStageTables {
 #ifndef SX_STG_PF
 #define SX_STG_PF 16         // rows requested ahead of the one being pushed (the loop is a latency chain: its pace is the load latency / this)
 #endif
+// SX_STG_WAVES consecutive wave-blocks per workgroup: wavefronts that start together and advance at the same pace visit a row's
+// neighbouring KiB together (DRAM pages, TLB entries: a row is 10 - 67 MB from the next)
+#ifndef SX_STG_WAVES
+#define SX_STG_WAVES 4
+#endif
 template <bool GATHER>
-__global__ __launch_bounds__(64) void sx_k_chain_transpose(SxDeviceArrays A, SxStageTables S, int g0, int nb) {
-    extern __shared__ __attribute__((aligned(16))) float4 sx_fifo[];
-    const int b = blockIdx.x, L = threadIdx.x;
+__global__ __launch_bounds__(64 * SX_STG_WAVES) void sx_k_chain_transpose(SxDeviceArrays A, SxStageTables S, int g0, int nb, int nblocks, int lds_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) float4 sx_fifo_all[];
+    const int wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * SX_STG_WAVES + wv, L = threadIdx.x & 63;
+    if (b >= nblocks) return;
+    float4* const sx_fifo = sx_fifo_all + (size_t)wv * (lds_per_wave / 16);
     const int nL = S.wb_n[b], smin = S.wb_smin[b], spread = S.wb_spread[b];
     const bool lane = L < nL;
     const int sl = S.wb_slot0[b] + (lane ? L : 0), cs = sl - A.cs0;
