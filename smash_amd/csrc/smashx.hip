@@ -948,11 +948,14 @@ int smashx_plan_create(const smashx_config* cfg, const smashx_mesh* mesh, smashx
                     TRY(p->upload_vec(&d4, fg)); TRY(p->upload_vec(&d5, fs));
                     p->stg = SxStageTables{d0, d1, d2, d3, d4, d5};
                     p->stg_blocks = (int)slot0.size(); p->stg_rows_extra = extra; p->stg_lds = (lds + 15) / 16 * 16;
-                    if (p->stg_lds * SX_STG_WAVES > 48 * 1024) {       // beyond the default limit of dynamic LDS
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sx_k_chain_transpose<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(p->stg_lds * SX_STG_WAVES));
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sx_k_chain_transpose<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(p->stg_lds * SX_STG_WAVES));
-                    }
-                    A.cs0 = cs0; A.ncs = ncs;
+                    // the copy kernels may use all of a CU's LDS (160 KiB; the attribute belongs to the kernel, not to the plan: the same
+                    // value for every plan of the process).  Where that is refused, a plan that needs more than the default keeps the plain rows
+                    static const bool lds_ok = []() {
+                        return hipFuncSetAttribute(reinterpret_cast<const void*>(&sx_k_chain_transpose<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess
+                            && hipFuncSetAttribute(reinterpret_cast<const void*>(&sx_k_chain_transpose<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+                    }();
+                    if (lds_ok || p->stg_lds * SX_STG_WAVES <= 48 * 1024) { A.cs0 = cs0; A.ncs = ncs; }
+                    else (void)hipGetLastError();
                 }
             }
         }
